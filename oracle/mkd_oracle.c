@@ -1,0 +1,606 @@
+/*
+ * mkd_oracle.c -- CPU restatement of the reference's MKD descriptor path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under local-features_amd/ (the product) may
+ * include, link or call this file.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, and only as the checker / the timed CPU
+ * baseline ("port").
+ *
+ * PARITY UNPINNED by the reference: tnibler/local-features ships no golden
+ * vectors, no known-answer tests and no runnable implementation of this path in
+ * this environment (Rust + Vulkan; its only tests are commented out and name
+ * absent files, local_features/src/mkd_ref.rs:393-453).  What pins this file
+ * instead is tools/gen_golden.py: an independent NumPy float64 restatement
+ * written from the same sources, which must agree with this one to < 1e-5
+ * relative L2 per descriptor (tests/test_oracle.py), and whose outputs are
+ * committed under tests/golden/.
+ *
+ * Every function cites the reference file:line it follows.  Paths are relative
+ * to /root/reference/local_features/src/ ("shaders/" = vulkan/shaders/).
+ *
+ * All arithmetic is IEEE f32; build with -ffp-contract=off so that a*b+c is a
+ * rounded multiply followed by a rounded add, as the Rust CPU twin does.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PS 32           /* PATCH_SIZE            shaders/common.glsl:19 */
+#define NPX (PS * PS)
+#define DIMS_IN 7       /* DIMS_INPUT            shaders/common.glsl:22 */
+#define D_CART 9        /* DIMS_EMB_CARTESIAN    shaders/common.glsl:23 */
+#define D_POLAR 25      /* DIMS_EMB_POLAR        shaders/common.glsl:24 */
+#define RAW 238         /* DESCRIPTOR_SIZE       shaders/common.glsl:33 */
+#define OUT 128         /* PCAD_DESCRIPTOR_SIZE  shaders/common.glsl:20 */
+
+#define ATAN_SHADER 0   /* polynomial atan2 incl. its quirks (parity gate)  */
+#define ATAN_LIBM 1     /* exact atan2f, as the CPU twin mkd_ref.rs:140     */
+
+/* mkd_ref.rs:7-9 */
+static const float VM_N3_K8[4] = {0.37872374f, 0.51796234f, 0.46882015f, 0.39798096f};
+static const float VM_N1_K1[2] = {0.618176f, 0.6934725f};
+static const float VM_N2_K8[3] = {0.37872374f, 0.51796234f, 0.46882015f};
+
+/* Layout of ConstantData, shaders/common.glsl:34-40 */
+typedef struct {
+    float gradient_angle[NPX];
+    float embedding_polar[D_POLAR * NPX];
+    float embedding_cartesian[D_CART * NPX];
+    float mean_vec[RAW];
+    float eigen_vecs[OUT * RAW]; /* W_T row-major [128][238] */
+} mkd_consts;
+
+/* ------------------------------------------------------------------------- */
+/* LUT builders: mkd_ref.rs:173-267                                          */
+/* ------------------------------------------------------------------------- */
+
+/* mkd_ref.rs:173-185 mesh_grid: grid[0]=x coordinate, grid[1]=y coordinate */
+static void mesh_grid(float *gx, float *gy)
+{
+    for (int y = 0; y < PS; y++)
+        for (int x = 0; x < PS; x++) {
+            gx[y * PS + x] = 2.f * (float)x / ((float)PS - 1.f) - 1.f;
+            gy[y * PS + x] = 2.f * (float)y / ((float)PS - 1.f) - 1.f;
+        }
+}
+
+/* mkd_ref.rs:133-144 cart2pol: mag=sqrt(x^2+y^2+eps), angle=-atan2(y,x) */
+static void cart2pol(const float *x, const float *y, float *mag, float *ang)
+{
+    const float eps = 1e-8f;
+    for (int i = 0; i < NPX; i++) {
+        mag[i] = sqrtf(x[i] * x[i] + y[i] * y[i] + eps);
+        ang[i] = -atan2f(y[i], x[i]);
+    }
+}
+
+/* mkd_ref.rs:146-171 von_mises: [c0, c_k cos(k t), c_k sin(k t)] k=1..n */
+static void von_mises(const float *t, const float *coeffs, int n, float *out /*[2n+1][NPX]*/)
+{
+    for (int i = 0; i < NPX; i++) {
+        out[i] = 1.f * coeffs[0];
+        for (int k = 1; k <= n; k++) {
+            const float a = t[i] * (float)k;
+            out[k * NPX + i] = cosf(a) * coeffs[k];
+            out[(n + k) * NPX + i] = sinf(a) * coeffs[k];
+        }
+    }
+}
+
+/* mkd_ref.rs:259-267 gaussian_weighting */
+static void gaussian_weighting(float *g)
+{
+    float gx[NPX], gy[NPX], norm[NPX];
+    mesh_grid(gx, gy);
+    float mx = 0.f;
+    for (int i = 0; i < NPX; i++) {
+        norm[i] = sqrtf(gx[i] * gx[i] + gy[i] * gy[i]);
+        if (norm[i] > mx) mx = norm[i];
+    }
+    for (int i = 0; i < NPX; i++) {
+        const float nn = norm[i] / mx;
+        g[i] = expf((nn * nn) / -(1.f * 1.f));
+    }
+}
+
+/* mkd_ref.rs:210-231 spatial_kernel_embedding_cart, times the Gaussian
+ * (vulkan/mod.rs:1614-1615) */
+static void build_embedding_cart(float *ec /*[9][NPX]*/)
+{
+    float gx[NPX], gy[NPX], g[NPX];
+    static float ea[3 * NPX], eb[3 * NPX];
+    mesh_grid(gx, gy);
+    for (int i = 0; i < NPX; i++) {
+        gx[i] *= 1.57079632679489661923f;
+        gy[i] *= 1.57079632679489661923f;
+    }
+    von_mises(gx, VM_N1_K1, 1, ea);
+    von_mises(gy, VM_N1_K1, 1, eb);
+    gaussian_weighting(g);
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++)
+            for (int i = 0; i < NPX; i++)
+                ec[(a * 3 + b) * NPX + i] = (ea[a * NPX + i] * eb[b * NPX + i]) * g[i];
+}
+
+/* mkd_ref.rs:233-257 spatial_kernel_embedding_polar, times the Gaussian
+ * (vulkan/mod.rs:1616-1617) */
+static void build_embedding_polar(float *ep /*[25][NPX]*/)
+{
+    float gx[NPX], gy[NPX], rho[NPX], phi[NPX], g[NPX];
+    static float ea[5 * NPX], eb[5 * NPX];
+    mesh_grid(gx, gy);
+    cart2pol(gx, gy, rho, phi);
+    for (int i = 0; i < NPX; i++) {
+        rho[i] = rho[i] * 3.14159265358979323846f / 1.41421356237309504880f;
+        phi[i] = phi[i] * -1.f;
+    }
+    von_mises(phi, VM_N2_K8, 2, ea);
+    von_mises(rho, VM_N2_K8, 2, eb);
+    gaussian_weighting(g);
+    for (int a = 0; a < 5; a++)
+        for (int b = 0; b < 5; b++)
+            for (int i = 0; i < NPX; i++)
+                ep[(a * 5 + b) * NPX + i] = (ea[a * NPX + i] * eb[b * NPX + i]) * g[i];
+}
+
+/* vulkan/mod.rs:1594-1619 upload_constant_data: everything the shaders read */
+void mkd_oracle_build_consts(const float *mean, const float *eigvals, const float *eigvecs,
+                             mkd_consts *c)
+{
+    float gx[NPX], gy[NPX], mag[NPX];
+    mesh_grid(gx, gy);
+    cart2pol(gx, gy, mag, c->gradient_angle); /* mod.rs:1618-1619 */
+    build_embedding_polar(c->embedding_polar);
+    build_embedding_cart(c->embedding_cartesian);
+    memcpy(c->mean_vec, mean, sizeof(float) * RAW);
+    /* mod.rs:1604-1612: t=0.7, m=-0.5t, W = eigvecs[:, :128]*eigvals[:128]^m, stored transposed */
+    const float t = 0.7f;
+    const float m = -0.5f * t;
+    for (int r = 0; r < OUT; r++) {
+        const float s = powf(eigvals[r], m);
+        for (int col = 0; col < RAW; col++)
+            c->eigen_vecs[r * RAW + col] = eigvecs[col * RAW + r] * s;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* safetensors reader: mkd_ref.rs:352-391 (format: 8-byte LE header length,   */
+/* JSON header, raw little-endian F32 tensors; crate safetensors 0.5.2,       */
+/* Cargo.lock:3214-3216, is not in the reference tree -- format restated)     */
+/* ------------------------------------------------------------------------- */
+static int st_find(const char *hdr, const char *name, long *begin, long *end)
+{
+    char key[64];
+    snprintf(key, sizeof key, "\"%s\"", name);
+    const char *p = strstr(hdr, key);
+    if (!p) return -1;
+    p = strstr(p, "\"data_offsets\"");
+    if (!p) return -1;
+    p = strchr(p, '[');
+    if (!p) return -1;
+    if (sscanf(p, "[%ld,%ld]", begin, end) != 2) return -1;
+    return 0;
+}
+
+int mkd_oracle_load_pca(const char *path, float *mean, float *eigvals, float *eigvecs)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    uint64_t hlen = 0;
+    if (fread(&hlen, 8, 1, f) != 1 || hlen > (1u << 20)) { fclose(f); return -2; }
+    char *hdr = (char *)calloc(hlen + 1, 1);
+    if (fread(hdr, 1, hlen, f) != hlen) { free(hdr); fclose(f); return -2; }
+    const struct { const char *name; float *dst; long n; } t[3] = {
+        {"mean", mean, RAW}, {"eigvals", eigvals, RAW}, {"eigvecs", eigvecs, RAW * RAW}};
+    int rc = 0;
+    for (int i = 0; i < 3 && rc == 0; i++) {
+        long b, e;
+        if (st_find(hdr, t[i].name, &b, &e) || e - b != t[i].n * 4) { rc = -3; break; }
+        fseek(f, 8 + (long)hlen + b, SEEK_SET);
+        if (fread(t[i].dst, 4, t[i].n, f) != (size_t)t[i].n) rc = -4;
+    }
+    free(hdr);
+    fclose(f);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* shaders/atan2.glsl:19-46.  Signature atan2(x, y): angle of the point (x,y) */
+/* ------------------------------------------------------------------------- */
+static float glsl_sign(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+float mkd_oracle_atan2_shader(float x, float y)
+{
+    const float A1 = 0.99997726f, A3 = -0.33262347f, A5 = 0.19354346f, A7 = -0.11643287f,
+                A9 = 0.05265332f, A11 = -0.0117212f;
+    const float PI_F = 3.1415927f, FRAC_PI_2 = 1.5707964f;
+    if (x == 0.f && y == 0.f) return 0.f;
+    const int swap = fabsf(x) < fabsf(y);
+    const float a = swap ? (x / y) : (y / x);
+    const float asq = a * a;
+    const float atan_res =
+        a * (A1 + asq * (A3 + asq * (A5 + asq * (A7 + asq * (A9 + asq * A11)))));
+    /* sign(a) is 0 when a == 0: atan2(0, y!=0) returns 0, not +-pi/2 (lines 33-38) */
+    const float res = swap ? (FRAC_PI_2 * glsl_sign(a) - atan_res) : atan_res;
+    if (glsl_sign(x) == -1.f) {
+        /* bits(sign(y)) | bits(1.0): -1 for y<0, +1 otherwise (y==0 -> +1) */
+        const float sign_y = (glsl_sign(y) == -1.f) ? -1.f : 1.f;
+        return PI_F * sign_y + res;
+    }
+    return res;
+}
+
+/* ------------------------------------------------------------------------- */
+/* shaders/mkd/patch_gradients.glsl:20-28,72-104 (blur + gradient + polar)    */
+/* CPU twin: mkd_ref.rs:82-144,304-307                                        */
+/* ------------------------------------------------------------------------- */
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+void mkd_oracle_patch_gradients(const float *patch, float *mag, float *angle, int atan_mode)
+{
+    static const float k[5] = {0.0096f, 0.2054f, 0.5699f, 0.2054f, 0.0096f};
+    float tmp[NPX], blur[NPX];
+    for (int y = 0; y < PS; y++) /* vertical pass, lines 72-81 */
+        for (int x = 0; x < PS; x++) {
+            float sum = 0.f;
+            for (int i = 0; i < 5; i++) {
+                const int yy = clampi(y + i - 2, 0, PS - 1);
+                sum += k[i] * patch[yy * PS + x];
+            }
+            tmp[y * PS + x] = sum;
+        }
+    for (int y = 0; y < PS; y++) /* horizontal pass, lines 83-92 */
+        for (int x = 0; x < PS; x++) {
+            float sum = 0.f;
+            for (int i = 0; i < 5; i++) {
+                const int xx = clampi(x + i - 2, 0, PS - 1);
+                sum += k[i] * tmp[y * PS + xx];
+            }
+            blur[y * PS + x] = sum;
+        }
+    for (int y = 0; y < PS; y++)
+        for (int x = 0; x < PS; x++) {
+            /* lines 94-96: gx = left - right, gy = down - up, replicate border */
+            const float gx = blur[y * PS + clampi(x, 1, PS - 1) - 1] -
+                             blur[y * PS + clampi(x, 0, PS - 2) + 1];
+            const float gy = blur[(clampi(y, 0, PS - 2) + 1) * PS + x] -
+                             blur[(clampi(y, 1, PS - 1) - 1) * PS + x];
+            /* lines 98-101: mag = sqrt(sqrt(.)), the outer sqrt hoisted from the embedding */
+            mag[y * PS + x] = sqrtf(sqrtf(gx * gx + gy * gy + 1e-8f));
+            angle[y * PS + x] = (atan_mode == ATAN_SHADER) ? -mkd_oracle_atan2_shader(gx, gy)
+                                                           : -atan2f(gy, gx);
+        }
+}
+
+/* shaders/mkd/embedding.glsl:34-51 von_mises_n3k8 */
+static float von_mises_n3k8(int i, float ori, float mag)
+{
+    if (i == 0) return VM_N3_K8[0] * mag;
+    if (i < 4) return cosf((float)i * ori) * VM_N3_K8[i] * mag;
+    return sinf(((float)i - 3.f) * ori) * VM_N3_K8[i - 3] * mag;
+}
+
+/* Sum 64 per-thread partial sums the way a 64-wide subgroupAdd tree would.
+ * The reference leaves the order to the driver (embedding.glsl:90-111). */
+static float tree64(float *v)
+{
+    for (int s = 32; s > 0; s >>= 1)
+        for (int i = 0; i < s; i++) v[i] += v[i + s];
+    return v[0];
+}
+
+/* shaders/mkd/embedding.glsl:53-121: pooled[i*D+j] = sum_px vm_i(px) * E_j(px).
+ * One 32x2 workgroup per in_dim: thread (lx,ly) walks rows ly, ly+2, ... */
+static void embed_pool(const float *mag, const float *angle, const float *phi /*or NULL*/,
+                       const float *lut, int D, float *out /*[7*D]*/)
+{
+    for (int i = 0; i < DIMS_IN; i++) {
+        static __thread float part[D_POLAR][64];
+        memset(part, 0, sizeof part);
+        for (int row = 0; row < PS; row += 2)
+            for (int ly = 0; ly < 2; ly++)
+                for (int lx = 0; lx < PS; lx++) {
+                    const int px = (row + ly) * PS + lx;
+                    const float ori = phi ? angle[px] + phi[px] : angle[px];
+                    const float g = von_mises_n3k8(i, ori, mag[px]);
+                    for (int j = 0; j < D; j++) part[j][ly * PS + lx] += g * lut[j * NPX + px];
+                }
+        for (int j = 0; j < D; j++) out[i * D + j] = tree64(part[j]);
+    }
+}
+
+/* shaders/mkd/normalize.glsl:22-142; CPU twin mkd_ref.rs:313-326 */
+static void normalize_raw(const float *polar, const float *cart, float *raw)
+{
+    float sp = 0.f, sc = 0.f;
+    for (int i = 0; i < DIMS_IN * D_POLAR; i++) sp += polar[i] * polar[i];
+    for (int i = 0; i < DIMS_IN * D_CART; i++) sc += cart[i] * cart[i];
+    const float np = sqrtf(sp), nc = sqrtf(sc);
+    float s = 0.f;
+    for (int i = 0; i < RAW; i++) {
+        const float v = i < DIMS_IN * D_POLAR ? polar[i] / np : cart[i - DIMS_IN * D_POLAR] / nc;
+        raw[i] = v;
+        s += v * v;
+    }
+    const float n = sqrtf(s);
+    for (int i = 0; i < RAW; i++) raw[i] = raw[i] / n;
+}
+
+/* shaders/mkd/whitening.glsl:22-77 + normalize_final.glsl:17-59 */
+static void whiten(const mkd_consts *c, const float *raw, float *out)
+{
+    float vec[RAW];
+    for (int i = 0; i < RAW; i++) vec[i] = raw[i] - c->mean_vec[i];
+    float s = 0.f;
+    for (int r = 0; r < OUT; r++) {
+        float acc = 0.f;
+        for (int col = 0; col < RAW; col += 64) { /* one subgroupAdd per 64-column chunk */
+            float p[64];
+            for (int l = 0; l < 64; l++)
+                p[l] = (col + l < RAW) ? vec[col + l] * c->eigen_vecs[r * RAW + col + l] : 0.f;
+            acc += tree64(p);
+        }
+        out[r] = acc;
+        s += acc * acc;
+    }
+    const float n = sqrtf(s);
+    for (int r = 0; r < OUT; r++) out[r] = out[r] / n;
+}
+
+/* One patch through rows 3-9 of SURVEY.md section 8(a). raw238 may be NULL. */
+void mkd_oracle_describe_patch(const mkd_consts *c, const float *patch, float *desc128,
+                               float *raw238, int atan_mode)
+{
+    float mag[NPX], ang[NPX], polar[DIMS_IN * D_POLAR], cart[DIMS_IN * D_CART], raw[RAW];
+    mkd_oracle_patch_gradients(patch, mag, ang, atan_mode);
+    embed_pool(mag, ang, c->gradient_angle, c->embedding_polar, D_POLAR, polar);
+    embed_pool(mag, ang, NULL, c->embedding_cartesian, D_CART, cart);
+    normalize_raw(polar, cart, raw);
+    if (raw238) memcpy(raw238, raw, sizeof raw);
+    if (desc128) whiten(c, raw, desc128);
+}
+
+typedef struct {
+    const mkd_consts *c;
+    const float *patches;
+    float *desc, *raw;
+    long begin, end;
+    int atan_mode;
+} job_t;
+
+static void *worker(void *arg)
+{
+    job_t *j = (job_t *)arg;
+    for (long i = j->begin; i < j->end; i++)
+        mkd_oracle_describe_patch(j->c, j->patches + i * NPX, j->desc ? j->desc + i * OUT : NULL,
+                                  j->raw ? j->raw + i * RAW : NULL, j->atan_mode);
+    return NULL;
+}
+
+/* Batch entry point; nthreads>1 partitions patches over pthreads (CPU baseline). */
+void mkd_oracle_describe_patches(const mkd_consts *c, const float *patches, long n, float *desc128,
+                                 float *raw238, int atan_mode, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    job_t jobs[256];
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t] = (job_t){c, patches, desc128, raw238, n * t / nthreads, n * (t + 1) / nthreads,
+                          atan_mode};
+        if (nthreads == 1) worker(&jobs[t]);
+        else pthread_create(&th[t], NULL, worker, &jobs[t]);
+    }
+    if (nthreads > 1)
+        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Keypoint mode: patch pyramid + rotated/scaled bilinear sampling            */
+/* ------------------------------------------------------------------------- */
+
+/* Sampler: linear filter, MirroredRepeat (vulkan/mod.rs:940-943).  Exact-f32
+ * restatement of VK bilinear filtering at unnormalised coordinate u (texel
+ * centres at i+0.5): texels floor(u-0.5), +1, weight frac(u-0.5).  The weight
+ * precision of real samplers is implementation-defined. */
+static int mirror(int i, int n)
+{
+    const int p = 2 * n;
+    int m = i % p;
+    if (m < 0) m += p;
+    return m < n ? m : p - 1 - m;
+}
+
+static float tex_bilinear(const float *img, int w, int h, float u, float v)
+{
+    const float fu = u - 0.5f, fv = v - 0.5f;
+    const float x0f = floorf(fu), y0f = floorf(fv);
+    const float ax = fu - x0f, ay = fv - y0f;
+    const int x0 = mirror((int)x0f, w), x1 = mirror((int)x0f + 1, w);
+    const int y0 = mirror((int)y0f, h), y1 = mirror((int)y0f + 1, h);
+    const float t00 = img[y0 * w + x0], t10 = img[y0 * w + x1];
+    const float t01 = img[y1 * w + x0], t11 = img[y1 * w + x1];
+    const float top = t00 * (1.f - ax) + t10 * ax;
+    const float bot = t01 * (1.f - ax) + t11 * ax;
+    return top * (1.f - ay) + bot * ay;
+}
+
+/* shaders/blur.glsl:18-64: sigma 0.6 Gaussian as 3 bilinear fetches per pass,
+ * H pass (layer0 -> layer1) then V pass (layer1 -> layer0);
+ * dispatch vulkan/tasks_detect.rs:150-161 */
+static void blur_sigma06(const float *in, int w, int h, float *tmp, float *out)
+{
+    const float W0 = 0.66381836f, W1 = 0.16809084f, OFF = 0.015267163f;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const float cx = (float)x + 0.5f, cy = (float)y + 0.5f, o = 1.f + OFF;
+            float sum = tex_bilinear(in, w, h, cx, cy) * W0;
+            sum += (tex_bilinear(in, w, h, cx - o, cy) + tex_bilinear(in, w, h, cx + o, cy)) * W1;
+            tmp[y * w + x] = sum;
+        }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const float cx = (float)x + 0.5f, cy = (float)y + 0.5f, o = 1.f + OFF;
+            float sum = tex_bilinear(tmp, w, h, cx, cy) * W0;
+            sum += (tex_bilinear(tmp, w, h, cx, cy - o) + tex_bilinear(tmp, w, h, cx, cy + o)) * W1;
+            out[y * w + x] = sum;
+        }
+}
+
+/* shaders/swt.glsl:18-57 with in_level=0: B3-spline [1,4,6,4,1]/16, dilation 1,
+ * H (layer 0 -> scratch) then V (scratch -> layer 1).  Taps land on texel
+ * centres, so the fetches are plain texel reads with mirrored addressing. */
+static void swt_level0(const float *in, int w, int h, float *tmp, float *out)
+{
+    const float K0 = 6.f / 16.f, K1 = 4.f / 16.f, K2 = 1.f / 16.f;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float sum = in[y * w + x] * K0;
+            sum += in[y * w + mirror(x - 2, w)] * K2;
+            sum += in[y * w + mirror(x - 1, w)] * K1;
+            sum += in[y * w + mirror(x + 1, w)] * K1;
+            sum += in[y * w + mirror(x + 2, w)] * K2;
+            tmp[y * w + x] = sum;
+        }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float sum = tmp[y * w + x] * K0;
+            sum += tmp[mirror(y - 1, h) * w + x] * K1;
+            sum += tmp[mirror(y - 2, h) * w + x] * K2;
+            sum += tmp[mirror(y + 2, h) * w + x] * K2;
+            sum += tmp[mirror(y + 1, h) * w + x] * K1;
+            out[y * w + x] = sum;
+        }
+}
+
+/* Level geometry: content of level l is (w >> l) x (h >> l)
+ * (vulkan/patch_pyramid.rs:179-180, mip sizes vulkan/mod.rs:840-852 with
+ * max_image == image, which every caller in the reference uses). */
+int mkd_oracle_pyramid_levels(int w, int h)
+{
+    /* vulkan/mod.rs:372-373: ceil(log2(min(w,h))) */
+    const float m = (float)(w < h ? w : h);
+    return (int)roundf(ceilf(log2f(m)));
+}
+
+long mkd_oracle_pyramid_floats(int w, int h)
+{
+    long n = 0;
+    const int L = mkd_oracle_pyramid_levels(w, h);
+    for (int l = 0; l < L; l++) {
+        const int lw = (w >> l) > 0 ? (w >> l) : 1, lh = (h >> l) > 0 ? (h >> l) : 1;
+        n += (long)lw * lh;
+    }
+    return n;
+}
+
+/* Build the patch pyramid into `pyr` (levels packed back to back, level l is
+ * (w>>l)x(h>>l) row-major).  vulkan/patch_pyramid.rs:38-156,232-289,
+ * shaders/blur_pyramid.glsl:24-62. */
+void mkd_oracle_build_pyramid(const float *img, int w, int h, float *pyr)
+{
+    const int L = mkd_oracle_pyramid_levels(w, h);
+    float *tmp = (float *)malloc(sizeof(float) * w * h);
+    float *coarse1 = (float *)malloc(sizeof(float) * w * h);
+    float *lvl0 = pyr;
+    blur_sigma06(img, w, h, tmp, lvl0); /* level 0 = coarse layer 0 (Nearest blit 1:1) */
+    long off = (long)w * h;
+    int pw = w, ph = h;
+    const float *prev = lvl0;
+    for (int l = 1; l < L; l++) {
+        const int lw = (w >> l) > 0 ? (w >> l) : 1, lh = (h >> l) > 0 ? (h >> l) : 1;
+        float *dst = pyr + off;
+        if (l == 1) {
+            /* coarse layer 1 = one a-trous pass over layer 0, then a Nearest blit
+             * from [0,w)x[0,h) to [0,w/2)x[0,h/2): source texel floor((i+.5)*w/(w/2))
+             * (patch_pyramid.rs:74-96,251-285) */
+            swt_level0(lvl0, w, h, tmp, coarse1);
+            const int dw = w / 2, dh = h / 2;
+            for (int y = 0; y < lh; y++)
+                for (int x = 0; x < lw; x++) {
+                    int sx = (int)floorf(((float)x + 0.5f) * (float)w / (float)dw);
+                    int sy = (int)floorf(((float)y + 0.5f) * (float)h / (float)dh);
+                    if (sx > w - 1) sx = w - 1;
+                    if (sy > h - 1) sy = h - 1;
+                    dst[y * lw + x] = coarse1[sy * w + sx];
+                }
+        } else if (pw / 2 >= 1 && ph / 2 >= 1) {
+            /* blur_pyramid.glsl: H pass at full resolution of level l-1 ... */
+            const float W0 = 0.375f, W1 = 0.3125f, O = 1.2f;
+            for (int y = 0; y < ph; y++)
+                for (int x = 0; x < pw; x++) {
+                    const float cx = (float)x + 0.5f, cy = (float)y + 0.5f;
+                    const float s = tex_bilinear(prev, pw, ph, cx, cy) * W0 +
+                                    (tex_bilinear(prev, pw, ph, cx - O, cy) +
+                                     tex_bilinear(prev, pw, ph, cx + O, cy)) * W1;
+                    tmp[y * pw + x] = s;
+                }
+            /* ... then V pass centred on texel (2x, 2y) of the H result */
+            for (int y = 0; y < lh; y++)
+                for (int x = 0; x < lw; x++) {
+                    const float cx = 2.f * (float)x + 0.5f, cy = 2.f * (float)y + 0.5f;
+                    const float s = tex_bilinear(tmp, pw, ph, cx, cy) * W0 +
+                                    (tex_bilinear(tmp, pw, ph, cx, cy - O) +
+                                     tex_bilinear(tmp, pw, ph, cx, cy + O)) * W1;
+                    dst[y * lw + x] = s;
+                }
+        } else {
+            for (long i = 0; i < (long)lw * lh; i++) dst[i] = prev[0];
+        }
+        prev = dst;
+        pw = lw;
+        ph = lh;
+        off += (long)lw * lh;
+    }
+    free(tmp);
+    free(coarse1);
+}
+
+/* shaders/mkd/patch_gradients.glsl:42-70: sample one 32x32 patch.
+ * kp = {x, y, size, angle_deg}.  Level clamped to [0, L-1] (the detector never
+ * emits sizes below 1.64). */
+void mkd_oracle_sample_patch(const float *pyr, int w, int h, const float *kp,
+                             float patch_scale_factor, float *patch)
+{
+    const int L = mkd_oracle_pyramid_levels(w, h);
+    const float scale = kp[2] * patch_scale_factor / (float)PS;
+    const float log2_scale = log2f(scale);
+    float lvl = floorf(log2_scale);
+    if (lvl < 0.f) lvl = 0.f;
+    if (lvl > (float)(L - 1)) lvl = (float)(L - 1);
+    const float rem_scale = exp2f(log2_scale - lvl);
+    const int l = (int)lvl;
+    long off = 0;
+    for (int i = 0; i < l; i++) {
+        const int lw = (w >> i) > 0 ? (w >> i) : 1, lh = (h >> i) > 0 ? (h >> i) : 1;
+        off += (long)lw * lh;
+    }
+    const int lw = (w >> l) > 0 ? (w >> l) : 1, lh = (h >> l) > 0 ? (h >> l) : 1;
+    const float *img = pyr + off;
+    const float ang = kp[3] * (3.14159265358979323846f / 180.f); /* radians() */
+    const float ca = cosf(ang), sa = sinf(ang);
+    const float inv = 1.f / exp2f(lvl);
+    for (int ly = 0; ly < PS; ly++)
+        for (int lx = 0; lx < PS; lx++) {
+            const float dx = (float)lx - 16.f, dy = (float)ly - 16.f;
+            const float xx = dx * ca - dy * sa;
+            const float yy = dx * sa + dy * ca;
+            const float sx = xx * rem_scale + kp[0] * inv;
+            const float sy = yy * rem_scale + kp[1] * inv;
+            /* textureLod at ((s+0.5)/size): unnormalised coordinate s+0.5 */
+            patch[ly * PS + lx] = tex_bilinear(img, lw, lh, sx + 0.5f, sy + 0.5f);
+        }
+}
+
+void mkd_oracle_sample_patches(const float *pyr, int w, int h, const float *kps /*[n][4]*/, long n,
+                               float patch_scale_factor, float *patches)
+{
+    for (long i = 0; i < n; i++)
+        mkd_oracle_sample_patch(pyr, w, h, kps + 4 * i, patch_scale_factor, patches + i * NPX);
+}
+
+unsigned long mkd_oracle_sizeof_consts(void) { return sizeof(mkd_consts); }

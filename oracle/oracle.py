@@ -1,0 +1,139 @@
+"""ctypes front end of the CPU oracle (oracle/mkd_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product (local-features_amd/) never imports it.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libmkd_oracle.so")
+
+ATAN_SHADER = 0
+ATAN_LIBM = 1
+
+_fp = ctypes.POINTER(ctypes.c_float)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class MkdOracle:
+    """CPU restatement of the reference MKD path for one PCA model."""
+
+    def __init__(self, pca_path):
+        if not os.path.exists(_LIB):
+            build()
+        L = ctypes.CDLL(_LIB)
+        self.L = L
+        L.mkd_oracle_sizeof_consts.restype = ctypes.c_ulong
+        L.mkd_oracle_pyramid_floats.restype = ctypes.c_long
+        L.mkd_oracle_pyramid_floats.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.mkd_oracle_pyramid_levels.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.mkd_oracle_atan2_shader.restype = ctypes.c_float
+        L.mkd_oracle_atan2_shader.argtypes = [ctypes.c_float, ctypes.c_float]
+        L.mkd_oracle_describe_patches.argtypes = [
+            ctypes.c_void_p, _fp, ctypes.c_long, _fp, _fp, ctypes.c_int, ctypes.c_int]
+        L.mkd_oracle_sample_patches.argtypes = [
+            _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_long, ctypes.c_float, _fp]
+        L.mkd_oracle_build_pyramid.argtypes = [_fp, ctypes.c_int, ctypes.c_int, _fp]
+        L.mkd_oracle_patch_gradients.argtypes = [_fp, _fp, _fp, ctypes.c_int]
+        self.mean = np.zeros(238, np.float32)
+        self.eigvals = np.zeros(238, np.float32)
+        self.eigvecs = np.zeros((238, 238), np.float32)
+        rc = L.mkd_oracle_load_pca(pca_path.encode(), _ptr(self.mean), _ptr(self.eigvals),
+                                   _ptr(self.eigvecs))
+        if rc != 0:
+            raise RuntimeError(f"oracle: cannot load PCA model {pca_path} (rc={rc})")
+        self._consts = np.zeros(L.mkd_oracle_sizeof_consts() // 4, np.float32)
+        L.mkd_oracle_build_consts(_ptr(self.mean), _ptr(self.eigvals), _ptr(self.eigvecs),
+                                  self._consts.ctypes.data_as(ctypes.c_void_p))
+
+    # ConstantData fields (shaders/common.glsl:34-40)
+    @property
+    def gradient_angle(self):
+        return self._consts[0:1024].reshape(32, 32)
+
+    @property
+    def embedding_polar(self):
+        return self._consts[1024:1024 + 25 * 1024].reshape(25, 32, 32)
+
+    @property
+    def embedding_cartesian(self):
+        o = 1024 + 25 * 1024
+        return self._consts[o:o + 9 * 1024].reshape(9, 32, 32)
+
+    @property
+    def mean_vec(self):
+        o = 1024 + 34 * 1024
+        return self._consts[o:o + 238]
+
+    @property
+    def eigen_vecs(self):
+        o = 1024 + 34 * 1024 + 238
+        return self._consts[o:o + 128 * 238].reshape(128, 238)
+
+    def atan2_shader(self, x, y):
+        return self.L.mkd_oracle_atan2_shader(float(x), float(y))
+
+    def patch_gradients(self, patch, atan_mode=ATAN_SHADER):
+        p = _f32(patch).reshape(32, 32)
+        mag = np.zeros((32, 32), np.float32)
+        ang = np.zeros((32, 32), np.float32)
+        self.L.mkd_oracle_patch_gradients(_ptr(p), _ptr(mag), _ptr(ang), atan_mode)
+        return mag, ang
+
+    def describe_patches(self, patches, atan_mode=ATAN_SHADER, nthreads=1, want_raw=False):
+        p = _f32(patches).reshape(-1, 32, 32)
+        n = p.shape[0]
+        desc = np.zeros((n, 128), np.float32)
+        raw = np.zeros((n, 238), np.float32) if want_raw else None
+        self.L.mkd_oracle_describe_patches(
+            self._consts.ctypes.data_as(ctypes.c_void_p), _ptr(p), n, _ptr(desc),
+            _ptr(raw) if want_raw else None, atan_mode, nthreads)
+        return (desc, raw) if want_raw else desc
+
+    def pyramid_levels(self, w, h):
+        return self.L.mkd_oracle_pyramid_levels(w, h)
+
+    def build_pyramid(self, img):
+        img = _f32(img)
+        h, w = img.shape
+        pyr = np.zeros(self.L.mkd_oracle_pyramid_floats(w, h), np.float32)
+        self.L.mkd_oracle_build_pyramid(_ptr(img), w, h, _ptr(pyr))
+        return pyr
+
+    def split_pyramid(self, pyr, w, h):
+        out, off = [], 0
+        for l in range(self.pyramid_levels(w, h)):
+            lw, lh = max(w >> l, 1), max(h >> l, 1)
+            out.append(pyr[off:off + lw * lh].reshape(lh, lw))
+            off += lw * lh
+        return out
+
+    def sample_patches(self, pyr, w, h, kps, patch_scale_factor=24.0):
+        """kps: [n,4] (x, y, size, angle_deg)."""
+        k = _f32(kps).reshape(-1, 4)
+        n = k.shape[0]
+        patches = np.zeros((n, 32, 32), np.float32)
+        self.L.mkd_oracle_sample_patches(_ptr(pyr), w, h, _ptr(k), n, patch_scale_factor,
+                                         _ptr(patches))
+        return patches
+
+    def describe_keypoints(self, img, kps, patch_scale_factor=24.0, **kw):
+        img = _f32(img)
+        h, w = img.shape
+        pyr = self.build_pyramid(img)
+        return self.describe_patches(self.sample_patches(pyr, w, h, kps, patch_scale_factor), **kw)

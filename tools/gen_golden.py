@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Independent NumPy float64 restatement of the reference MKD path + golden generator.
+
+Purpose: the reference (tnibler/local-features) pins no numerical results for this
+path, so two restatements written separately from the same sources pin each other:
+the C f32 oracle (oracle/mkd_oracle.c) and this vectorised float64 one.  This script
+writes tests/golden/*.npz (inputs + float64-computed outputs stored as f32); the
+tests check the C oracle, and the HIP path, against them.
+
+Sources followed (paths relative to /root/reference/local_features/src/):
+  mkd_ref.rs:7-9,146-267      LUT builders        vulkan/mod.rs:1594-1619  constants
+  vulkan/shaders/mkd/patch_gradients.glsl:20-28,42-104   vulkan/shaders/atan2.glsl:19-46
+  vulkan/shaders/mkd/embedding.glsl:34-88  normalize.glsl  whitening.glsl  normalize_final.glsl
+  vulkan/patch_pyramid.rs, shaders/blur.glsl, swt.glsl, blur_pyramid.glsl (keypoint mode)
+
+Run:  python tools/gen_golden.py   (needs only numpy; reads the PCA models shipped in
+local-features_amd/models/mkd/, byte-identical copies of the reference's data files).
+"""
+import json
+import os
+import struct
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODELS = os.path.join(ROOT, "local-features_amd", "models", "mkd")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+C_N3K8 = np.array([0.37872374, 0.51796234, 0.46882015, 0.39798096], np.float32).astype(np.float64)
+C_N1K1 = np.array([0.618176, 0.6934725], np.float32).astype(np.float64)
+C_N2K8 = C_N3K8[:3]
+BLUR = np.array([0.0096, 0.2054, 0.5699, 0.2054, 0.0096], np.float32).astype(np.float64)
+
+
+def load_pca(name):
+    b = open(os.path.join(MODELS, f"concat-pca-{name}.safetensors"), "rb").read()
+    (hl,) = struct.unpack("<Q", b[:8])
+    hdr = json.loads(b[8:8 + hl])
+    out = {}
+    for k, v in hdr.items():
+        if k == "__metadata__":
+            continue
+        s, e = v["data_offsets"]
+        out[k] = np.frombuffer(b[8 + hl + s:8 + hl + e], "<f4").reshape(v["shape"]).astype(np.float64)
+    return out["mean"], out["eigvals"], out["eigvecs"]
+
+
+def vm(t, c):
+    n = len(c) - 1
+    return np.stack([np.full_like(t, c[0])] + [c[k] * np.cos(k * t) for k in range(1, n + 1)]
+                    + [c[k] * np.sin(k * t) for k in range(1, n + 1)])
+
+
+def luts():
+    ax = 2.0 * np.arange(32) / 31.0 - 1.0
+    gx, gy = np.meshgrid(ax, ax)            # gx varies along x (columns), gy along y (rows)
+    phi = -np.arctan2(gy, gx)               # gradient_angle
+    rho = np.sqrt(gx ** 2 + gy ** 2 + 1e-8)
+    nrm = np.sqrt(gx ** 2 + gy ** 2)
+    g = np.exp(-(nrm / nrm.max()) ** 2)
+    a, b = vm(gx * np.pi / 2, C_N1K1), vm(gy * np.pi / 2, C_N1K1)
+    ec = np.stack([a[i] * b[j] * g for i in range(3) for j in range(3)])
+    a, b = vm(-phi, C_N2K8), vm(rho * np.pi / np.sqrt(2.0), C_N2K8)
+    ep = np.stack([a[i] * b[j] * g for i in range(5) for j in range(5)])
+    return phi, ep, ec
+
+
+def atan2_shader(x, y):
+    """shaders/atan2.glsl evaluated in f64; atan2(x, y) = angle of point (x, y)."""
+    A = [0.99997726, -0.33262347, 0.19354346, -0.11643287, 0.05265332, -0.0117212]
+    A = [float(np.float32(v)) for v in A]
+    PI, HPI = float(np.float32(3.1415927)), float(np.float32(1.5707964))
+    swap = np.abs(x) < np.abs(y)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a = np.where(swap, x / np.where(y == 0, 1, y), y / np.where(x == 0, 1, x))
+    s = a * a
+    p = a * (A[0] + s * (A[1] + s * (A[2] + s * (A[3] + s * (A[4] + s * A[5])))))
+    res = np.where(swap, HPI * np.sign(a) - p, p)
+    res = np.where(x < 0, PI * np.where(y < 0, -1.0, 1.0) + res, res)
+    return np.where((x == 0) & (y == 0), 0.0, res)
+
+
+def describe(patches, pca, mode="shader", want_raw=False):
+    phi, ep, ec = luts()
+    mean, eigvals, eigvecs = pca
+    P = np.asarray(patches, np.float64).reshape(-1, 32, 32)
+    pv = np.pad(P, ((0, 0), (2, 2), (0, 0)), mode="edge")
+    V = sum(BLUR[i] * pv[:, i:i + 32, :] for i in range(5))
+    ph = np.pad(V, ((0, 0), (0, 0), (2, 2)), mode="edge")
+    B = sum(BLUR[i] * ph[:, :, i:i + 32] for i in range(5))
+    bx = np.pad(B, ((0, 0), (0, 0), (1, 1)), mode="edge")
+    by = np.pad(B, ((0, 0), (1, 1), (0, 0)), mode="edge")
+    gx = bx[:, :, 0:32] - bx[:, :, 2:34]     # left - right
+    gy = by[:, 2:34, :] - by[:, 0:32, :]     # down - up
+    mag = (gx ** 2 + gy ** 2 + 1e-8) ** 0.25
+    th = -(atan2_shader(gx, gy) if mode == "shader" else np.arctan2(gy, gx))
+
+    def emb(t):
+        return np.stack([C_N3K8[0] * mag] + [C_N3K8[k] * np.cos(k * t) * mag for k in (1, 2, 3)]
+                        + [C_N3K8[k] * np.sin(k * t) * mag for k in (1, 2, 3)], axis=1)
+    polar = np.einsum("nipq,jpq->nij", emb(th + phi), ep).reshape(len(P), 175)
+    cart = np.einsum("nipq,jpq->nij", emb(th), ec).reshape(len(P), 63)
+    polar /= np.linalg.norm(polar, axis=1, keepdims=True)
+    cart /= np.linalg.norm(cart, axis=1, keepdims=True)
+    raw = np.concatenate([polar, cart], axis=1)
+    raw /= np.linalg.norm(raw, axis=1, keepdims=True)
+    W = eigvecs[:, :128] * eigvals[:128] ** float(np.float32(-0.5) * np.float32(0.7))
+    d = (raw - mean) @ W
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return (d, raw) if want_raw else d
+
+
+# ---------------------------------------------------------------- keypoint mode
+def mirror(i, n):
+    m = np.mod(i, 2 * n)
+    return np.where(m < n, m, 2 * n - 1 - m)
+
+
+def tex(img, u, v):
+    """Bilinear, MirroredRepeat, unnormalised coords with texel centres at i+0.5."""
+    h, w = img.shape
+    fu, fv = u - 0.5, v - 0.5
+    x0, y0 = np.floor(fu), np.floor(fv)
+    ax, ay = fu - x0, fv - y0
+    x0, y0 = x0.astype(np.int64), y0.astype(np.int64)
+    xa, xb, ya, yb = mirror(x0, w), mirror(x0 + 1, w), mirror(y0, h), mirror(y0 + 1, h)
+    top = img[ya, xa] * (1 - ax) + img[ya, xb] * ax
+    bot = img[yb, xa] * (1 - ax) + img[yb, xb] * ax
+    return top * (1 - ay) + bot * ay
+
+
+def sep3(img, w0, w1, off):
+    h, w = img.shape
+    yy, xx = np.mgrid[0:h, 0:w]
+    cx, cy = xx + 0.5, yy + 0.5
+    t = tex(img, cx, cy) * w0 + (tex(img, cx - off, cy) + tex(img, cx + off, cy)) * w1
+    return tex(t, cx, cy) * w0 + (tex(t, cx, cy - off) + tex(t, cx, cy + off)) * w1
+
+
+def pyramid(img):
+    img = np.asarray(img, np.float64)
+    h, w = img.shape
+    L = int(np.ceil(np.log2(min(w, h))))
+    W0, W1, OFF = (float(np.float32(v)) for v in (0.66381836, 0.16809084, 0.015267163))
+    lv = [sep3(img, W0, W1, 1.0 + OFF)]
+    k = np.array([1, 4, 6, 4, 1]) / 16.0
+    a = lv[0]
+    t = sum(k[i] * a[:, mirror(np.arange(w) + i - 2, w)] for i in range(5))
+    c1 = sum(k[i] * t[mirror(np.arange(h) + i - 2, h), :] for i in range(5))
+    lw, lh = max(w >> 1, 1), max(h >> 1, 1)
+    sx = np.minimum(np.floor((np.arange(lw) + 0.5) * w / (w // 2)).astype(int), w - 1)
+    sy = np.minimum(np.floor((np.arange(lh) + 0.5) * h / (h // 2)).astype(int), h - 1)
+    lv.append(c1[np.ix_(sy, sx)])
+    for l in range(2, L):
+        p = lv[-1]
+        ph, pw = p.shape
+        lw, lh = max(w >> l, 1), max(h >> l, 1)
+        yy, xx = np.mgrid[0:ph, 0:pw]
+        cx, cy = xx + 0.5, yy + 0.5
+        t = tex(p, cx, cy) * 0.375 + (tex(p, cx - 1.2, cy) + tex(p, cx + 1.2, cy)) * 0.3125
+        yy, xx = np.mgrid[0:lh, 0:lw]
+        cx, cy = 2.0 * xx + 0.5, 2.0 * yy + 0.5
+        lv.append(tex(t, cx, cy) * 0.375 + (tex(t, cx, cy - 1.2) + tex(t, cx, cy + 1.2)) * 0.3125)
+    return lv
+
+
+def sample(lv, kps, psf=24.0):
+    out = []
+    ly, lx = np.mgrid[0:32, 0:32]
+    dx, dy = lx - 16.0, ly - 16.0
+    for x, y, size, ang in np.asarray(kps, np.float64):
+        ls = np.log2(size * psf / 32.0)
+        l = int(min(max(np.floor(ls), 0), len(lv) - 1))
+        r = 2.0 ** (ls - l)
+        a = np.deg2rad(ang)
+        xx = dx * np.cos(a) - dy * np.sin(a)
+        yy = dx * np.sin(a) + dy * np.cos(a)
+        out.append(tex(lv[l], xx * r + x / 2 ** l + 0.5, yy * r + y / 2 ** l + 0.5))
+    return np.stack(out)
+
+
+# ---------------------------------------------------------------- inputs
+def structured_patches():
+    y, x = np.mgrid[0:32, 0:32].astype(np.float64)
+    ps = [x / 31.0, y / 31.0, (x + 2 * y) / 93.0]
+    ps.append(np.exp(-((x - 14.3) ** 2 + (y - 17.9) ** 2) / 40.0))
+    for deg in (17.0, 61.0, 133.0):                       # step edges off the axes
+        a = np.deg2rad(deg)
+        ps.append(((x - 15.5) * np.cos(a) + (y - 15.5) * np.sin(a) > 0.3).astype(np.float64))
+    ps.append(0.5 + 0.5 * np.sin(x * 0.7) * np.cos(y * 0.45))
+    ps.append(np.full((32, 32), 0.37))                    # flat: mag==0.01, angle==0 everywhere
+    ps.append(((x // 4 + y // 4) % 2).astype(np.float64))  # checkerboard: axis-aligned (gx==0 quirk)
+    return np.stack(ps)
+
+
+def smooth_image(h, w, seed):
+    rng = np.random.default_rng(seed)
+    img = rng.random((h + 16, w + 16))
+    k = np.exp(-0.5 * (np.arange(-6, 7) / 2.0) ** 2)
+    k /= k.sum()
+    img = np.apply_along_axis(lambda r: np.convolve(r, k, "same"), 1, img)
+    img = np.apply_along_axis(lambda r: np.convolve(r, k, "same"), 0, img)
+    img = img[8:-8, 8:-8]
+    return ((img - img.min()) / (img.max() - img.min())).astype(np.float32)
+
+
+def random_keypoints(n, w, h, seed, margin=8.0):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(margin, w - margin, n)
+    y = rng.uniform(margin, h - margin, n)
+    size = np.exp(rng.uniform(np.log(1.64), np.log(min(52.0, min(w, h) / 6.0)), n))
+    ang = rng.uniform(0.0, 360.0, n)
+    return np.stack([x, y, size, ang], axis=1).astype(np.float32)
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    rng = np.random.default_rng(0x4D4B44)
+    rand = rng.random((16, 32, 32)).astype(np.float32)
+    struct_p = structured_patches().astype(np.float32)
+    patches = np.concatenate([rand, struct_p])
+    for name in ("liberty", "notredame", "yosemite"):
+        pca = load_pca(name)
+        d_s, raw_s = describe(patches, pca, "shader", want_raw=True)
+        d_l, raw_l = describe(patches, pca, "libm", want_raw=True)
+        np.savez_compressed(
+            os.path.join(GOLDEN, f"patches_{name}.npz"), patches=patches,
+            desc_shader=d_s.astype(np.float32), raw_shader=raw_s.astype(np.float32),
+            desc_libm=d_l.astype(np.float32), raw_libm=raw_l.astype(np.float32))
+        print(name, "patch goldens:", patches.shape, "->", d_s.shape)
+    # keypoint mode: one small frame, float64 pyramid + sampling + descriptors
+    w, h = 200, 136
+    img = smooth_image(h, w, 7)
+    kps = random_keypoints(24, w, h, 11)
+    lv = pyramid(img)
+    sp = sample(lv, kps)
+    pca = load_pca("liberty")
+    d = describe(sp, pca, "shader")
+    np.savez_compressed(
+        os.path.join(GOLDEN, "keypoints_liberty.npz"), image=img, keypoints=kps,
+        level1=lv[1].astype(np.float32), level3=lv[3].astype(np.float32),
+        patches=sp.astype(np.float32), desc_shader=d.astype(np.float32))
+    print("keypoint goldens:", img.shape, kps.shape, "->", d.shape)
+    phi, ep, ec = luts()
+    np.savez_compressed(os.path.join(GOLDEN, "luts.npz"), gradient_angle=phi.astype(np.float32),
+                        embedding_polar=ep.astype(np.float32), embedding_cartesian=ec.astype(np.float32))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
