@@ -1,0 +1,143 @@
+/*
+ * lf_mkd.h -- C ABI of the MI355X-native MKD descriptor path (liblf_mkd.so).
+ *
+ * This is the drop-in boundary for ONE path of tnibler/local-features: the
+ * "describe" half of LocalFeaturesVulkan::detect (local_features/src/vulkan/mod.rs:435-453),
+ * i.e. the extract task graph (mod.rs:1277-1572) minus keypoint orientation:
+ *   patch sampling -> blur/gradients -> von-Mises x spatial-kernel pooling
+ *   -> normalise -> PCA whitening -> L2.
+ * Plain pointers and sizes only; no C++/torch types.  Each entry point cites the
+ * reference interface it replaces.  The Rust-side binding a maintainer would add
+ * is shown in INTEGRATION.md.
+ *
+ * Threading: a handle is NOT thread-safe (the reference takes &mut self on every
+ * call, mod.rs:346-367); use one handle per device/stream.  All functions return
+ * LF_MKD_OK (0) or a negative lf_mkd_status; they never abort.  The message for
+ * the last failure on a handle is available from lf_mkd_last_error().
+ */
+#ifndef LF_MKD_H
+#define LF_MKD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LF_MKD_PATCH_SIZE 32       /* lib.rs:15  PATCH_SIZE            */
+#define LF_MKD_RAW_LEN 238         /* lib.rs:12  RAW_DESCRIPTOR_LEN    */
+#define LF_MKD_DESC_LEN 128        /* lib.rs:13  DESCRIPTOR_LEN        */
+
+typedef enum {
+    LF_MKD_OK = 0,
+    LF_MKD_ERR_BAD_ARG = -1,   /* null pointer, zero size, image larger than max_image_* ... */
+    LF_MKD_ERR_HIP = -2,       /* a HIP runtime call failed; see lf_mkd_last_error         */
+    LF_MKD_ERR_IO = -3,        /* cannot read / parse the PCA model file                   */
+    LF_MKD_ERR_NO_IMAGE = -4,  /* describe_keypoints before set_image                      */
+    LF_MKD_ERR_NO_DEVICE = -5  /* no usable gfx950 device                                  */
+} lf_mkd_status;
+
+/* Which PCA model to load from a model directory: enum MKDPCA, lib.rs:26-32. */
+typedef enum { LF_MKD_PCA_LIBERTY = 0, LF_MKD_PCA_NOTREDAME = 1, LF_MKD_PCA_YOSEMITE = 2 } lf_mkd_pca;
+
+/* Angle path of the gradient stage.
+ * SHADER  : the reference's polynomial atan2 incl. its quirks (shaders/atan2.glsl:19-46). Default.
+ * EXACT   : cos/sin of the gradient direction taken as gx/|g|, gy/|g| (what the polynomial
+ *           approximates to 1e-5 rad; matches mkd_ref.rs:140, the CPU twin). */
+typedef enum { LF_MKD_ANGLE_SHADER = 0, LF_MKD_ANGLE_EXACT = 1 } lf_mkd_angle_mode;
+
+/* Arithmetic of the pooling contraction (1024 px x 7 in-dims x 34 kernels per patch).
+ * F32     : v_mfma_f32_16x16x4_f32, bit-for-bit an f32 fma chain.
+ * F16X3   : operands split into f16 hi+lo, three f16 MFMAs per product (hi*hi, hi*lo, lo*hi),
+ *           f32 accumulate; ~2^-21 relative per product. */
+typedef enum { LF_MKD_POOL_F32 = 0, LF_MKD_POOL_F16X3 = 1 } lf_mkd_pool_mode;
+
+/* Mirrors BuildTimeParams (lib.rs:54-75) + FeatureDetectParams (lib.rs:34-52) for this path.
+ * Zero-initialise, then set what you need; 0 means "default". */
+typedef struct {
+    uint32_t max_image_width;   /* BuildTimeParams.max_image_width  (0: keypoint mode unused) */
+    uint32_t max_image_height;  /* BuildTimeParams.max_image_height                            */
+    uint32_t max_features;      /* BuildTimeParams.max_features: descriptors per internal batch;
+                                   larger requests are processed in batches (default 2000 -> raised
+                                   to a multiple of 64) */
+    float patch_scale_factor;   /* FeatureDetectParams.patch_scale_factor (default 24)         */
+    int32_t device;             /* HIP device ordinal                                          */
+    int32_t angle_mode;         /* lf_mkd_angle_mode                                           */
+    int32_t pool_mode;          /* lf_mkd_pool_mode                                            */
+    uint32_t reserved[5];
+} lf_mkd_params;
+
+/* Keypoint as the path consumes it: struct Keypoint, lib.rs:17-24 (angle in DEGREES,
+ * keypoint_orientation.glsl:162-167; response is carried through, not used). */
+typedef struct {
+    float x, y, size, angle, response;
+} lf_mkd_keypoint;
+
+typedef struct lf_mkd lf_mkd; /* opaque; owns all device memory */
+
+/* Replaces new_vulkan() + upload_constant_data() for this path (lib.rs:94-100,
+ * mod.rs:1587-1713).  PCA tensors are the three arrays of the reference's safetensors
+ * model (mkd_ref.rs:352-391): mean[238], eigvals[238], eigvecs[238*238] row-major. */
+int lf_mkd_create(const lf_mkd_params *params, const float *mean, const float *eigvals,
+                  const float *eigvecs, lf_mkd **out);
+
+/* Same, reading concat-pca-*.safetensors (models/mkd/, embedded by mkd_ref.rs:26-31). */
+int lf_mkd_create_from_file(const lf_mkd_params *params, const char *safetensors_path,
+                            lf_mkd **out);
+
+void lf_mkd_destroy(lf_mkd *h);
+
+const char *lf_mkd_last_error(const lf_mkd *h);
+
+/* Patch mode: the extract graph from patch_gradients' blur onwards
+ * (tasks_extract.rs:72-333; CPU twin Mkd::patch, mkd_ref.rs:57-77).
+ * patches: [n][32][32] f32 row-major, out: [n][128] f32.  Host pointers; synchronous. */
+int lf_mkd_describe_patches(lf_mkd *h, const float *patches, uint64_t n, float *out);
+
+/* Same with DEVICE pointers, enqueued on `stream` (a hipStream_t, or NULL for the handle's
+ * own stream); asynchronous.  This is what a caller that already holds patches in HBM uses. */
+int lf_mkd_describe_patches_device(lf_mkd *h, const float *d_patches, uint64_t n, float *d_out,
+                                   void *stream);
+
+/* Debug/verification tap: un-whitened 238-D descriptor (RawDescriptorBuffer, common.glsl:133-139).
+ * Device pointers, asynchronous. */
+int lf_mkd_raw_descriptors_device(lf_mkd *h, const float *d_patches, uint64_t n, float *d_raw,
+                                  void *stream);
+
+/* Keypoint mode, step 1: upload one frame (f32 in [0,1], row-major, contiguous; mod.rs:368)
+ * and build the patch pyramid (patch_pyramid.rs:38-156 + blur.glsl + swt.glsl level 0).
+ * width/height must not exceed max_image_*; the pyramid mirrors at the content edge. */
+int lf_mkd_set_image(lf_mkd *h, const float *image, uint32_t width, uint32_t height);
+int lf_mkd_set_image_device(lf_mkd *h, const float *d_image, uint32_t width, uint32_t height,
+                            void *stream);
+
+/* Keypoint mode, step 2: sample + describe (patch_gradients.glsl:42-70 onwards).
+ * out: [n][128].  Host pointers; synchronous. */
+int lf_mkd_describe_keypoints(lf_mkd *h, const lf_mkd_keypoint *kps, uint64_t n, float *out);
+int lf_mkd_describe_keypoints_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64_t n,
+                                     float *d_out, void *stream);
+
+/* Verification taps for keypoint mode (device pointers). */
+int lf_mkd_sample_patches_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64_t n,
+                                 float *d_patches, void *stream);
+/* Copies pyramid level `level` ((w>>level) x (h>>level) f32) to a host buffer. */
+int lf_mkd_get_pyramid_level(lf_mkd *h, uint32_t level, float *out, uint32_t *w, uint32_t *hgt);
+
+/* Host-only verification tap: the constants upload_constant_data (mod.rs:1587-1713) would place in
+ * ConstantData (common.glsl:34-40), as this library builds them.  Any output pointer may be NULL.
+ * gradient_angle[1024], embedding_polar[25*1024], embedding_cartesian[9*1024], w_t[128*238].
+ * Needs no device. */
+int lf_mkd_build_constants(const float *mean, const float *eigvals, const float *eigvecs,
+                           float *gradient_angle, float *embedding_polar,
+                           float *embedding_cartesian, float *w_t);
+
+/* Blocks until everything enqueued on the handle's own stream has finished. */
+int lf_mkd_synchronize(lf_mkd *h);
+
+/* Library identification: "lf_mkd <version> gfx950". */
+const char *lf_mkd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LF_MKD_H */

@@ -1,0 +1,350 @@
+// C ABI of the MKD path (include/lf_mkd.h): handle management, batching, host<->device staging.
+// Product code: it never touches oracle/; without a HIP device every entry point fails loudly.
+#include "../../include/lf_mkd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "mkd_consts.hpp"
+#include "mkd_device.h"
+
+using namespace lfmkd;
+
+struct lf_mkd {
+    lf_mkd_params params{};
+    hipStream_t stream = nullptr;
+    DeviceConsts dc;
+    uint64_t batch = 0;         // descriptors per internal batch (multiple of 64)
+    float *d_pooled = nullptr;  // [batch][238]  pooled sums between the two kernels
+    float *d_patches = nullptr; // [batch][1024] staging: host patches / sampled patches
+    float *d_out = nullptr;     // [batch][128]  staging for host output
+    float *d_kps = nullptr;     // [batch][5]
+    // keypoint mode
+    PyramidDesc pd{};
+    float *d_image = nullptr, *d_pyr = nullptr, *d_tmp_a = nullptr, *d_tmp_b = nullptr;
+    bool have_image = false;
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+#define LF_HIP(h, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return LF_MKD_ERR_HIP;                                                          \
+        }                                                                                   \
+    } while (0)
+
+int fail(lf_mkd *h, int code, const std::string &msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+template <typename T>
+hipError_t upload(T **dst, const void *src, size_t bytes) {
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+}
+
+long pyramid_levels(uint32_t w, uint32_t h) {  // mod.rs:271-277,372-373
+    return std::lround(std::ceil(std::log2(float(std::min(w, h)))));
+}
+
+void describe_pyramid(uint32_t w, uint32_t h, PyramidDesc &pd) {
+    pd.levels = int(std::min<long>(std::max<long>(pyramid_levels(w, h), 1), kMaxPyrLevels));
+    long off = 0;
+    for (int l = 0; l < pd.levels; ++l) {
+        pd.w[l] = std::max<int>(int(w >> l), 1);
+        pd.h[l] = std::max<int>(int(h >> l), 1);
+        pd.offset[l] = off;
+        off += long(pd.w[l]) * pd.h[l];
+    }
+}
+
+long pyramid_floats(uint32_t w, uint32_t h) {
+    PyramidDesc pd{};
+    describe_pyramid(w, h, pd);
+    return pd.offset[pd.levels - 1] + long(pd.w[pd.levels - 1]) * pd.h[pd.levels - 1];
+}
+
+int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) {
+    if (!params || !out) return LF_MKD_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || params->device < 0 || params->device >= ndev) {
+        g_create_error = "no HIP device " + std::to_string(params->device) + " (devices visible: " +
+                         std::to_string(ndev) + ")";
+        return LF_MKD_ERR_NO_DEVICE;
+    }
+    lf_mkd *h = new (std::nothrow) lf_mkd;
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    h->params = *params;
+    if (h->params.patch_scale_factor == 0.f) h->params.patch_scale_factor = 24.f;  // lib.rs:46
+    const uint64_t mf = params->max_features ? params->max_features : 2000;        // lib.rs:69
+    h->batch = (mf + 63) / 64 * 64;
+    auto bail = [&](int code) {
+        g_create_error = h->err;
+        lf_mkd_destroy(h);
+        return code;
+    };
+#define LF_CREATE_HIP(call)                                                   \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) {                                               \
+            h->err = std::string(#call) + ": " + hipGetErrorString(e_);       \
+            return bail(LF_MKD_ERR_HIP);                                      \
+        }                                                                     \
+    } while (0)
+    LF_CREATE_HIP(hipSetDevice(params->device));
+    LF_CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HostConsts hc;
+    build_host_consts(pca, hc);
+    LF_CREATE_HIP(upload(&h->dc.phi_cs, hc.phi_cs.data(), hc.phi_cs.size() * 4));
+    LF_CREATE_HIP(upload(&h->dc.colmap, hc.colmap.data(), hc.colmap.size() * 2));
+    LF_CREATE_HIP(upload(&h->dc.pool_b_f32, hc.pool_b_f32.data(), hc.pool_b_f32.size() * 4));
+    LF_CREATE_HIP(upload(&h->dc.pool_b_f16, hc.pool_b_f16.data(), hc.pool_b_f16.size() * 2));
+    LF_CREATE_HIP(upload(&h->dc.white_b_f32, hc.white_b_f32.data(), hc.white_b_f32.size() * 4));
+    LF_CREATE_HIP(upload(&h->dc.mean_pad, hc.mean_pad.data(), hc.mean_pad.size() * 4));
+    LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_pooled), h->batch * kRaw * 4));
+    LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_patches), h->batch * kPx * 4));
+    LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_out), h->batch * kOut * 4));
+    LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_kps), h->batch * 5 * 4));
+    if (params->max_image_width && params->max_image_height) {
+        const size_t px = size_t(params->max_image_width) * params->max_image_height;
+        LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_image), px * 4));
+        LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_tmp_a), px * 4));
+        LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_tmp_b), px * 4));
+        LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_pyr),
+                                size_t(pyramid_floats(params->max_image_width, params->max_image_height)) * 4));
+    }
+#undef LF_CREATE_HIP
+    *out = h;
+    return LF_MKD_OK;
+}
+
+// pooled sums -> descriptors for one batch already resident on the device
+int run_batch(lf_mkd *h, const float *d_patches, uint64_t n, float *d_out, float *d_raw, hipStream_t s) {
+    launch_pool_f32(d_patches, long(n), h->dc, h->params.angle_mode, h->d_pooled, s);
+    LF_HIP(h, hipGetLastError());
+    launch_whiten_f32(h->d_pooled, long(n), h->dc, d_out ? d_out : h->d_out, d_raw, s);
+    LF_HIP(h, hipGetLastError());
+    return LF_MKD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *lf_mkd_version(void) { return "lf_mkd 0.1.0 gfx950"; }
+
+int lf_mkd_create(const lf_mkd_params *params, const float *mean, const float *eigvals, const float *eigvecs,
+                  lf_mkd **out) {
+    if (!mean || !eigvals || !eigvecs) return LF_MKD_ERR_BAD_ARG;
+    PcaModel pca;
+    pca.mean.assign(mean, mean + kRaw);
+    pca.eigvals.assign(eigvals, eigvals + kRaw);
+    pca.eigvecs.assign(eigvecs, eigvecs + size_t(kRaw) * kRaw);
+    return create_impl(params, pca, out);
+}
+
+int lf_mkd_build_constants(const float *mean, const float *eigvals, const float *eigvecs, float *gradient_angle,
+                           float *embedding_polar, float *embedding_cartesian, float *w_t) {
+    if (!mean || !eigvals || !eigvecs) return LF_MKD_ERR_BAD_ARG;
+    PcaModel pca;
+    pca.mean.assign(mean, mean + kRaw);
+    pca.eigvals.assign(eigvals, eigvals + kRaw);
+    pca.eigvecs.assign(eigvecs, eigvecs + size_t(kRaw) * kRaw);
+    HostConsts hc;
+    build_host_consts(pca, hc);
+    if (gradient_angle) std::memcpy(gradient_angle, hc.gradient_angle.data(), hc.gradient_angle.size() * 4);
+    if (embedding_polar) std::memcpy(embedding_polar, hc.embedding_polar.data(), hc.embedding_polar.size() * 4);
+    if (embedding_cartesian)
+        std::memcpy(embedding_cartesian, hc.embedding_cartesian.data(), hc.embedding_cartesian.size() * 4);
+    if (w_t) std::memcpy(w_t, hc.w_t.data(), hc.w_t.size() * 4);
+    return LF_MKD_OK;
+}
+
+int lf_mkd_create_from_file(const lf_mkd_params *params, const char *path, lf_mkd **out) {
+    if (!path) return LF_MKD_ERR_BAD_ARG;
+    PcaModel pca;
+    const std::string e = load_pca_safetensors(path, pca);
+    if (!e.empty()) {
+        g_create_error = e;
+        return LF_MKD_ERR_IO;
+    }
+    return create_impl(params, pca, out);
+}
+
+void lf_mkd_destroy(lf_mkd *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->params.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *ptrs[] = {h->dc.phi_cs, h->dc.colmap, h->dc.pool_b_f32, h->dc.pool_b_f16, h->dc.white_b_f32,
+                    h->dc.mean_pad, h->d_pooled,  h->d_patches,    h->d_out,         h->d_kps,
+                    h->d_image,   h->d_pyr,     h->d_tmp_a,      h->d_tmp_b};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char *lf_mkd_last_error(const lf_mkd *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int lf_mkd_synchronize(lf_mkd *h) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_HIP(h, hipStreamSynchronize(h->stream));
+    return LF_MKD_OK;
+}
+
+int lf_mkd_describe_patches_device(lf_mkd *h, const float *d_patches, uint64_t n, float *d_out, void *stream) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (n == 0) return LF_MKD_OK;
+    if (!d_patches || !d_out) return fail(h, LF_MKD_ERR_BAD_ARG, "describe_patches_device: null pointer");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    for (uint64_t off = 0; off < n; off += h->batch) {
+        const uint64_t m = std::min<uint64_t>(h->batch, n - off);
+        const int rc = run_batch(h, d_patches + off * kPx, m, d_out + off * kOut, nullptr, s);
+        if (rc) return rc;
+    }
+    return LF_MKD_OK;
+}
+
+int lf_mkd_raw_descriptors_device(lf_mkd *h, const float *d_patches, uint64_t n, float *d_raw, void *stream) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (n == 0) return LF_MKD_OK;
+    if (!d_patches || !d_raw) return fail(h, LF_MKD_ERR_BAD_ARG, "raw_descriptors_device: null pointer");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    for (uint64_t off = 0; off < n; off += h->batch) {
+        const uint64_t m = std::min<uint64_t>(h->batch, n - off);
+        const int rc = run_batch(h, d_patches + off * kPx, m, nullptr, d_raw + off * kRaw, s);
+        if (rc) return rc;
+    }
+    return LF_MKD_OK;
+}
+
+int lf_mkd_describe_patches(lf_mkd *h, const float *patches, uint64_t n, float *out) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (n == 0) return LF_MKD_OK;
+    if (!patches || !out) return fail(h, LF_MKD_ERR_BAD_ARG, "describe_patches: null pointer");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    for (uint64_t off = 0; off < n; off += h->batch) {
+        const uint64_t m = std::min<uint64_t>(h->batch, n - off);
+        LF_HIP(h, hipMemcpyAsync(h->d_patches, patches + off * kPx, m * kPx * 4, hipMemcpyHostToDevice, h->stream));
+        const int rc = run_batch(h, h->d_patches, m, h->d_out, nullptr, h->stream);
+        if (rc) return rc;
+        LF_HIP(h, hipMemcpyAsync(out + off * kOut, h->d_out, m * kOut * 4, hipMemcpyDeviceToHost, h->stream));
+        LF_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return LF_MKD_OK;
+}
+
+int lf_mkd_set_image_device(lf_mkd *h, const float *d_image, uint32_t width, uint32_t height, void *stream) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!d_image || width < 2 || height < 2) return fail(h, LF_MKD_ERR_BAD_ARG, "set_image: bad image");
+    if (!h->d_pyr || width > h->params.max_image_width || height > h->params.max_image_height)
+        return fail(h, LF_MKD_ERR_BAD_ARG,
+                    "set_image: image " + std::to_string(width) + "x" + std::to_string(height) +
+                        " exceeds max_image_width/height given at creation");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    describe_pyramid(width, height, h->pd);
+    launch_build_pyramid(d_image, h->d_pyr, h->d_tmp_a, h->d_tmp_b, h->pd, s);
+    LF_HIP(h, hipGetLastError());
+    h->have_image = true;
+    return LF_MKD_OK;
+}
+
+int lf_mkd_set_image(lf_mkd *h, const float *image, uint32_t width, uint32_t height) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!image) return fail(h, LF_MKD_ERR_BAD_ARG, "set_image: null image");
+    if (!h->d_image || width > h->params.max_image_width || height > h->params.max_image_height)
+        return fail(h, LF_MKD_ERR_BAD_ARG, "set_image: image exceeds max_image_width/height given at creation");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_HIP(h, hipMemcpyAsync(h->d_image, image, size_t(width) * height * 4, hipMemcpyHostToDevice, h->stream));
+    const int rc = lf_mkd_set_image_device(h, h->d_image, width, height, h->stream);
+    if (rc) return rc;
+    LF_HIP(h, hipStreamSynchronize(h->stream));
+    return LF_MKD_OK;
+}
+
+int lf_mkd_sample_patches_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64_t n, float *d_patches,
+                                 void *stream) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "sample_patches: call lf_mkd_set_image first");
+    if (n == 0) return LF_MKD_OK;
+    if (!d_kps || !d_patches) return fail(h, LF_MKD_ERR_BAD_ARG, "sample_patches: null pointer");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    launch_sample_patches(h->d_pyr, h->pd, reinterpret_cast<const float *>(d_kps), long(n),
+                          h->params.patch_scale_factor, d_patches, s);
+    LF_HIP(h, hipGetLastError());
+    return LF_MKD_OK;
+}
+
+int lf_mkd_describe_keypoints_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64_t n, float *d_out,
+                                     void *stream) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "describe_keypoints: call lf_mkd_set_image first");
+    if (n == 0) return LF_MKD_OK;
+    if (!d_kps || !d_out) return fail(h, LF_MKD_ERR_BAD_ARG, "describe_keypoints_device: null pointer");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    for (uint64_t off = 0; off < n; off += h->batch) {
+        const uint64_t m = std::min<uint64_t>(h->batch, n - off);
+        launch_sample_patches(h->d_pyr, h->pd, reinterpret_cast<const float *>(d_kps + off), long(m),
+                              h->params.patch_scale_factor, h->d_patches, s);
+        LF_HIP(h, hipGetLastError());
+        const int rc = run_batch(h, h->d_patches, m, d_out + off * kOut, nullptr, s);
+        if (rc) return rc;
+    }
+    return LF_MKD_OK;
+}
+
+int lf_mkd_describe_keypoints(lf_mkd *h, const lf_mkd_keypoint *kps, uint64_t n, float *out) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "describe_keypoints: call lf_mkd_set_image first");
+    if (n == 0) return LF_MKD_OK;
+    if (!kps || !out) return fail(h, LF_MKD_ERR_BAD_ARG, "describe_keypoints: null pointer");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    for (uint64_t off = 0; off < n; off += h->batch) {
+        const uint64_t m = std::min<uint64_t>(h->batch, n - off);
+        LF_HIP(h, hipMemcpyAsync(h->d_kps, kps + off, m * sizeof(lf_mkd_keypoint), hipMemcpyHostToDevice, h->stream));
+        launch_sample_patches(h->d_pyr, h->pd, h->d_kps, long(m), h->params.patch_scale_factor, h->d_patches,
+                              h->stream);
+        LF_HIP(h, hipGetLastError());
+        const int rc = run_batch(h, h->d_patches, m, h->d_out, nullptr, h->stream);
+        if (rc) return rc;
+        LF_HIP(h, hipMemcpyAsync(out + off * kOut, h->d_out, m * kOut * 4, hipMemcpyDeviceToHost, h->stream));
+        LF_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return LF_MKD_OK;
+}
+
+int lf_mkd_get_pyramid_level(lf_mkd *h, uint32_t level, float *out, uint32_t *w, uint32_t *hgt) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "get_pyramid_level: call lf_mkd_set_image first");
+    if (level >= uint32_t(h->pd.levels)) return fail(h, LF_MKD_ERR_BAD_ARG, "get_pyramid_level: no such level");
+    if (w) *w = uint32_t(h->pd.w[level]);
+    if (hgt) *hgt = uint32_t(h->pd.h[level]);
+    if (!out) return LF_MKD_OK;
+    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_HIP(h, hipStreamSynchronize(h->stream));
+    LF_HIP(h, hipMemcpy(out, h->d_pyr + h->pd.offset[level], size_t(h->pd.w[level]) * h->pd.h[level] * 4,
+                        hipMemcpyDeviceToHost));
+    return LF_MKD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+// Builds the constants of the MKD path on the host (once per handle).
+// Formulas follow the reference's LUT builders, local_features/src/mkd_ref.rs:146-267, and its
+// upload step, local_features/src/vulkan/mod.rs:1594-1619; the layouts are this library's own.
+#include "mkd_consts.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace lfmkd {
+
+namespace {
+
+// von-Mises Fourier coefficients, mkd_ref.rs:7-9
+const float kVmN3K8[4] = {0.37872374f, 0.51796234f, 0.46882015f, 0.39798096f};
+const float kVmN1K1[2] = {0.618176f, 0.6934725f};
+const float kVmN2K8[3] = {0.37872374f, 0.51796234f, 0.46882015f};
+
+struct Grid {
+    float x[kPx], y[kPx];
+    Grid() {  // mkd_ref.rs:173-185
+        for (int r = 0; r < kPatch; ++r)
+            for (int c = 0; c < kPatch; ++c) {
+                x[r * kPatch + c] = 2.f * float(c) / float(kPatch - 1) - 1.f;
+                y[r * kPatch + c] = 2.f * float(r) / float(kPatch - 1) - 1.f;
+            }
+    }
+};
+
+// component a of the (2n+1)-vector [c0, c_k cos(k t), c_k sin(k t)], mkd_ref.rs:146-171
+float vm_component(const float *coef, int n, int a, float t) {
+    if (a == 0) return coef[0];
+    if (a <= n) return std::cos(t * float(a)) * coef[a];
+    return std::sin(t * float(a - n)) * coef[a - n];
+}
+
+uint16_t f16_bits(float v) {
+    _Float16 h = static_cast<_Float16>(v);  // round to nearest even
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+float f16_value(uint16_t b) {
+    _Float16 h;
+    std::memcpy(&h, &b, 2);
+    return static_cast<float>(h);
+}
+
+// One packed output column: which spatial kernel, which descriptor slot, which coefficient.
+struct Column {
+    int desc;       // 0..237 or -1 (padding)
+    bool polar;     // EP or EC
+    int j;          // kernel index within EP/EC
+    float coef;     // von-Mises coefficient of the in-dim (embedding.glsl:27-32)
+};
+
+Column column_of(int tile, int c) {
+    const int s = kTileStream[tile];
+    Column col{-1, false, 0, 0.f};
+    // in-dim of the stream: m -> 0, cos k -> k, sin k -> k+3 (both for abs and rel streams)
+    int i = 0, k = 0;
+    if (s >= 1 && s <= 3) { k = s; i = k; }
+    if (s >= 4 && s <= 6) { k = s - 3; i = k + 3; }
+    if (s >= 7 && s <= 9) { k = s - 6; i = k; }
+    if (s >= 10 && s <= 12) { k = s - 9; i = k + 3; }
+    col.coef = kVmN3K8[k];
+    // first tile of the stream? (streams with polar columns own two consecutive tiles; m owns three)
+    int first = tile;
+    while (first > 0 && kTileStream[first - 1] == s) --first;
+    const int part = tile - first;
+    const bool has_polar = (s == 0) || s >= 7;
+    const bool has_cart = s <= 6;
+    if (has_polar && part == 0) {  // EP 0..15
+        col = {i * kPolar + c, true, c, col.coef};
+    } else if (has_polar && part == 1) {  // EP 16..24, then (m only) EC 0..6
+        if (c < 9) col = {i * kPolar + 16 + c, true, 16 + c, col.coef};
+        else if (s == 0) col = {kDimsIn * kPolar + (c - 9), false, c - 9, col.coef};
+    } else if (s == 0 && part == 2) {  // m: EC 7, 8
+        if (c < 2) col = {kDimsIn * kPolar + 7 + c, false, 7 + c, col.coef};
+    } else if (has_cart && s != 0) {  // abs streams: EC 0..8
+        if (c < kCart) col = {kDimsIn * kPolar + i * kCart + c, false, c, col.coef};
+    }
+    return col;
+}
+
+}  // namespace
+
+std::string load_pca_safetensors(const std::string &path, PcaModel &out) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return "cannot open " + path;
+    std::string err;
+    uint64_t hlen = 0;
+    std::vector<char> hdr;
+    if (std::fread(&hlen, 8, 1, f) != 1 || hlen == 0 || hlen > (1u << 20)) err = "bad header length";
+    if (err.empty()) {
+        hdr.assign(hlen + 1, 0);
+        if (std::fread(hdr.data(), 1, hlen, f) != hlen) err = "truncated header";
+    }
+    auto tensor = [&](const char *name, size_t count, std::vector<float> &dst) {
+        if (!err.empty()) return;
+        const std::string key = std::string("\"") + name + "\"";
+        const char *p = std::strstr(hdr.data(), key.c_str());
+        if (p) p = std::strstr(p, "\"data_offsets\"");
+        if (p) p = std::strchr(p, '[');
+        long b = 0, e = 0;
+        if (!p || std::sscanf(p, "[%ld,%ld]", &b, &e) != 2 || size_t(e - b) != count * 4) {
+            err = std::string("tensor '") + name + "' missing or of unexpected size";
+            return;
+        }
+        dst.resize(count);
+        std::fseek(f, long(8 + hlen) + b, SEEK_SET);
+        if (std::fread(dst.data(), 4, count, f) != count) err = "truncated tensor data";
+    };
+    tensor("mean", kRaw, out.mean);
+    tensor("eigvals", kRaw, out.eigvals);
+    tensor("eigvecs", size_t(kRaw) * kRaw, out.eigvecs);
+    std::fclose(f);
+    return err.empty() ? "" : path + ": " + err;
+}
+
+void build_host_consts(const PcaModel &pca, HostConsts &hc) {
+    static const Grid grid;
+    const float kPi = 3.14159265358979323846f, kSqrt2 = 1.41421356237309504880f;
+
+    // gradient_angle = -atan2(y, x) of the pixel grid; rho with its epsilon (mkd_ref.rs:133-144)
+    hc.gradient_angle.resize(kPx);
+    std::vector<float> rho(kPx), gauss(kPx);
+    float max_norm = 0.f;
+    for (int p = 0; p < kPx; ++p) {
+        hc.gradient_angle[p] = -std::atan2(grid.y[p], grid.x[p]);
+        rho[p] = std::sqrt(grid.x[p] * grid.x[p] + grid.y[p] * grid.y[p] + 1e-8f);
+        max_norm = std::fmax(max_norm, std::sqrt(grid.x[p] * grid.x[p] + grid.y[p] * grid.y[p]));
+    }
+    for (int p = 0; p < kPx; ++p) {  // mkd_ref.rs:259-267, sigma = 1
+        const float nn = std::sqrt(grid.x[p] * grid.x[p] + grid.y[p] * grid.y[p]) / max_norm;
+        gauss[p] = std::exp((nn * nn) / -1.f);
+    }
+    // EC[a*3+b] = vM1(x pi/2)[a] vM1(y pi/2)[b] G   (mkd_ref.rs:210-231, mod.rs:1614-1615)
+    hc.embedding_cartesian.resize(size_t(kCart) * kPx);
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            for (int p = 0; p < kPx; ++p) {
+                const float ea = vm_component(kVmN1K1, 1, a, grid.x[p] * (kPi / 2.f));
+                const float eb = vm_component(kVmN1K1, 1, b, grid.y[p] * (kPi / 2.f));
+                hc.embedding_cartesian[size_t(a * 3 + b) * kPx + p] = (ea * eb) * gauss[p];
+            }
+    // EP[a*5+b] = vM2(+atan2)[a] vM2(rho pi/sqrt2)[b] G   (mkd_ref.rs:233-257, mod.rs:1616-1617)
+    hc.embedding_polar.resize(size_t(kPolar) * kPx);
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b)
+            for (int p = 0; p < kPx; ++p) {
+                const float ea = vm_component(kVmN2K8, 2, a, hc.gradient_angle[p] * -1.f);
+                const float eb = vm_component(kVmN2K8, 2, b, rho[p] * kPi / kSqrt2);
+                hc.embedding_polar[size_t(a * 5 + b) * kPx + p] = (ea * eb) * gauss[p];
+            }
+    // W_T[r][c] = eigvecs[c][r] * eigvals[r]^(-0.35)   (mod.rs:1604-1612)
+    hc.mean = pca.mean;
+    hc.w_t.resize(size_t(kOut) * kRaw);
+    const float expo = -0.5f * 0.7f;
+    for (int r = 0; r < kOut; ++r) {
+        const float s = std::pow(pca.eigvals[r], expo);
+        for (int c = 0; c < kRaw; ++c) hc.w_t[size_t(r) * kRaw + c] = pca.eigvecs[size_t(c) * kRaw + r] * s;
+    }
+
+    // ---- device layouts ----
+    hc.phi_cs.resize(size_t(kPx) * 2);
+    for (int p = 0; p < kPx; ++p) {
+        hc.phi_cs[2 * p] = float(std::cos(double(hc.gradient_angle[p])));
+        hc.phi_cs[2 * p + 1] = float(std::sin(double(hc.gradient_angle[p])));
+    }
+    hc.colmap.assign(kPackedCols, -1);
+    for (int t = 0; t < kTiles; ++t)
+        for (int c = 0; c < kTileCols; ++c) hc.colmap[t * kTileCols + c] = int16_t(column_of(t, c).desc);
+
+    auto lut_value = [&](const Column &col, int px) -> float {
+        if (col.desc < 0) return 0.f;
+        const float e = col.polar ? hc.embedding_polar[size_t(col.j) * kPx + px]
+                                  : hc.embedding_cartesian[size_t(col.j) * kPx + px];
+        return col.coef * e;
+    };
+    hc.pool_b_f32.assign(size_t(kPatch) * kTiles * 2 * 64 * 4, 0.f);
+    hc.pool_b_f16.assign(size_t(kPatch) * kTiles * 2 * 64 * 8, 0);
+    for (int y = 0; y < kPatch; ++y)
+        for (int t = 0; t < kTiles; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+                const Column col = column_of(t, lane & 15);
+                const int q = lane >> 4;
+                for (int e = 0; e < 8; ++e) {
+                    const float v = lut_value(col, y * kPatch + 8 * q + e);
+                    hc.pool_b_f32[(((size_t(y) * kTiles + t) * 2 + (e >> 2)) * 64 + lane) * 4 + (e & 3)] = v;
+                    const uint16_t hi = f16_bits(v);
+                    const uint16_t lo = f16_bits((v - f16_value(hi)) * 2048.f);
+                    hc.pool_b_f16[(((size_t(y) * kTiles + t) * 2 + 0) * 64 + lane) * 8 + e] = hi;
+                    hc.pool_b_f16[(((size_t(y) * kTiles + t) * 2 + 1) * 64 + lane) * 8 + e] = lo;
+                }
+            }
+    constexpr int kKSteps = 60;  // 238 -> 240
+    hc.white_b_f32.assign(size_t(kKSteps) * 8 * 64, 0.f);
+    for (int ks = 0; ks < kKSteps; ++ks)
+        for (int t = 0; t < 8; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int k = 4 * ks + (lane >> 4), n = 16 * t + (lane & 15);
+                if (k < kRaw) hc.white_b_f32[(size_t(ks) * 8 + t) * 64 + lane] = hc.w_t[size_t(n) * kRaw + k];
+            }
+    hc.mean_pad.assign(240, 0.f);
+    for (int c = 0; c < kRaw; ++c) hc.mean_pad[c] = pca.mean[c];
+}
+
+}  // namespace lfmkd

@@ -1,0 +1,41 @@
+// Launch interface between the C ABI (lf_mkd.cpp) and the gfx950 kernels (mkd_device.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LF_ANGLE_SHADER 0
+#define LF_ANGLE_EXACT 1
+#define LF_POOL_F32 0
+#define LF_POOL_F16X3 1
+
+namespace lfmkd {
+
+constexpr int kMaxPyrLevels = 16;
+
+// Patch pyramid: levels packed back to back in one allocation; level l is w[l] x h[l] f32.
+struct PyramidDesc {
+    int levels;
+    int w[kMaxPyrLevels], h[kMaxPyrLevels];
+    long offset[kMaxPyrLevels];  // in floats
+};
+
+// Device copies of HostConsts' device layouts (mkd_consts.hpp).
+struct DeviceConsts {
+    float *phi_cs = nullptr;        // [1024][2]
+    short *colmap = nullptr;        // [336]
+    float *pool_b_f32 = nullptr;    // [32][21][2][64][4]
+    uint16_t *pool_b_f16 = nullptr; // [32][21][2][64][8]
+    float *white_b_f32 = nullptr;   // [60][8][64]
+    float *mean_pad = nullptr;      // [240]
+};
+
+void launch_pool_f32(const float *patches, long n, const DeviceConsts &dc, int angle_mode, float *pooled,
+                     hipStream_t stream);
+void launch_whiten_f32(const float *pooled, long n, const DeviceConsts &dc, float *out, float *raw_out,
+                       hipStream_t stream);
+void launch_sample_patches(const float *pyr, const PyramidDesc &pd, const float *kps, long n, float psf,
+                           float *patches, hipStream_t stream);
+void launch_build_pyramid(const float *image, float *pyr, float *tmp_a, float *tmp_b, const PyramidDesc &pd,
+                          hipStream_t stream);
+
+}  // namespace lfmkd

@@ -1,0 +1,95 @@
+"""Python face of the MI355X MKD descriptor path, mirroring the reference's pyo3 module
+`local_features_python` (python/src/lib.rs:11-160) for the part of it this build covers.
+
+The reference class exposes `detect` / `detect_top_n` (detector + describe in one call,
+python/src/lib.rs:86-149); there is no public describe-only call.  This build accelerates the
+describe half, so the class keeps the constructor signature, the Keypoint
+type and the `(list[Keypoint], ndarray[n,128] f32)` result shape, and adds `describe`, which takes
+the keypoint list the detector would have produced.  `detect*` raise: the detector is a "next"
+row, and nothing here falls back to a CPU path.
+"""
+import threading
+
+import numpy as np
+
+from ._lib import (ANGLE_EXACT, ANGLE_SHADER, KEYPOINT_DTYPE, LIB_PATH, MODEL_DIR, PCA_NAMES,
+                   POOL_F16X3, POOL_F32, SYMBOLS, MkdHandle, load_library, model_path)
+
+__all__ = ["Keypoint", "LocalFeatures", "MkdHandle", "ANGLE_SHADER", "ANGLE_EXACT", "POOL_F32",
+           "POOL_F16X3", "KEYPOINT_DTYPE", "PCA_NAMES", "SYMBOLS", "LIB_PATH", "MODEL_DIR",
+           "load_library", "model_path"]
+
+
+class Keypoint:
+    """python/src/lib.rs:11-23; angle in degrees (keypoint_orientation.glsl:162-167)."""
+    __slots__ = ("x", "y", "size", "angle", "response")
+
+    def __init__(self, x, y, size, angle, response=0.0):
+        self.x, self.y, self.size, self.angle, self.response = (
+            float(x), float(y), float(size), float(angle), float(response))
+
+    def __repr__(self):
+        return (f"Keypoint(x={self.x:.3f}, y={self.y:.3f}, size={self.size:.3f}, "
+                f"angle={self.angle:.2f}, response={self.response:.4f})")
+
+
+def _keypoints_to_array(keypoints):
+    if isinstance(keypoints, np.ndarray):
+        if keypoints.dtype == KEYPOINT_DTYPE:
+            return np.ascontiguousarray(keypoints)
+        k = np.ascontiguousarray(keypoints, np.float32)
+        if k.ndim != 2 or k.shape[1] not in (4, 5):
+            raise RuntimeError("keypoints array must be [n,4] (x,y,size,angle) or [n,5] (+response)")
+        if k.shape[1] == 4:
+            k = np.concatenate([k, np.zeros((k.shape[0], 1), np.float32)], axis=1)
+        return np.ascontiguousarray(k)
+    return np.array([(k.x, k.y, k.size, k.angle, k.response) for k in keypoints],
+                    dtype=np.float32).reshape(-1, 5)
+
+
+class LocalFeatures:
+    """LocalFeatures(max_image_width, max_image_height, max_features, max_blobs, n_scales, pca)
+    -- python/src/lib.rs:43-84.  max_blobs and n_scales belong to the detector and are kept only
+    for signature compatibility."""
+
+    def __init__(self, max_image_width, max_image_height, max_features, max_blobs=8000, n_scales=4,
+                 pca="liberty", device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_F32):
+        if pca not in PCA_NAMES:
+            raise RuntimeError("Invalid PCA argument")
+        try:
+            self._inner = MkdHandle(pca=pca, max_features=max_features, max_image_width=max_image_width,
+                                    max_image_height=max_image_height, device=device,
+                                    angle_mode=angle_mode, pool_mode=pool_mode)
+        except RuntimeError as e:   # python/src/lib.rs:77-82
+            raise RuntimeError("Failed to initialize local features", str(e)) from e
+        self._lock = threading.Lock()   # Mutex<LocalFeaturesVulkan>, python/src/lib.rs:38
+        self.max_blobs, self.n_scales = max_blobs, n_scales
+
+    def describe(self, img, keypoints):
+        """img: 2-D float32 array in [0,1]; keypoints: list[Keypoint] or [n,4|5] array.
+        Returns (list[Keypoint], ndarray[n,128] float32), the reference's result shape."""
+        arr = np.asarray(img)
+        if arr.ndim != 2:
+            raise RuntimeError("Failed to extract features", "image must be 2-dimensional")
+        kps = _keypoints_to_array(keypoints)
+        with self._lock:
+            try:
+                self._inner.set_image(arr)
+                desc = self._inner.describe_keypoints(kps)
+            except RuntimeError as e:   # python/src/lib.rs:97-102
+                raise RuntimeError("Failed to extract features", str(e)) from e
+        out_k = [Keypoint(*row) for row in kps.reshape(-1, 5)] if not isinstance(keypoints, list) else keypoints
+        return out_k, desc
+
+    def describe_patches(self, patches):
+        """patches: [n,32,32] float32 -> ndarray[n,128] (the CPU twin's Mkd::patch, mkd_ref.rs:57-77)."""
+        with self._lock:
+            return self._inner.describe_patches(patches)
+
+    def detect(self, img):
+        raise NotImplementedError("detector (scan_extrema + orientation) is outside this build's hot path; "
+                                  "use describe(img, keypoints) -- SURVEY.md 8(f)")
+
+    def detect_top_n(self, img, n, min_size):
+        raise NotImplementedError("detector (scan_extrema + orientation) is outside this build's hot path; "
+                                  "use describe(img, keypoints) -- SURVEY.md 8(f)")

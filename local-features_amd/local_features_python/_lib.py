@@ -1,0 +1,171 @@
+"""ctypes binding of liblf_mkd.so (include/lf_mkd.h).  No fallback: if the HIP library is
+missing or no gfx950 device is visible, construction raises."""
+import ctypes
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_ROOT, "liblf_mkd.so")
+MODEL_DIR = os.path.join(_ROOT, "models", "mkd")
+
+ANGLE_SHADER, ANGLE_EXACT = 0, 1
+POOL_F32, POOL_F16X3 = 0, 1
+PCA_NAMES = ("liberty", "notredame", "yosemite")   # enum MKDPCA, lib.rs:26-32
+
+# every symbol include/lf_mkd.h declares
+SYMBOLS = (
+    "lf_mkd_create", "lf_mkd_create_from_file", "lf_mkd_destroy", "lf_mkd_last_error",
+    "lf_mkd_describe_patches", "lf_mkd_describe_patches_device", "lf_mkd_raw_descriptors_device",
+    "lf_mkd_set_image", "lf_mkd_set_image_device", "lf_mkd_describe_keypoints",
+    "lf_mkd_describe_keypoints_device", "lf_mkd_sample_patches_device", "lf_mkd_get_pyramid_level",
+    "lf_mkd_build_constants", "lf_mkd_synchronize", "lf_mkd_version",
+)
+
+
+class Params(ctypes.Structure):
+    _fields_ = [
+        ("max_image_width", ctypes.c_uint32), ("max_image_height", ctypes.c_uint32),
+        ("max_features", ctypes.c_uint32), ("patch_scale_factor", ctypes.c_float),
+        ("device", ctypes.c_int32), ("angle_mode", ctypes.c_int32), ("pool_mode", ctypes.c_int32),
+        ("reserved", ctypes.c_uint32 * 5),
+    ]
+
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4")])
+
+_lib = None
+
+
+def model_path(pca):
+    if pca not in PCA_NAMES:
+        raise RuntimeError("Invalid PCA argument")   # python/src/lib.rs:60-64
+    return os.path.join(MODEL_DIR, f"concat-pca-{pca}.safetensors")
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not built: run `make -C local-features_amd` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64, and a
+    # process that loads the system copy first and torch's second ends up with two HSA runtimes (torch
+    # then sees no device).  Callers hand us torch device pointers and streams, so let torch load its
+    # runtime first; liblf_mkd.so's libamdhip64.so.7 dependency then binds to the copy already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u64, u32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32
+    L.lf_mkd_version.restype = ctypes.c_char_p
+    L.lf_mkd_last_error.restype = ctypes.c_char_p
+    L.lf_mkd_last_error.argtypes = [vp]
+    L.lf_mkd_create.argtypes = [ctypes.POINTER(Params), vp, vp, vp, ctypes.POINTER(vp)]
+    L.lf_mkd_create_from_file.argtypes = [ctypes.POINTER(Params), ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.lf_mkd_destroy.argtypes = [vp]
+    L.lf_mkd_destroy.restype = None
+    L.lf_mkd_describe_patches.argtypes = [vp, vp, u64, vp]
+    L.lf_mkd_describe_patches_device.argtypes = [vp, vp, u64, vp, vp]
+    L.lf_mkd_raw_descriptors_device.argtypes = [vp, vp, u64, vp, vp]
+    L.lf_mkd_set_image.argtypes = [vp, vp, u32, u32]
+    L.lf_mkd_set_image_device.argtypes = [vp, vp, u32, u32, vp]
+    L.lf_mkd_describe_keypoints.argtypes = [vp, vp, u64, vp]
+    L.lf_mkd_describe_keypoints_device.argtypes = [vp, vp, u64, vp, vp]
+    L.lf_mkd_sample_patches_device.argtypes = [vp, vp, u64, vp, vp]
+    L.lf_mkd_get_pyramid_level.argtypes = [vp, u32, vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.lf_mkd_synchronize.argtypes = [vp]
+    L.lf_mkd_build_constants.argtypes = [vp] * 7
+    _lib = L
+    return L
+
+
+class MkdHandle:
+    """Thin owner of one lf_mkd handle.  Host arrays are numpy; device arguments are raw
+    pointers (ints), e.g. torch.Tensor.data_ptr()."""
+
+    def __init__(self, pca="liberty", max_features=2000, max_image_width=0, max_image_height=0,
+                 patch_scale_factor=24.0, device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_F32):
+        self._h = None
+        self.L = load_library()
+        p = Params(max_image_width=max_image_width, max_image_height=max_image_height,
+                   max_features=max_features, patch_scale_factor=patch_scale_factor,
+                   device=device, angle_mode=angle_mode, pool_mode=pool_mode)
+        h = ctypes.c_void_p()
+        rc = self.L.lf_mkd_create_from_file(ctypes.byref(p), model_path(pca).encode(), ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"lf_mkd_create failed ({rc}): {self.L.lf_mkd_last_error(None).decode()}")
+        self._h = h
+
+    def close(self):
+        if self._h is not None:
+            self.L.lf_mkd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.L.lf_mkd_last_error(self._h).decode()}")
+
+    # --- host-pointer entry points -----------------------------------------------------------
+    def describe_patches(self, patches):
+        p = np.ascontiguousarray(patches, np.float32).reshape(-1, 32, 32)
+        out = np.empty((p.shape[0], 128), np.float32)
+        self._check(self.L.lf_mkd_describe_patches(self._h, p.ctypes.data, p.shape[0], out.ctypes.data),
+                    "lf_mkd_describe_patches")
+        return out
+
+    def set_image(self, img):
+        if img.ndim != 2:
+            raise RuntimeError("image must be 2-D")
+        a = np.ascontiguousarray(img, np.float32)
+        self._check(self.L.lf_mkd_set_image(self._h, a.ctypes.data, a.shape[1], a.shape[0]), "lf_mkd_set_image")
+
+    def describe_keypoints(self, kps):
+        k = np.ascontiguousarray(kps)
+        if k.dtype != KEYPOINT_DTYPE:
+            k = np.ascontiguousarray(k, np.float32).reshape(-1, 5)
+        n = k.shape[0]
+        out = np.empty((n, 128), np.float32)
+        self._check(self.L.lf_mkd_describe_keypoints(self._h, k.ctypes.data, n, out.ctypes.data),
+                    "lf_mkd_describe_keypoints")
+        return out
+
+    def pyramid_level(self, level):
+        w, h = ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self.L.lf_mkd_get_pyramid_level(self._h, level, None, ctypes.byref(w), ctypes.byref(h)),
+                    "lf_mkd_get_pyramid_level")
+        out = np.empty((h.value, w.value), np.float32)
+        self._check(self.L.lf_mkd_get_pyramid_level(self._h, level, out.ctypes.data, None, None),
+                    "lf_mkd_get_pyramid_level")
+        return out
+
+    # --- device-pointer entry points ---------------------------------------------------------
+    def describe_patches_device(self, d_patches, n, d_out, stream=None):
+        self._check(self.L.lf_mkd_describe_patches_device(self._h, d_patches, n, d_out, stream),
+                    "lf_mkd_describe_patches_device")
+
+    def raw_descriptors_device(self, d_patches, n, d_raw, stream=None):
+        self._check(self.L.lf_mkd_raw_descriptors_device(self._h, d_patches, n, d_raw, stream),
+                    "lf_mkd_raw_descriptors_device")
+
+    def set_image_device(self, d_image, width, height, stream=None):
+        self._check(self.L.lf_mkd_set_image_device(self._h, d_image, width, height, stream),
+                    "lf_mkd_set_image_device")
+
+    def describe_keypoints_device(self, d_kps, n, d_out, stream=None):
+        self._check(self.L.lf_mkd_describe_keypoints_device(self._h, d_kps, n, d_out, stream),
+                    "lf_mkd_describe_keypoints_device")
+
+    def sample_patches_device(self, d_kps, n, d_patches, stream=None):
+        self._check(self.L.lf_mkd_sample_patches_device(self._h, d_kps, n, d_patches, stream),
+                    "lf_mkd_sample_patches_device")
+
+    def synchronize(self):
+        self._check(self.L.lf_mkd_synchronize(self._h), "lf_mkd_synchronize")

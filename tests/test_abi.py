@@ -1,0 +1,66 @@
+"""CPU tests of the drop-in boundary: liblf_mkd.so loads, exports every symbol include/lf_mkd.h
+declares, builds the same constants as the oracle, and fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+import local_features_python as lfp
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "lf_mkd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(lf_mkd_[a-z_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = lfp.load_library()
+    declared = _declared_symbols()
+    assert declared == sorted(lfp.SYMBOLS)
+    for s in declared:
+        assert hasattr(L, s), f"liblf_mkd.so does not export {s}"
+    assert L.lf_mkd_version().decode().startswith("lf_mkd ") and b"gfx950" in L.lf_mkd_version()
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(lfp._lib.Params) == 48          # lf_mkd_params
+    assert lfp.KEYPOINT_DTYPE.itemsize == 20             # lf_mkd_keypoint: x,y,size,angle,response
+
+
+def test_host_constants_match_oracle(oracle):
+    L = lfp.load_library()
+    ga = np.zeros(1024, np.float32)
+    ep = np.zeros(25 * 1024, np.float32)
+    ec = np.zeros(9 * 1024, np.float32)
+    wt = np.zeros(128 * 238, np.float32)
+    rc = L.lf_mkd_build_constants(oracle.mean.ctypes.data, oracle.eigvals.ctypes.data, oracle.eigvecs.ctypes.data,
+                                  ga.ctypes.data, ep.ctypes.data, ec.ctypes.data, wt.ctypes.data)
+    assert rc == 0
+    assert np.abs(ga - oracle.gradient_angle.ravel()).max() < 1e-6
+    assert np.abs(ep - oracle.embedding_polar.ravel()).max() < 1e-6
+    assert np.abs(ec - oracle.embedding_cartesian.ravel()).max() < 1e-6
+    assert np.allclose(wt, oracle.eigen_vecs.ravel(), rtol=2e-6, atol=1e-7)
+
+
+def test_bad_arguments_are_reported_not_fatal():
+    L = lfp.load_library()
+    h = ctypes.c_void_p()
+    assert L.lf_mkd_create_from_file(None, b"x", ctypes.byref(h)) != 0
+    p = lfp._lib.Params(device=0)
+    assert L.lf_mkd_create_from_file(ctypes.byref(p), b"/nonexistent.safetensors", ctypes.byref(h)) == -3
+    assert b"nonexistent" in L.lf_mkd_last_error(None)
+    with pytest.raises(RuntimeError, match="Invalid PCA argument"):       # python/src/lib.rs:60-64
+        lfp.LocalFeatures(640, 480, 100, pca="oxford")
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="Failed to initialize local features"):
+        lfp.LocalFeatures(640, 480, 100)

@@ -1,0 +1,115 @@
+"""CPU tests: the C oracle against the committed float64 goldens (tools/gen_golden.py), against
+known values derived from the reference's sources, and against properties of the algorithm.
+The reference ships no golden vectors of its own (mkd_ref.rs:393-453 names absent files)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MODELS, golden, rel_l2
+from oracle import ATAN_LIBM, ATAN_SHADER
+
+# sha256 of the reference's model files
+SHA = {"liberty": "bb731ff7d9d900184fb1dcf720826cf5e4ce8f9331351c83367a324dc1041773",
+       "notredame": "9bf382ad89dd90d40dd06aef3477115e1ec3c090aa2d7e32c88b7d03ca3f8c16",
+       "yosemite": "cf2beffc3bc5a78f4b67643db732bf562fc91ce9cbb54d120ff37f111de9fac0"}
+
+
+@pytest.mark.parametrize("name", sorted(SHA))
+def test_model_files_are_the_reference_data(name):
+    b = open(os.path.join(MODELS, f"concat-pca-{name}.safetensors"), "rb").read()
+    assert len(b) == 228696
+    assert hashlib.sha256(b).hexdigest() == SHA[name]
+
+
+def test_pca_model_properties(oracle):
+    # eigvals normalised, descending; eigvec columns unit norm
+    assert oracle.eigvals[0] == pytest.approx(1.0)
+    assert np.all(np.diff(oracle.eigvals[:128]) <= 0)
+    assert np.allclose(np.linalg.norm(oracle.eigvecs, axis=0), 1.0, atol=1e-4)
+    w = oracle.eigvecs[:, :128] * oracle.eigvals[:128] ** np.float32(-0.35)
+    assert np.allclose(oracle.eigen_vecs, w.T, rtol=2e-6, atol=1e-7)
+
+
+def test_luts_match_float64_restatement(oracle):
+    g = golden("luts.npz")
+    assert np.abs(oracle.gradient_angle - g["gradient_angle"]).max() < 2e-6
+    assert np.abs(oracle.embedding_polar - g["embedding_polar"]).max() < 2e-6
+    assert np.abs(oracle.embedding_cartesian - g["embedding_cartesian"]).max() < 1e-6
+
+
+def test_lut_known_values(oracle):
+    ep, ec = oracle.embedding_polar, oracle.embedding_cartesian
+    assert ep.shape == (25, 32, 32) and ec.shape == (9, 32, 32)
+    c0p, c0c = np.float32(0.37872374), np.float32(0.618176)
+    # kernel 0 = c0*c0*G: corner G = e^-1, centre 4 px G = 0.99895996 (mkd_ref.rs:259-267)
+    assert ep[0, 0, 0] == pytest.approx(c0p * c0p * 0.36787944, rel=1e-5)
+    assert ec[0, 0, 0] == pytest.approx(c0c * c0c * 0.36787944, rel=1e-5)
+    assert ec[0, 15, 15] == pytest.approx(c0c * c0c * 0.99895996, rel=1e-5)
+    assert ec[0, 16, 16] == pytest.approx(ec[0, 15, 15], rel=1e-6)
+    # gradient_angle = -atan2(y, x): top-left pixel (x=-1,y=-1) -> +3pi/4
+    assert oracle.gradient_angle[0, 0] == pytest.approx(0.75 * np.pi, rel=1e-6)
+    assert oracle.gradient_angle[31, 31] == pytest.approx(-0.25 * np.pi, rel=1e-6)
+
+
+def test_shader_atan2_quirks(oracle):
+    """shaders/atan2.glsl:19-46."""
+    a = oracle.atan2_shader
+    assert a(0.0, 0.0) == 0.0
+    assert a(0.0, 1.0) == 0.0          # libm: +pi/2
+    assert a(0.0, -3.0) == 0.0         # libm: -pi/2
+    assert a(-0.0, 0.0) == 0.0
+    assert a(-1.0, 0.0) == pytest.approx(np.pi, rel=1e-6)   # y == 0 -> +pi
+    rng = np.random.default_rng(1)
+    for x, y in rng.normal(size=(2000, 2)).astype(np.float32):
+        assert abs(a(x, y) - np.arctan2(y, x)) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["liberty", "notredame", "yosemite"])
+def test_oracle_matches_float64_goldens(oracles, name):
+    g = golden(f"patches_{name}.npz")
+    for mode, key in ((ATAN_SHADER, "shader"), (ATAN_LIBM, "libm")):
+        d, raw = oracles[name].describe_patches(g["patches"], atan_mode=mode, want_raw=True)
+        assert rel_l2(raw, g[f"raw_{key}"]).max() < 1e-5
+        assert rel_l2(d, g[f"desc_{key}"]).max() < 1e-5
+        assert np.abs(d - g[f"desc_{key}"]).max() < 1e-5      # mkd_ref.rs:426-427 asks 1e-4
+
+
+def test_keypoint_mode_matches_float64_goldens(oracle):
+    g = golden("keypoints_liberty.npz")
+    img = g["image"]
+    h, w = img.shape
+    pyr = oracle.build_pyramid(img)
+    lv = oracle.split_pyramid(pyr, w, h)
+    assert len(lv) == 8 and lv[1].shape == (68, 100) and lv[3].shape == (17, 25)
+    assert np.abs(lv[1] - g["level1"]).max() < 1e-6
+    assert np.abs(lv[3] - g["level3"]).max() < 1e-6
+    p = oracle.sample_patches(pyr, w, h, g["keypoints"])
+    assert np.abs(p - g["patches"]).max() < 5e-6
+    assert rel_l2(oracle.describe_patches(p), g["desc_shader"]).max() < 5e-5
+
+
+def test_properties(oracle):
+    rng = np.random.default_rng(3)
+    p = rng.random((8, 32, 32)).astype(np.float32)
+    d, raw = oracle.describe_patches(p, want_raw=True)
+    assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-5)
+    assert np.allclose(np.linalg.norm(raw, axis=1), 1.0, atol=1e-5)
+    # polar and cartesian halves each carry norm 1/sqrt(2) (normalize.glsl)
+    assert np.allclose(np.linalg.norm(raw[:, :175], axis=1), np.sqrt(0.5), atol=1e-5)
+    # additive constants vanish in the gradient; positive gain only moves the 1e-8 epsilon
+    d2 = oracle.describe_patches(p * np.float32(0.5) + np.float32(0.25))
+    assert rel_l2(d2, d).max() < 2e-4
+    # flat patch: mag == 0.01, angle == 0 everywhere, whatever the constant
+    f1 = oracle.describe_patches(np.full((1, 32, 32), 0.2, np.float32))
+    f2 = oracle.describe_patches(np.full((1, 32, 32), 0.9, np.float32))
+    assert np.array_equal(f1, f2)
+    mag, ang = oracle.patch_gradients(np.full((32, 32), 0.5, np.float32))
+    assert np.allclose(mag, 0.01) and np.all(ang == 0)
+
+
+def test_threads_agree(oracle):
+    rng = np.random.default_rng(5)
+    p = rng.random((37, 32, 32)).astype(np.float32)
+    assert np.array_equal(oracle.describe_patches(p, nthreads=1), oracle.describe_patches(p, nthreads=4))
