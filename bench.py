@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- MKD descriptors/second on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+A "step" is one pass of the describe path (lf_mkd_describe_patches_device through the C ABI) over one
+batch of synthetic 32x32 f32 patches already resident in HBM.  Default workload: 2^20 patches per GPU
+(the per-GPU share of BASELINE.json configs[3]; SURVEY.md 8(d) headline "patch mode").  For N > 1 the
+driver launches one process per GPU (torch.distributed, backend nccl = RCCL); patches shard by rank
+with no data-path collective, so scaling is "weak".
+
+Extra objects on the line:
+  roofline      dominant kernel (pooling) vs the 8 TB/s HBM roof: algorithmic bytes per launch
+                (4608 B x descriptors) / its mean launch time from HIP events recorded
+                by the library on the launch stream (lf_mkd_kernel_times)
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm) timed on this host, rank 0, N=1,
+                on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "local-features_amd"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_DESC = 4608          # 4096 B patch read + 512 B descriptor write
+
+
+def cpu_baseline(n_sample, seed):
+    """Oracle (oracle/mkd_oracle.c) on the host cores; the only place bench.py touches oracle/."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import MkdOracle
+    cores = len(os.sched_getaffinity(0))
+    o = MkdOracle(os.path.join(ROOT, "local-features_amd", "models", "mkd", "concat-pca-liberty.safetensors"))
+    p = np.random.default_rng(seed).random((n_sample, 32, 32), dtype=np.float32)
+    o.describe_patches(p[:256], nthreads=cores)                    # warm
+    t0 = time.perf_counter()
+    o.describe_patches(p, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "descriptors/s", "cores": cores, "kind": "port",
+            "sample": f"{n_sample} uniform-random 32x32 patches, {cores} pthreads, {dt:.1f} s; "
+                      "LUTs and whitening matrix built once (the reference rebuilds them per patch)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--patches", type=int, default=1 << 20, help="patches per GPU per step")
+    ap.add_argument("--angle", choices=["shader", "exact"], default="shader")
+    ap.add_argument("--pool", choices=["f32", "f16x3"], default=os.environ.get("LF_MKD_POOL", "f32"))
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="patches for the CPU baseline (0: skip)")
+    args = ap.parse_args()
+
+    import torch
+    import local_features_python as lfp
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1) and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the describe path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n = args.patches
+    gen = torch.Generator(device="cuda").manual_seed(0x4D4B44 + rank)
+    patches = torch.rand((n, 32, 32), device="cuda", generator=gen)
+    out = torch.empty((n, 128), device="cuda")
+    h = lfp.MkdHandle(pca="liberty", max_features=n, device=local_rank,
+                      angle_mode=lfp.ANGLE_SHADER if args.angle == "shader" else lfp.ANGLE_EXACT,
+                      pool_mode=lfp.POOL_F32 if args.pool == "f32" else lfp.POOL_F16X3,
+                      flags=lfp.FLAG_KERNEL_TIMING)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        h.describe_patches_device(patches.data_ptr(), n, out.data_ptr(), stream)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    h.kernel_times()                       # drop warm-up events
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    pool_ms, whiten_ms, launches = h.kernel_times()
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity on the timed output: finite, unit norm (a wrong-but-fast kernel must not pass silently)
+    nrm = out.norm(dim=1)
+    ok = bool(torch.isfinite(out).all().item()) and float((nrm - 1).abs().max().item()) < 1e-4
+    if not ok:
+        raise SystemExit("bench.py: descriptors are not finite / unit norm")
+
+    if rank == 0:
+        total = n * world * args.steps
+        kern_s = pool_ms / 1e3 / max(launches, 1)
+        achieved = BYTES_PER_DESC * n / kern_s / 1e9 if kern_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("patches") == n and tj.get("pool") == args.pool:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "MKD descriptors/sec (32x32 patch, 128-D)", "value": total / dt, "unit": "descriptors/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.pool == "f32" else "f32 (f16x3 split MFMA pooling)",
+            "data": "synthetic",
+            "config": {"workload": f"patch mode: {n} uniform-random 32x32 f32 patches per GPU resident in HBM "
+                                   "(per-GPU share of BASELINE configs[3]; SURVEY 8(d) headline), PCA=liberty",
+                       "patches_per_gpu": n, "angle_mode": args.angle, "pool_mode": args.pool,
+                       "parallelism": f"shard-by-rank x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "mkd_pool", "kernel_ms": kern_s * 1e3,
+                         "whiten_kernel_ms": whiten_ms / max(launches, 1),
+                         "algorithmic_bytes_per_launch": BYTES_PER_DESC * n},
+        }
+        if world == 1:
+            ns = args.cpu_sample
+            if ns < 0:
+                ns = 131072
+            if ns > 0:
+                cb = cpu_baseline(8192, 1)          # calibrate: aim at ~15 s
+                ns = int(min(max(cb["value"] * 15, 8192), ns * 4))
+                line["cpu_baseline"] = cpu_baseline(ns, 0x4D4B44)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,10 @@ typedef enum { LF_MKD_ANGLE_SHADER = 0, LF_MKD_ANGLE_EXACT = 1 } lf_mkd_angle_mo
  *           f32 accumulate; ~2^-21 relative per product. */
 typedef enum { LF_MKD_POOL_F32 = 0, LF_MKD_POOL_F16X3 = 1 } lf_mkd_pool_mode;
 
+/* lf_mkd_params.flags */
+#define LF_MKD_FLAG_KERNEL_TIMING 1u /* bracket every kernel launch with HIP events on its stream;
+                                        read the sums with lf_mkd_kernel_times (bench.py's roofline) */
+
 /* Mirrors BuildTimeParams (lib.rs:54-75) + FeatureDetectParams (lib.rs:34-52) for this path.
  * Zero-initialise, then set what you need; 0 means "default". */
 typedef struct {
@@ -64,7 +68,8 @@ typedef struct {
     int32_t device;             /* HIP device ordinal                                          */
     int32_t angle_mode;         /* lf_mkd_angle_mode                                           */
     int32_t pool_mode;          /* lf_mkd_pool_mode                                            */
-    uint32_t reserved[5];
+    uint32_t flags;             /* LF_MKD_FLAG_*                                               */
+    uint32_t reserved[4];
 } lf_mkd_params;
 
 /* Keypoint as the path consumes it: struct Keypoint, lib.rs:17-24 (angle in DEGREES,
@@ -130,6 +135,11 @@ int lf_mkd_get_pyramid_level(lf_mkd *h, uint32_t level, float *out, uint32_t *w,
 int lf_mkd_build_constants(const float *mean, const float *eigvals, const float *eigvecs,
                            float *gradient_angle, float *embedding_polar,
                            float *embedding_cartesian, float *w_t);
+
+/* With LF_MKD_FLAG_KERNEL_TIMING: waits for the recorded launches, returns the summed device time
+ * (ms) of the pooling and of the whitening kernel and the number of batches since the previous
+ * call, then resets the sums.  Any output pointer may be NULL. */
+int lf_mkd_kernel_times(lf_mkd *h, double *pool_ms, double *whiten_ms, uint64_t *launches);
 
 /* Blocks until everything enqueued on the handle's own stream has finished. */
 int lf_mkd_synchronize(lf_mkd *h);

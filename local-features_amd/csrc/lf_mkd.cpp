@@ -6,9 +6,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "mkd_consts.hpp"
 #include "mkd_device.h"
@@ -28,6 +30,10 @@ struct lf_mkd {
     PyramidDesc pd{};
     float *d_image = nullptr, *d_pyr = nullptr, *d_tmp_a = nullptr, *d_tmp_b = nullptr;
     bool have_image = false;
+    int num_cus = 256;
+    bool pool_v1 = false;  // LF_MKD_POOL_V1=1: first-generation pooling kernel (A/B comparisons)
+    // LF_MKD_FLAG_KERNEL_TIMING: (start, after pooling, after whitening) per batch
+    std::vector<hipEvent_t> ev_pending, ev_free;
     std::string err;
 };
 
@@ -107,6 +113,13 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     } while (0)
     LF_CREATE_HIP(hipSetDevice(params->device));
     LF_CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    {
+        hipDeviceProp_t prop;
+        LF_CREATE_HIP(hipGetDeviceProperties(&prop, params->device));
+        h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        const char *v1 = std::getenv("LF_MKD_POOL_V1");
+        h->pool_v1 = v1 && v1[0] == '1';
+    }
     HostConsts hc;
     build_host_consts(pca, hc);
     LF_CREATE_HIP(upload(&h->dc.phi_cs, hc.phi_cs.data(), hc.phi_cs.size() * 4));
@@ -133,11 +146,32 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
 }
 
 // pooled sums -> descriptors for one batch already resident on the device
+int mark(lf_mkd *h, hipStream_t s) {
+    if (!(h->params.flags & LF_MKD_FLAG_KERNEL_TIMING)) return LF_MKD_OK;
+    hipEvent_t e;
+    if (!h->ev_free.empty()) {
+        e = h->ev_free.back();
+        h->ev_free.pop_back();
+    } else {
+        LF_HIP(h, hipEventCreate(&e));
+    }
+    h->ev_pending.push_back(e);
+    LF_HIP(h, hipEventRecord(e, s));
+    return LF_MKD_OK;
+}
+
 int run_batch(lf_mkd *h, const float *d_patches, uint64_t n, float *d_out, float *d_raw, hipStream_t s) {
-    launch_pool_f32(d_patches, long(n), h->dc, h->params.angle_mode, h->d_pooled, s);
+    if (int rc = mark(h, s)) return rc;
+    if (h->pool_v1)
+        launch_pool_f32(d_patches, long(n), h->dc, h->params.angle_mode, h->d_pooled, s);
+    else
+        launch_pool_lds(d_patches, long(n), h->dc, h->params.angle_mode, h->params.pool_mode, h->d_pooled,
+                        h->num_cus, s);
     LF_HIP(h, hipGetLastError());
+    if (int rc = mark(h, s)) return rc;
     launch_whiten_f32(h->d_pooled, long(n), h->dc, d_out ? d_out : h->d_out, d_raw, s);
     LF_HIP(h, hipGetLastError());
+    if (int rc = mark(h, s)) return rc;
     return LF_MKD_OK;
 }
 
@@ -194,11 +228,34 @@ void lf_mkd_destroy(lf_mkd *h) {
                     h->d_image,   h->d_pyr,     h->d_tmp_a,      h->d_tmp_b};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : h->ev_pending) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
 const char *lf_mkd_last_error(const lf_mkd *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int lf_mkd_kernel_times(lf_mkd *h, double *pool_ms, double *whiten_ms, uint64_t *launches) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    LF_HIP(h, hipSetDevice(h->params.device));
+    double tp = 0, tw = 0;
+    const size_t nb = h->ev_pending.size() / 3;
+    for (size_t i = 0; i < nb; ++i) {
+        float a = 0, b = 0;
+        LF_HIP(h, hipEventSynchronize(h->ev_pending[3 * i + 2]));
+        LF_HIP(h, hipEventElapsedTime(&a, h->ev_pending[3 * i], h->ev_pending[3 * i + 1]));
+        LF_HIP(h, hipEventElapsedTime(&b, h->ev_pending[3 * i + 1], h->ev_pending[3 * i + 2]));
+        tp += a;
+        tw += b;
+    }
+    h->ev_free.insert(h->ev_free.end(), h->ev_pending.begin(), h->ev_pending.end());
+    h->ev_pending.clear();
+    if (pool_ms) *pool_ms = tp;
+    if (whiten_ms) *whiten_ms = tw;
+    if (launches) *launches = nb;
+    return LF_MKD_OK;
+}
 
 int lf_mkd_synchronize(lf_mkd *h) {
     if (!h) return LF_MKD_ERR_BAD_ARG;

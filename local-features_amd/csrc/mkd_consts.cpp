@@ -187,11 +187,11 @@ void build_host_consts(const PcaModel &pca, HostConsts &hc) {
                 const int q = lane >> 4;
                 for (int e = 0; e < 8; ++e) {
                     const float v = lut_value(col, y * kPatch + 8 * q + e);
-                    hc.pool_b_f32[(((size_t(y) * kTiles + t) * 2 + (e >> 2)) * 64 + lane) * 4 + (e & 3)] = v;
+                    hc.pool_b_f32[(((size_t(y) * kTiles + tile_slot(t)) * 2 + (e >> 2)) * 64 + lane) * 4 + (e & 3)] = v;
                     const uint16_t hi = f16_bits(v);
-                    const uint16_t lo = f16_bits((v - f16_value(hi)) * 2048.f);
-                    hc.pool_b_f16[(((size_t(y) * kTiles + t) * 2 + 0) * 64 + lane) * 8 + e] = hi;
-                    hc.pool_b_f16[(((size_t(y) * kTiles + t) * 2 + 1) * 64 + lane) * 8 + e] = lo;
+                    const uint16_t lo = f16_bits(v - f16_value(hi));  // f16 subnormals survive the MFMA (tools/micro)
+                    hc.pool_b_f16[(((size_t(y) * kTiles + tile_slot(t)) * 2 + 0) * 64 + lane) * 8 + e] = hi;
+                    hc.pool_b_f16[(((size_t(y) * kTiles + tile_slot(t)) * 2 + 1) * 64 + lane) * 8 + e] = lo;
                 }
             }
     constexpr int kKSteps = 60;  // 238 -> 240

@@ -31,6 +31,8 @@ struct DeviceConsts {
 
 void launch_pool_f32(const float *patches, long n, const DeviceConsts &dc, int angle_mode, float *pooled,
                      hipStream_t stream);
+void launch_pool_lds(const float *patches, long n, const DeviceConsts &dc, int angle_mode, int pool_mode,
+                     float *pooled, int num_cus, hipStream_t stream);
 void launch_whiten_f32(const float *pooled, long n, const DeviceConsts &dc, float *out, float *raw_out,
                        hipStream_t stream);
 void launch_sample_patches(const float *pyr, const PyramidDesc &pd, const float *kps, long n, float psf,

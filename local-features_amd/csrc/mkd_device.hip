@@ -29,6 +29,9 @@ constexpr int kTiles = 21;
 __device__ constexpr int kTileStreamDev[kTiles] = {0, 0, 0, 7, 7, 8, 8, 9, 9, 10, 10,
                                                    11, 11, 12, 12, 1, 2, 3, 4, 5, 6};
 
+// position of tile t inside a LUT row image (host twin: mkd_consts.hpp tile_slot)
+__device__ __host__ constexpr int tile_slot(int t) { return t < 3 ? t : (t >= 15 ? 3 + (t - 15) : 9 + (t - 3)); }
+
 // 5-tap sigma=0.7 kernel, patch_gradients.glsl:22-28
 constexpr float kB0 = 0.0096f, kB1 = 0.2054f, kB2 = 0.5699f;
 
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void mkd_pool_f32(const float *__restrict__ pa
             pixel_streams<ANGLE>(gx[4 * jg + 3], gy[4 * jg + 3], pb[2], pb[3], av[3]);
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) {
-                const f32x4 b = lrow[(t * 2 + jg) * 64];
+                const f32x4 b = lrow[(tile_slot(t) * 2 + jg) * 64];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e][kTileStreamDev[t]], b[e], acc[t], 0, 0, 0);
@@ -226,6 +229,324 @@ __global__ __launch_bounds__(256) void mkd_pool_f32(const float *__restrict__ pa
         for (int i = 0; i < 4; ++i) {
             const long row = base + 4 * q + i;
             if (row < n) pooled[row * 238 + d] = acc[t][i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pooling, v2: B fragments (the spatial-kernel LUT) are streamed L2 -> LDS once per patch row and
+// shared by the 8 waves of a workgroup (128 patches per pass), double-buffered with one barrier per
+// row.  POOL selects the arithmetic: exact f32 MFMA, or f16 hi/lo split (3 f16 MFMAs per product).
+// The LUT row image in global memory is byte-for-byte the LDS image: 21 tiles x 2 pieces x 1 KiB
+// (f32: pieces = pixels 0-3 / 4-7 of the lane's segment; f16: pieces = hi / lo halves).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// LDS map of the pooling kernel (bytes)
+constexpr int kRowBytes = kTiles * 2 * 1024;        // 43008: one LUT row image = phase A pieces, then phase B
+constexpr int kPiecesA = 9 * 2, kPiecesB = 12 * 2;   // 1 KiB pieces per phase
+constexpr int kPhiOff = kRowBytes;                  // cos/sin(phi) table, 8 KiB
+constexpr int kRingOff = kPhiOff + 8192;            // raw patch rows: [wave 8][slot 6][2 KiB]
+constexpr int kRingSlots = 6;
+constexpr int kPoolLds = kRingOff + 8 * kRingSlots * 2048;   // 149504
+
+__device__ __forceinline__ void lds_dma16(const void *gsrc, void *ldst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+}
+
+// pieces [first, first+count) of LUT row `row`, spread over the 8 waves (wave-uniform control flow)
+__device__ __forceinline__ void issue_lut_pieces(const unsigned char *__restrict__ lut_rows, int row, int first,
+                                                 int count, unsigned char *s_mem, int wave, int lane) {
+    const unsigned char *g = lut_rows + (size_t)row * kRowBytes + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int i = wave + 8 * j;
+        if (i < count) lds_dma16(g + (first + i) * 1024, s_mem + (first + i) * 1024);
+    }
+}
+
+// one raw patch row (16 patches x 128 B) of this wave into ring slot `slot`; rows outside [0,31] replicate
+__device__ __forceinline__ void issue_raw_row(const float *__restrict__ src_lane, int row, unsigned char *ring,
+                                              int slot) {
+    const int y = row < 0 ? 0 : (row > 31 ? 31 : row);
+    lds_dma16(src_lane + y * 32, ring + slot * 2048);
+    lds_dma16(src_lane + y * 32 + 16, ring + slot * 2048 + 1024);
+}
+
+__device__ __forceinline__ unsigned pack_rtz(float a, float b) {
+    auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    return __builtin_bit_cast(unsigned, h);
+}
+
+// One A stream (8 pixels of this lane) against tiles [T0, T0+NT).
+template <int POOL, int T0, int NT>
+__device__ __forceinline__ void emit_stream(const float (&a)[8], const unsigned char *brow, f32x4 (&acc)[kTiles]) {
+    if constexpr (POOL == LF_POOL_F32) {
+#pragma unroll
+        for (int t = T0; t < T0 + NT; ++t) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(brow + (tile_slot(t) * 2 + 0) * 1024);
+            const f32x4 b1 = *reinterpret_cast<const f32x4 *>(brow + (tile_slot(t) * 2 + 1) * 1024);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 + e], b1[e], acc[t], 0, 0, 0);
+        }
+    } else {
+        // a = hi + lo with hi = f16 truncation of a (exact residual), lo = f16(a - hi)
+        u32x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned h = pack_rtz(a[2 * e], a[2 * e + 1]);
+            const float h0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xffffu));
+            const float h1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h >> 16));
+            hi[e] = h;
+            lo[e] = pack_rtz(a[2 * e] - h0, a[2 * e + 1] - h1);
+        }
+        const f16x8 ah = __builtin_bit_cast(f16x8, hi), al = __builtin_bit_cast(f16x8, lo);
+        f16x8 bh[NT], bl[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            bh[t] = *reinterpret_cast<const f16x8 *>(brow + (tile_slot(T0 + t) * 2 + 0) * 1024);
+            bl[t] = *reinterpret_cast<const f16x8 *>(brow + (tile_slot(T0 + t) * 2 + 1) * 1024);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[T0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[t], acc[T0 + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[T0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[t], acc[T0 + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[T0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[t], acc[T0 + t], 0, 0, 0);
+#ifdef LF_EXP_NOP
+        asm volatile("s_nop %0" ::"n"(LF_EXP_NOP));
+#endif
+    }
+}
+
+// Per-pixel base values of one patch row (8 pixels of this lane).
+template <int ANGLE>
+__device__ __forceinline__ void row_base(const float (&gx)[8], const float (&gy)[8], float (&m)[8], float (&c1)[8],
+                                         float (&s1)[8]) {
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        // patch_gradients.glsl:98-100: mag = sqrt(sqrt(gx^2 + gy^2 + eps))
+        m[x] = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(gx[x] * gx[x] + gy[x] * gy[x] + 1e-8f));
+        gradient_direction<ANGLE>(gx[x], gy[x], c1[x], s1[x]);
+    }
+}
+
+// Streams m cos(k t), m sin(k t), k = 1..3, for one orientation family (angle addition), against
+// TC tiles per cos stream starting at tile C0 and per sin stream starting at tile S0.
+template <int POOL, int C0, int S0, int NT>
+__device__ __forceinline__ void pool_family(const float (&m)[8], const float (&c1)[8], const float (&s1)[8],
+                                            const unsigned char *brow, f32x4 (&acc)[kTiles]) {
+    float ck[8], sk[8], v[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) { ck[x] = c1[x]; sk[x] = s1[x]; }
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] = m[x] * ck[x];
+    emit_stream<POOL, C0, NT>(v, brow, acc);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] = m[x] * sk[x];
+    emit_stream<POOL, S0, NT>(v, brow, acc);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) { const float c = ck[x] * c1[x] - sk[x] * s1[x]; sk[x] = sk[x] * c1[x] + ck[x] * s1[x]; ck[x] = c; }
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] = m[x] * ck[x];
+    emit_stream<POOL, C0 + NT, NT>(v, brow, acc);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] = m[x] * sk[x];
+    emit_stream<POOL, S0 + NT, NT>(v, brow, acc);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) { const float c = ck[x] * c1[x] - sk[x] * s1[x]; sk[x] = sk[x] * c1[x] + ck[x] * s1[x]; ck[x] = c; }
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] = m[x] * ck[x];
+    emit_stream<POOL, C0 + 2 * NT, NT>(v, brow, acc);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] = m[x] * sk[x];
+    emit_stream<POOL, S0 + 2 * NT, NT>(v, brow, acc);
+}
+
+// Blurred row of this lane's segment from the raw-row ring (patch_gradients.glsl:72-92): vertical 5 taps over
+// ring slots s0..s0+4, then horizontal 5 taps with the neighbours fetched from lanes -/+16.
+// Returns the row plus its x-1 / x+8 neighbours.
+__device__ __forceinline__ void blur_row(const unsigned char *ring_lane, int s0, int addr_l, int addr_r, bool has_l,
+                                         bool has_r, float (&out)[8], float &out_l, float &out_r) {
+    float vb[8];
+    const float kk[5] = {kB0, kB1, kB2, kB1, kB0};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int sl = s0 + i;
+        sl = sl >= kRingSlots ? sl - kRingSlots : sl;
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(ring_lane + sl * 2048);
+        const f32x4 hi = *reinterpret_cast<const f32x4 *>(ring_lane + sl * 2048 + 256);
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const float r = x < 4 ? lo[x & 3] : hi[x & 3];
+            vb[x] = i == 0 ? kk[0] * r : fmaf(kk[i], r, vb[x]);
+        }
+    }
+    float ext[12];
+    const float l0 = lane_fetch(addr_l, vb[6]), l1 = lane_fetch(addr_l, vb[7]);
+    const float r0 = lane_fetch(addr_r, vb[0]), r1 = lane_fetch(addr_r, vb[1]);
+    ext[0] = has_l ? l0 : vb[0];
+    ext[1] = has_l ? l1 : vb[0];
+    ext[10] = has_r ? r0 : vb[7];
+    ext[11] = has_r ? r1 : vb[7];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) ext[2 + x] = vb[x];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        float s = kB0 * ext[x];
+        s = fmaf(kB1, ext[x + 1], s);
+        s = fmaf(kB2, ext[x + 2], s);
+        s = fmaf(kB1, ext[x + 3], s);
+        s = fmaf(kB0, ext[x + 4], s);
+        out[x] = s;
+    }
+    const float hl = lane_fetch(addr_l, out[7]), hr = lane_fetch(addr_r, out[0]);
+    out_l = has_l ? hl : out[0];
+    out_r = has_r ? hr : out[7];
+}
+
+}  // namespace
+
+// grid = min(#batches, #CUs) persistent workgroups of 8 waves; a batch is 128 patches (16 per wave).
+// Per patch row g (32 per batch), two phases separated by barriers:
+//   A: LUT pieces of the m stream and the absolute-angle family      (while B's pieces are landing)
+//   B: LUT pieces of the relative-angle family                        (while A's pieces of row g+1 land)
+// Raw patch rows arrive by LDS-DMA into a 6-slot ring private to each wave, one row per step, so the
+// main loop holds no patch data in VGPRs beyond the three blurred rows of the gradient stencil.
+template <int ANGLE, int POOL>
+__global__ __launch_bounds__(512) void mkd_pool_lds(const float *__restrict__ patches, long n,
+                                                    const unsigned char *__restrict__ lut_rows,
+                                                    const float *__restrict__ phi_cs,
+                                                    const short *__restrict__ colmap,
+                                                    float *__restrict__ pooled) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kPoolLds];
+    float *s_phi = reinterpret_cast<float *>(s_mem + kPhiOff);
+    for (int i = threadIdx.x; i < 2048; i += 512) s_phi[i] = phi_cs[i];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 15, q = lane >> 4;
+    const int addr_l = ((lane - 16) & 63) * 4, addr_r = ((lane + 16) & 63) * 4;
+    const bool has_l = q > 0, has_r = q < 3;
+    const long nbatch = (n + 127) / 128;
+    unsigned char *ring = s_mem + kRingOff + wave * (kRingSlots * 2048);
+    // DMA writes are lane-linear (lane l -> bytes [16l, 16l+16) of a 1 KiB piece): lane (p, q) moves the 16-B
+    // chunk q of its patch's half-row; the reader (p, q) needs chunks 2(q&1), 2(q&1)+1 of half q>>1.
+    const unsigned char *ring_lane = ring + (q >> 1) * 1024 + ((2 * (q & 1)) * 16 + p) * 16;
+    const unsigned char *brow = s_mem + lane * 16;
+
+    auto lane_src = [&](long batch) {
+        const long b0 = batch * 128 + wave * 16;
+        const long pidx = (b0 + p < n) ? b0 + p : n - 1;  // tail lanes recompute the last patch
+        return patches + pidx * 1024 + 4 * q;
+    };
+
+    long batch = blockIdx.x;
+    if (batch >= nbatch) return;
+    {
+        const float *src = lane_src(batch);
+#pragma unroll
+        for (int r = -2; r <= 3; ++r) issue_raw_row(src, r, ring, r + 2);
+        issue_lut_pieces(lut_rows, 0, 0, kPiecesA, s_mem, wave, lane);
+    }
+
+    for (; batch < nbatch; batch += gridDim.x) {
+        const long base = batch * 128 + wave * 16;
+        const float *src = lane_src(batch);
+        const bool more = batch + gridDim.x < nbatch;
+        const float *src_next = more ? lane_src(batch + gridDim.x) : src;
+
+        f32x4 acc[kTiles];
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float cur[8], prv[8], cur_l = 0.f, cur_r = 0.f;  // blurred rows g and g-1 (row -1 replicates row 0)
+        int s0 = 1;                                      // ring slot of raw row g-1 (rows g-1..g+3 feed hb(g+1))
+
+#pragma unroll 1
+        for (int g = 0; g < 32; ++g) {
+            // ---- phase A: everyone is done with phase B of the previous row; A pieces + ring row g+3 landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            issue_lut_pieces(lut_rows, g, kPiecesA, kPiecesB, s_mem, wave, lane);
+            if (g == 0) {  // first blurred row of the batch: rows -2..2 sit in slots 0..4
+                blur_row(ring_lane, 0, addr_l, addr_r, has_l, has_r, cur, cur_l, cur_r);
+#pragma unroll
+                for (int x = 0; x < 8; ++x) prv[x] = cur[x];
+            }
+            float nxt[8], nxt_l, nxt_r;
+            if (g < 31) {  // hb(g+1) from raw rows g-1..g+3 = slots s0..s0+4
+                blur_row(ring_lane, s0, addr_l, addr_r, has_l, has_r, nxt, nxt_l, nxt_r);
+            } else {  // row 32 replicates row 31
+#pragma unroll
+                for (int x = 0; x < 8; ++x) nxt[x] = cur[x];
+                nxt_l = cur_l;
+                nxt_r = cur_r;
+            }
+            // the slot of raw row g-2 is free now (its last reader was the blur above when g == 0)
+            asm volatile("" ::: "memory");
+            if (g <= 29) {
+                issue_raw_row(src, g + 4, ring, s0 == 0 ? kRingSlots - 1 : s0 - 1);
+            } else if (g == 31 && more) {
+#pragma unroll
+                for (int r = -2; r <= 3; ++r) issue_raw_row(src_next, r, ring, r + 2);  // next batch's first rows
+            }
+            s0 = s0 == kRingSlots - 1 ? 0 : s0 + 1;
+            float m[8], c1[8], s1[8];
+            {
+                float gx[8], gy[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {  // patch_gradients.glsl:94-96: left - right, down - up
+                    const float left = x == 0 ? cur_l : cur[x - 1];
+                    const float right = x == 7 ? cur_r : cur[x + 1];
+                    gx[x] = left - right;
+                    gy[x] = nxt[x] - prv[x];
+                }
+                row_base<ANGLE>(gx, gy, m, c1, s1);
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                prv[x] = cur[x];
+                cur[x] = nxt[x];
+            }
+            cur_l = nxt_l;
+            cur_r = nxt_r;
+            emit_stream<POOL, 0, 3>(m, brow, acc);
+            pool_family<POOL, 15, 18, 1>(m, c1, s1, brow, acc);   // absolute angle x cartesian kernels
+
+            // ---- phase B: B pieces of this row landed; everyone is done with the A pieces
+            float d1[8], e1[8];
+            {
+                const f32x4 *pp = reinterpret_cast<const f32x4 *>(&s_phi[(g * 32 + 8 * q) * 2]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // angle + gradient_angle(px), embedding.glsl:70-72
+                    const f32x4 t4 = pp[i];
+                    d1[2 * i] = c1[2 * i] * t4[0] - s1[2 * i] * t4[1];
+                    e1[2 * i] = s1[2 * i] * t4[0] + c1[2 * i] * t4[1];
+                    d1[2 * i + 1] = c1[2 * i + 1] * t4[2] - s1[2 * i + 1] * t4[3];
+                    e1[2 * i + 1] = s1[2 * i + 1] * t4[2] + c1[2 * i + 1] * t4[3];
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (g < 31 || more) issue_lut_pieces(lut_rows, (g + 1) & 31, 0, kPiecesA, s_mem, wave, lane);
+            pool_family<POOL, 3, 9, 2>(m, d1, e1, brow, acc);     // relative angle x polar kernels
+        }
+        // C layout of the 16x16 MFMA: lane holds column (lane & 15) of rows 4*(lane >> 4) + i.
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            const int d = colmap[t * 16 + p];
+            if (d < 0) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long row = base + 4 * q + i;
+                if (row < n) pooled[row * 238 + d] = acc[t][i];
+            }
         }
     }
 }
@@ -431,6 +752,25 @@ void launch_pool_f32(const float *patches, long n, const DeviceConsts &dc, int a
     else
         hipLaunchKernelGGL(mkd_pool_f32<LF_ANGLE_SHADER>, dim3(grid), dim3(256), 0, stream, patches, n, lut,
                            dc.phi_cs, dc.colmap, pooled);
+}
+
+void launch_pool_lds(const float *patches, long n, const DeviceConsts &dc, int angle_mode, int pool_mode,
+                     float *pooled, int num_cus, hipStream_t stream) {
+    if (n <= 0) return;
+    const long nbatch = (n + 127) / 128;
+    const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);  // one 94 KiB-LDS workgroup per CU
+    const unsigned char *lut = pool_mode == LF_POOL_F16X3 ? reinterpret_cast<const unsigned char *>(dc.pool_b_f16)
+                                                          : reinterpret_cast<const unsigned char *>(dc.pool_b_f32);
+#define LF_LAUNCH(A, P)                                                                                           \
+    hipLaunchKernelGGL((mkd_pool_lds<A, P>), dim3(grid), dim3(512), 0, stream, patches, n, lut, dc.phi_cs, dc.colmap, pooled)
+    if (pool_mode == LF_POOL_F16X3) {
+        if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH(LF_ANGLE_EXACT, LF_POOL_F16X3);
+        else LF_LAUNCH(LF_ANGLE_SHADER, LF_POOL_F16X3);
+    } else {
+        if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH(LF_ANGLE_EXACT, LF_POOL_F32);
+        else LF_LAUNCH(LF_ANGLE_SHADER, LF_POOL_F32);
+    }
+#undef LF_LAUNCH
 }
 
 void launch_whiten_f32(const float *pooled, long n, const DeviceConsts &dc, float *out, float *raw_out,

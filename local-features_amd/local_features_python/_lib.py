@@ -7,9 +7,10 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_ROOT, "liblf_mkd.so")
+LIB_PATH = os.environ.get("LF_MKD_LIB", os.path.join(_ROOT, "liblf_mkd.so"))   # override: A/B builds
 MODEL_DIR = os.path.join(_ROOT, "models", "mkd")
 
+FLAG_KERNEL_TIMING = 1
 ANGLE_SHADER, ANGLE_EXACT = 0, 1
 POOL_F32, POOL_F16X3 = 0, 1
 PCA_NAMES = ("liberty", "notredame", "yosemite")   # enum MKDPCA, lib.rs:26-32
@@ -20,7 +21,7 @@ SYMBOLS = (
     "lf_mkd_describe_patches", "lf_mkd_describe_patches_device", "lf_mkd_raw_descriptors_device",
     "lf_mkd_set_image", "lf_mkd_set_image_device", "lf_mkd_describe_keypoints",
     "lf_mkd_describe_keypoints_device", "lf_mkd_sample_patches_device", "lf_mkd_get_pyramid_level",
-    "lf_mkd_build_constants", "lf_mkd_synchronize", "lf_mkd_version",
+    "lf_mkd_build_constants", "lf_mkd_kernel_times", "lf_mkd_synchronize", "lf_mkd_version",
 )
 
 
@@ -29,7 +30,7 @@ class Params(ctypes.Structure):
         ("max_image_width", ctypes.c_uint32), ("max_image_height", ctypes.c_uint32),
         ("max_features", ctypes.c_uint32), ("patch_scale_factor", ctypes.c_float),
         ("device", ctypes.c_int32), ("angle_mode", ctypes.c_int32), ("pool_mode", ctypes.c_int32),
-        ("reserved", ctypes.c_uint32 * 5),
+        ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 4),
     ]
 
 
@@ -80,6 +81,8 @@ def load_library():
     L.lf_mkd_get_pyramid_level.argtypes = [vp, u32, vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.lf_mkd_synchronize.argtypes = [vp]
     L.lf_mkd_build_constants.argtypes = [vp] * 7
+    L.lf_mkd_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                      ctypes.POINTER(u64)]
     _lib = L
     return L
 
@@ -89,12 +92,12 @@ class MkdHandle:
     pointers (ints), e.g. torch.Tensor.data_ptr()."""
 
     def __init__(self, pca="liberty", max_features=2000, max_image_width=0, max_image_height=0,
-                 patch_scale_factor=24.0, device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_F32):
+                 patch_scale_factor=24.0, device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_F32, flags=0):
         self._h = None
         self.L = load_library()
         p = Params(max_image_width=max_image_width, max_image_height=max_image_height,
                    max_features=max_features, patch_scale_factor=patch_scale_factor,
-                   device=device, angle_mode=angle_mode, pool_mode=pool_mode)
+                   device=device, angle_mode=angle_mode, pool_mode=pool_mode, flags=flags)
         h = ctypes.c_void_p()
         rc = self.L.lf_mkd_create_from_file(ctypes.byref(p), model_path(pca).encode(), ctypes.byref(h))
         if rc != 0:
@@ -166,6 +169,13 @@ class MkdHandle:
     def sample_patches_device(self, d_kps, n, d_patches, stream=None):
         self._check(self.L.lf_mkd_sample_patches_device(self._h, d_kps, n, d_patches, stream),
                     "lf_mkd_sample_patches_device")
+
+    def kernel_times(self):
+        """(pool_ms, whiten_ms, batches) summed since the previous call; needs FLAG_KERNEL_TIMING."""
+        a, b, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint64()
+        self._check(self.L.lf_mkd_kernel_times(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)),
+                    "lf_mkd_kernel_times")
+        return a.value, b.value, n.value
 
     def synchronize(self):
         self._check(self.L.lf_mkd_synchronize(self._h), "lf_mkd_synchronize")

@@ -26,7 +26,7 @@ def torch():
 
 def _handles(lfp, **kw):
     return {(a, p): lfp.MkdHandle(angle_mode=a, pool_mode=p, **kw)
-            for a in (lfp.ANGLE_SHADER, lfp.ANGLE_EXACT) for p in (lfp.POOL_F32,)}
+            for a in (lfp.ANGLE_SHADER, lfp.ANGLE_EXACT) for p in (lfp.POOL_F32, lfp.POOL_F16X3)}
 
 
 @pytest.mark.parametrize("name", ["liberty", "notredame", "yosemite"])
