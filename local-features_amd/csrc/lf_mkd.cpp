@@ -31,7 +31,6 @@ struct lf_mkd {
     float *d_image = nullptr, *d_pyr = nullptr, *d_tmp_a = nullptr, *d_tmp_b = nullptr;
     bool have_image = false;
     int num_cus = 256;
-    bool pool_v1 = false;  // LF_MKD_POOL_V1=1: first-generation pooling kernel (A/B comparisons)
     // LF_MKD_FLAG_KERNEL_TIMING: (start, after pooling, after whitening) per batch
     std::vector<hipEvent_t> ev_pending, ev_free;
     std::string err;
@@ -117,8 +116,6 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
         hipDeviceProp_t prop;
         LF_CREATE_HIP(hipGetDeviceProperties(&prop, params->device));
         h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        const char *v1 = std::getenv("LF_MKD_POOL_V1");
-        h->pool_v1 = v1 && v1[0] == '1';
     }
     HostConsts hc;
     build_host_consts(pca, hc);
@@ -162,11 +159,7 @@ int mark(lf_mkd *h, hipStream_t s) {
 
 int run_batch(lf_mkd *h, const float *d_patches, uint64_t n, float *d_out, float *d_raw, hipStream_t s) {
     if (int rc = mark(h, s)) return rc;
-    if (h->pool_v1)
-        launch_pool_f32(d_patches, long(n), h->dc, h->params.angle_mode, h->d_pooled, s);
-    else
-        launch_pool_lds(d_patches, long(n), h->dc, h->params.angle_mode, h->params.pool_mode, h->d_pooled,
-                        h->num_cus, s);
+    launch_pool(d_patches, long(n), h->dc, h->params.angle_mode, h->params.pool_mode, h->d_pooled, h->num_cus, s);
     LF_HIP(h, hipGetLastError());
     if (int rc = mark(h, s)) return rc;
     launch_whiten_f32(h->d_pooled, long(n), h->dc, d_out ? d_out : h->d_out, d_raw, s);

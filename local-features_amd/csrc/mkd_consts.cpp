@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace lfmkd {
@@ -178,20 +179,23 @@ void build_host_consts(const PcaModel &pca, HostConsts &hc) {
                                   : hc.embedding_cartesian[size_t(col.j) * kPx + px];
         return col.coef * e;
     };
-    hc.pool_b_f32.assign(size_t(kPatch) * kTiles * 2 * 64 * 4, 0.f);
-    hc.pool_b_f16.assign(size_t(kPatch) * kTiles * 2 * 64 * 8, 0);
+    hc.pool_b_f32.assign(size_t(kPatch) * kUniqueTiles * 2 * 64 * 4, 0.f);
+    hc.pool_b_f16.assign(size_t(kPatch) * kUniqueTiles * 2 * 64 * 8, 0);
     for (int y = 0; y < kPatch; ++y)
-        for (int t = 0; t < kTiles; ++t)
+        for (int ut = 0; ut < kUniqueTiles; ++ut)
             for (int lane = 0; lane < 64; ++lane) {
-                const Column col = column_of(t, lane & 15);
+                const Column col = column_of(unique_tile_repr(ut), lane & 15);
+                const Column twin = column_of(unique_tile_twin(ut), lane & 15);
                 const int q = lane >> 4;
                 for (int e = 0; e < 8; ++e) {
-                    const float v = lut_value(col, y * kPatch + 8 * q + e);
-                    hc.pool_b_f32[(((size_t(y) * kTiles + tile_slot(t)) * 2 + (e >> 2)) * 64 + lane) * 4 + (e & 3)] = v;
+                    const int px = y * kPatch + 8 * q + e;
+                    const float v = lut_value(col, px);
+                    if (v != lut_value(twin, px)) std::abort();  // cos/sin twins must share their LUT tile
+                    hc.pool_b_f32[(((size_t(y) * kUniqueTiles + ut) * 2 + (e >> 2)) * 64 + lane) * 4 + (e & 3)] = v;
                     const uint16_t hi = f16_bits(v);
                     const uint16_t lo = f16_bits(v - f16_value(hi));  // f16 subnormals survive the MFMA (tools/micro)
-                    hc.pool_b_f16[(((size_t(y) * kTiles + tile_slot(t)) * 2 + 0) * 64 + lane) * 8 + e] = hi;
-                    hc.pool_b_f16[(((size_t(y) * kTiles + tile_slot(t)) * 2 + 1) * 64 + lane) * 8 + e] = lo;
+                    hc.pool_b_f16[(((size_t(y) * kUniqueTiles + ut) * 2 + 0) * 64 + lane) * 8 + e] = hi;
+                    hc.pool_b_f16[(((size_t(y) * kUniqueTiles + ut) * 2 + 1) * 64 + lane) * 8 + e] = lo;
                 }
             }
     constexpr int kKSteps = 60;  // 238 -> 240

@@ -32,11 +32,11 @@ constexpr int kPackedCols = kTiles * kTileCols;  // 336
 constexpr int kTileStream[kTiles] = {0, 0, 0, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12,
                                      1, 2, 3, 4, 5, 6};
 
-// Order of the tiles inside a LUT row image: the tiles of phase A (m stream + absolute-angle family:
-// tiles 0-2, 15-20) come first, then phase B (relative-angle family: tiles 3-14).  The pooling kernel
-// stages the two groups through LDS separately.
-constexpr int tile_slot(int t) { return t < 3 ? t : (t >= 15 ? 3 + (t - 15) : 9 + (t - 3)); }
-constexpr int kPhaseATiles = 9, kPhaseBTiles = 12;
+// The cos and the sin stream of one harmonic meet identical LUT columns (same kernels, same von-Mises
+// coefficient), so a LUT row stores 12 unique tiles: 0-2 m | 3-5 abs k=1..3 | 6-11 rel k=1..3 (2 each).
+constexpr int kUniqueTiles = 12;
+constexpr int unique_tile_repr(int ut) { return ut < 3 ? ut : (ut < 6 ? 15 + (ut - 3) : 3 + (ut - 6)); }   // a tile holding it
+constexpr int unique_tile_twin(int ut) { return ut < 3 ? ut : (ut < 6 ? 18 + (ut - 3) : 9 + (ut - 6)); }   // its sin twin
 
 struct PcaModel {
     std::vector<float> mean, eigvals, eigvecs;  // [238], [238], [238*238] row-major
@@ -57,10 +57,10 @@ struct HostConsts {
     std::vector<float> phi_cs;      // [1024][2] cos(phi), sin(phi)
     std::vector<int16_t> colmap;    // [336] packed column -> descriptor index (0..237) or -1
     // f32 pooling fragments for v_mfma_f32_16x16x4_f32:
-    //   [row y 32][slot 21][jg 2][lane 64][e 4] = coef * E_col(lane&15)[y][8*(lane>>4) + 4*jg + e]
+    //   [row y 32][unique tile 12][jg 2][lane 64][e 4] = coef * E_col(lane&15)[y][8*(lane>>4) + 4*jg + e]
     std::vector<float> pool_b_f32;
     // f16 hi/lo pooling fragments for v_mfma_f32_16x16x32_f16 (B[k][col], k = 8*(lane>>4)+e):
-    //   [row y 32][slot 21][hi|lo 2][lane 64][e 8] (uint16 bit patterns); v = hi + lo, both f16
+    //   [row y 32][unique tile 12][hi|lo 2][lane 64][e 8] (uint16 bit patterns); v = hi + lo, both f16
     std::vector<uint16_t> pool_b_f16;
     // whitening fragments for v_mfma_f32_16x16x4_f32: [ks 60][tile 8][lane 64]
     //   = W_T[16*tile + (lane&15)][4*ks + (lane>>4)] (0 beyond 238)

@@ -23,16 +23,14 @@ struct PyramidDesc {
 struct DeviceConsts {
     float *phi_cs = nullptr;        // [1024][2]
     short *colmap = nullptr;        // [336]
-    float *pool_b_f32 = nullptr;    // [32][21][2][64][4]
-    uint16_t *pool_b_f16 = nullptr; // [32][21][2][64][8]
+    float *pool_b_f32 = nullptr;    // [32][12][2][64][4]
+    uint16_t *pool_b_f16 = nullptr; // [32][12][2][64][8]
     float *white_b_f32 = nullptr;   // [60][8][64]
     float *mean_pad = nullptr;      // [240]
 };
 
-void launch_pool_f32(const float *patches, long n, const DeviceConsts &dc, int angle_mode, float *pooled,
-                     hipStream_t stream);
-void launch_pool_lds(const float *patches, long n, const DeviceConsts &dc, int angle_mode, int pool_mode,
-                     float *pooled, int num_cus, hipStream_t stream);
+void launch_pool(const float *patches, long n, const DeviceConsts &dc, int angle_mode, int pool_mode,
+                 float *pooled, int num_cus, hipStream_t stream);
 void launch_whiten_f32(const float *pooled, long n, const DeviceConsts &dc, float *out, float *raw_out,
                        hipStream_t stream);
 void launch_sample_patches(const float *pyr, const PyramidDesc &pd, const float *kps, long n, float psf,

@@ -1,7 +1,7 @@
 // MKD descriptor path: device code for gfx950 (CDNA4, wave64).
 //
 // Kernels (reference stage each one replaces; paths under local_features/src/vulkan/shaders/):
-//   mkd_pool_f32      mkd/patch_gradients.glsl:72-104 + mkd/embedding.glsl:53-121 (both variants)
+//   mkd_pool          mkd/patch_gradients.glsl:72-104 + mkd/embedding.glsl:53-121 (both variants)
 //   mkd_whiten_f32    mkd/normalize.glsl:22-142 + mkd/whitening.glsl:22-77 + mkd/normalize_final.glsl
 //   sample_patches    mkd/patch_gradients.glsl:42-70
 //   pyr_*             blur.glsl, swt.glsl (level 0), blur_pyramid.glsl, patch_pyramid.rs blits
@@ -11,8 +11,8 @@
 // x in [8q, 8q+8) of the current patch row, which is exactly the A-operand lane map of the
 // 16x16 MFMAs (row = l & 15, k-group = l >> 4).  So blur, gradients and the von-Mises
 // embedding are computed in the registers that feed the matrix cores; nothing but the final
-// sums leaves the wave.  The vertical blur runs as a transposed FIR (the window shifts through
-// the FMA destinations), horizontal neighbours come from lanes l -/+ 16 via ds_bpermute.
+// sums leaves the wave.  Horizontal neighbours come from lanes l -/+ 16 via ds_bpermute; vertical
+// neighbours from a ring of raw patch rows that LDS-DMA keeps filled.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,19 +24,49 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kTiles = 21;
-// tile -> A stream (host twin: mkd_consts.hpp kTileStream)
-__device__ constexpr int kTileStreamDev[kTiles] = {0, 0, 0, 7, 7, 8, 8, 9, 9, 10, 10,
-                                                   11, 11, 12, 12, 1, 2, 3, 4, 5, 6};
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// position of tile t inside a LUT row image (host twin: mkd_consts.hpp tile_slot)
-__device__ __host__ constexpr int tile_slot(int t) { return t < 3 ? t : (t >= 15 ? 3 + (t - 15) : 9 + (t - 3)); }
+constexpr int kTiles = 21;   // accumulator tiles (16 packed columns each), see mkd_consts.hpp
+// Accumulator tile numbering: m 0-2 | rel cos k 3+2(k-1).. | rel sin k 9+2(k-1).. | abs cos k 14+k | abs sin k 17+k.
+// The cos and sin streams of one harmonic meet the same LUT columns, so a LUT row holds 12 unique tiles:
+//   0-2 m | 3-5 abs k=1..3 | 6-11 rel k=1..3 (two tiles each).
+constexpr int kUniqueTiles = 12;
 
 // 5-tap sigma=0.7 kernel, patch_gradients.glsl:22-28
 constexpr float kB0 = 0.0096f, kB1 = 0.2054f, kB2 = 0.5699f;
 
+// LDS map of the pooling kernel (bytes)
+constexpr int kRowBytes = kUniqueTiles * 2 * 1024;   // 24576: one LUT row image, 2 x 1 KiB pieces per tile
+constexpr int kRowPieces = kUniqueTiles * 2;
+constexpr int kPhiOff = 2 * kRowBytes;               // cos/sin(phi) table, 8 KiB
+constexpr int kRingOff = kPhiOff + 8192;             // raw patch rows: [wave 8][slot 6][2 KiB]
+constexpr int kRingSlots = 6;
+constexpr int kPoolLds = kRingOff + 8 * kRingSlots * 2048;   // 155648
+
 __device__ __forceinline__ float lane_fetch(int byte_addr, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+
+__device__ __forceinline__ void lds_dma16(const void *gsrc, void *ldst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+}
+
+// one LUT row (24 pieces) into an LDS row buffer, 3 pieces per wave
+__device__ __forceinline__ void issue_lut_row(const unsigned char *__restrict__ lut_rows, int row,
+                                              unsigned char *lds_row, int wave, int lane) {
+    const unsigned char *g = lut_rows + (size_t)row * kRowBytes + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) lds_dma16(g + (wave + 8 * j) * 1024, lds_row + (wave + 8 * j) * 1024);
+}
+
+// one raw patch row (16 patches x 128 B) of this wave into ring slot `slot`; rows outside [0,31] replicate
+__device__ __forceinline__ void issue_raw_row(const float *__restrict__ src_lane, int row, unsigned char *ring,
+                                              int slot) {
+    const int y = row < 0 ? 0 : (row > 31 ? 31 : row);
+    lds_dma16(src_lane + y * 32, ring + slot * 2048);
+    lds_dma16(src_lane + y * 32 + 16, ring + slot * 2048 + 1024);
 }
 
 // cos/sin of the gradient angle theta = -atan2(gy over gx).
@@ -75,229 +105,35 @@ __device__ __forceinline__ void gradient_direction(float gx, float gy, float &ct
     }
 }
 
-// The 13 A-operand values of one pixel (streams: see mkd_consts.hpp).
-template <int ANGLE>
-__device__ __forceinline__ void pixel_streams(float gx, float gy, float cphi, float sphi, float (&a)[13]) {
-    // patch_gradients.glsl:98-100: mag = sqrt(sqrt(gx^2 + gy^2 + eps))
-    const float m = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(gx * gx + gy * gy + 1e-8f));
-    float c1, s1;
-    gradient_direction<ANGLE>(gx, gy, c1, s1);
-    const float c2 = c1 * c1 - s1 * s1, s2 = 2.f * c1 * s1;
-    const float c3 = c2 * c1 - s2 * s1, s3 = s2 * c1 + c2 * s1;
-    // polar variant: angle + gradient_angle(px), embedding.glsl:70-72
-    const float d1 = c1 * cphi - s1 * sphi, e1 = s1 * cphi + c1 * sphi;
-    const float d2 = d1 * d1 - e1 * e1, e2 = 2.f * d1 * e1;
-    const float d3 = d2 * d1 - e2 * e1, e3 = e2 * d1 + d2 * e1;
-    a[0] = m;
-    a[1] = m * c1; a[2] = m * c2; a[3] = m * c3;
-    a[4] = m * s1; a[5] = m * s2; a[6] = m * s3;
-    a[7] = m * d1; a[8] = m * d2; a[9] = m * d3;
-    a[10] = m * e1; a[11] = m * e2; a[12] = m * e3;
-}
+// ---- B fragments (LUT) and A fragments (streams) -------------------------------------------------
+// One unique LUT tile = two 1 KiB pieces: f32: pixels 0-3 / 4-7 of the lane's segment (K = 4 MFMAs);
+// f16: hi / lo halves of all 8 pixels (K = 32 MFMAs).  16 B per lane either way.
+struct BFrag { u32x4 p0, p1; };
 
-}  // namespace
-
-// ---------------------------------------------------------------------------------------------
-// Pooling, f32 MFMA.  grid = ceil(n / 64) blocks of 4 independent waves, 16 patches per wave.
-// Algorithmic HBM bytes per patch: 4096 read; 952 written (pooled sums, read back by whitening).
-// ---------------------------------------------------------------------------------------------
-template <int ANGLE>
-__global__ __launch_bounds__(256) void mkd_pool_f32(const float *__restrict__ patches, long n,
-                                                    const f32x4 *__restrict__ lut,
-                                                    const float *__restrict__ phi_cs,
-                                                    const short *__restrict__ colmap,
-                                                    float *__restrict__ pooled) {
-    __shared__ float s_phi[2048];
-    for (int i = threadIdx.x; i < 2048; i += 256) s_phi[i] = phi_cs[i];
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const long base = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
-    if (base >= n) return;
-    const int p = lane & 15, q = lane >> 4;
-    const long pidx = (base + p < n) ? base + p : n - 1;  // tail lanes recompute the last patch
-    const float *src = patches + pidx * 1024 + 8 * q;
-    const int addr_l = ((lane - 16) & 63) * 4, addr_r = ((lane + 16) & 63) * 4;
-    const bool has_l = q > 0, has_r = q < 3;
-
-    f32x4 acc[kTiles];
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float a0[8], a1[8], a2[8], a3[8];  // transposed-FIR state of the vertical blur
-    float cur[8], prv[8];              // blurred rows g and g-1
-    float cur_l = 0.f, cur_r = 0.f;    // blurred row g at x = 8q-1 and 8q+8
-#pragma unroll
-    for (int x = 0; x < 8; ++x) a0[x] = a1[x] = a2[x] = a3[x] = cur[x] = prv[x] = 0.f;
-
-    // r: raw row fed to the vertical blur (rows -2,-1 and 32,33 replicate the border);
-    // v = r - 2: blurred row produced; g = r - 3: gradient row consumed by the matrix cores.
-#pragma unroll 2
-    for (int r = -2; r <= 34; ++r) {
-        float nxt[8], nxt_l = 0.f, nxt_r = 0.f;
-        if (r <= 33) {
-            const int rr = r < 0 ? 0 : (r > 31 ? 31 : r);
-            const f32x4 lo = *reinterpret_cast<const f32x4 *>(src + rr * 32);
-            const f32x4 hi = *reinterpret_cast<const f32x4 *>(src + rr * 32 + 4);
-            const float raw[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            float vb[8];
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {  // patch_gradients.glsl:72-81, k0..k4 in order
-                vb[x] = fmaf(kB0, raw[x], a0[x]);
-                a0[x] = fmaf(kB1, raw[x], a1[x]);
-                a1[x] = fmaf(kB2, raw[x], a2[x]);
-                a2[x] = fmaf(kB1, raw[x], a3[x]);
-                a3[x] = kB0 * raw[x];
-            }
-            if (r >= 2) {  // horizontal pass on row v, patch_gradients.glsl:83-92
-                float ext[12];
-                const float l0 = lane_fetch(addr_l, vb[6]), l1 = lane_fetch(addr_l, vb[7]);
-                const float r0 = lane_fetch(addr_r, vb[0]), r1 = lane_fetch(addr_r, vb[1]);
-                ext[0] = has_l ? l0 : vb[0];
-                ext[1] = has_l ? l1 : vb[0];
-                ext[10] = has_r ? r0 : vb[7];
-                ext[11] = has_r ? r1 : vb[7];
-#pragma unroll
-                for (int x = 0; x < 8; ++x) ext[2 + x] = vb[x];
-#pragma unroll
-                for (int x = 0; x < 8; ++x) {
-                    float s = kB0 * ext[x];
-                    s = fmaf(kB1, ext[x + 1], s);
-                    s = fmaf(kB2, ext[x + 2], s);
-                    s = fmaf(kB1, ext[x + 3], s);
-                    s = fmaf(kB0, ext[x + 4], s);
-                    nxt[x] = s;
-                }
-                const float hl = lane_fetch(addr_l, nxt[7]), hr = lane_fetch(addr_r, nxt[0]);
-                nxt_l = has_l ? hl : nxt[0];
-                nxt_r = has_r ? hr : nxt[7];
-            }
-        } else {
-#pragma unroll
-            for (int x = 0; x < 8; ++x) nxt[x] = cur[x];  // row 32 replicates row 31
-        }
-        if (r < 2) continue;
-        if (r == 2) {  // row 0: also stands in for row -1
-#pragma unroll
-            for (int x = 0; x < 8; ++x) cur[x] = prv[x] = nxt[x];
-            cur_l = nxt_l;
-            cur_r = nxt_r;
-            continue;
-        }
-        const int g = r - 3;
-        // patch_gradients.glsl:94-96: gx = left - right, gy = down - up (replicated border)
-        float gx[8], gy[8];
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            const float left = x == 0 ? cur_l : cur[x - 1];
-            const float right = x == 7 ? cur_r : cur[x + 1];
-            gx[x] = left - right;
-            gy[x] = nxt[x] - prv[x];
-        }
-        const f32x4 *ph = reinterpret_cast<const f32x4 *>(&s_phi[(g * 32 + 8 * q) * 2]);
-        const f32x4 *lrow = lut + (size_t)g * kTiles * 2 * 64 + lane;
-#pragma unroll
-        for (int jg = 0; jg < 2; ++jg) {
-            float av[4][13];
-            const f32x4 pa = ph[2 * jg], pb = ph[2 * jg + 1];
-            pixel_streams<ANGLE>(gx[4 * jg + 0], gy[4 * jg + 0], pa[0], pa[1], av[0]);
-            pixel_streams<ANGLE>(gx[4 * jg + 1], gy[4 * jg + 1], pa[2], pa[3], av[1]);
-            pixel_streams<ANGLE>(gx[4 * jg + 2], gy[4 * jg + 2], pb[0], pb[1], av[2]);
-            pixel_streams<ANGLE>(gx[4 * jg + 3], gy[4 * jg + 3], pb[2], pb[3], av[3]);
-#pragma unroll
-            for (int t = 0; t < kTiles; ++t) {
-                const f32x4 b = lrow[(tile_slot(t) * 2 + jg) * 64];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e][kTileStreamDev[t]], b[e], acc[t], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            prv[x] = cur[x];
-            cur[x] = nxt[x];
-        }
-        cur_l = nxt_l;
-        cur_r = nxt_r;
-    }
-
-    // C layout of the 16x16 MFMA: lane holds column (lane & 15) of rows 4*(lane >> 4) + i.
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t) {
-        const int d = colmap[t * 16 + p];
-        if (d < 0) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long row = base + 4 * q + i;
-            if (row < n) pooled[row * 238 + d] = acc[t][i];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Pooling, v2: B fragments (the spatial-kernel LUT) are streamed L2 -> LDS once per patch row and
-// shared by the 8 waves of a workgroup (128 patches per pass), double-buffered with one barrier per
-// row.  POOL selects the arithmetic: exact f32 MFMA, or f16 hi/lo split (3 f16 MFMAs per product).
-// The LUT row image in global memory is byte-for-byte the LDS image: 21 tiles x 2 pieces x 1 KiB
-// (f32: pieces = pixels 0-3 / 4-7 of the lane's segment; f16: pieces = hi / lo halves).
-// ---------------------------------------------------------------------------------------------
-namespace {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// LDS map of the pooling kernel (bytes)
-constexpr int kRowBytes = kTiles * 2 * 1024;        // 43008: one LUT row image = phase A pieces, then phase B
-constexpr int kPiecesA = 9 * 2, kPiecesB = 12 * 2;   // 1 KiB pieces per phase
-constexpr int kPhiOff = kRowBytes;                  // cos/sin(phi) table, 8 KiB
-constexpr int kRingOff = kPhiOff + 8192;            // raw patch rows: [wave 8][slot 6][2 KiB]
-constexpr int kRingSlots = 6;
-constexpr int kPoolLds = kRingOff + 8 * kRingSlots * 2048;   // 149504
-
-__device__ __forceinline__ void lds_dma16(const void *gsrc, void *ldst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
-}
-
-// pieces [first, first+count) of LUT row `row`, spread over the 8 waves (wave-uniform control flow)
-__device__ __forceinline__ void issue_lut_pieces(const unsigned char *__restrict__ lut_rows, int row, int first,
-                                                 int count, unsigned char *s_mem, int wave, int lane) {
-    const unsigned char *g = lut_rows + (size_t)row * kRowBytes + lane * 16;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int i = wave + 8 * j;
-        if (i < count) lds_dma16(g + (first + i) * 1024, s_mem + (first + i) * 1024);
-    }
-}
-
-// one raw patch row (16 patches x 128 B) of this wave into ring slot `slot`; rows outside [0,31] replicate
-__device__ __forceinline__ void issue_raw_row(const float *__restrict__ src_lane, int row, unsigned char *ring,
-                                              int slot) {
-    const int y = row < 0 ? 0 : (row > 31 ? 31 : row);
-    lds_dma16(src_lane + y * 32, ring + slot * 2048);
-    lds_dma16(src_lane + y * 32 + 16, ring + slot * 2048 + 1024);
+template <int UT>
+__device__ __forceinline__ BFrag load_b(const unsigned char *brow) {
+    BFrag b;
+    b.p0 = *reinterpret_cast<const u32x4 *>(brow + (UT * 2 + 0) * 1024);
+    b.p1 = *reinterpret_cast<const u32x4 *>(brow + (UT * 2 + 1) * 1024);
+    return b;
 }
 
 __device__ __forceinline__ unsigned pack_rtz(float a, float b) {
-    auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    return __builtin_bit_cast(unsigned, h);
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
 
-// One A stream (8 pixels of this lane) against tiles [T0, T0+NT).
-template <int POOL, int T0, int NT>
-__device__ __forceinline__ void emit_stream(const float (&a)[8], const unsigned char *brow, f32x4 (&acc)[kTiles]) {
-    if constexpr (POOL == LF_POOL_F32) {
+// A operand of one stream: f32: the 8 values themselves; f16: hi = f16 truncation, lo = f16(a - hi)
+template <int POOL> struct AFrag;
+template <> struct AFrag<LF_POOL_F32> {
+    float v[8];
+    __device__ __forceinline__ void set(const float (&a)[8]) {
 #pragma unroll
-        for (int t = T0; t < T0 + NT; ++t) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(brow + (tile_slot(t) * 2 + 0) * 1024);
-            const f32x4 b1 = *reinterpret_cast<const f32x4 *>(brow + (tile_slot(t) * 2 + 1) * 1024);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], acc[t], 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 + e], b1[e], acc[t], 0, 0, 0);
-        }
-    } else {
-        // a = hi + lo with hi = f16 truncation of a (exact residual), lo = f16(a - hi)
-        u32x4 hi, lo;
+        for (int x = 0; x < 8; ++x) v[x] = a[x];
+    }
+};
+template <> struct AFrag<LF_POOL_F16X3> {
+    u32x4 hi, lo;
+    __device__ __forceinline__ void set(const float (&a)[8]) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const unsigned h = pack_rtz(a[2 * e], a[2 * e + 1]);
@@ -306,67 +142,45 @@ __device__ __forceinline__ void emit_stream(const float (&a)[8], const unsigned 
             hi[e] = h;
             lo[e] = pack_rtz(a[2 * e] - h0, a[2 * e + 1] - h1);
         }
-        const f16x8 ah = __builtin_bit_cast(f16x8, hi), al = __builtin_bit_cast(f16x8, lo);
-        f16x8 bh[NT], bl[NT];
+    }
+};
+
+// acc += A x B for one (stream, tile); part selects one third of the f16 split so callers can interleave
+// independent accumulators between the dependent MFMAs of one tile.
+template <int POOL, int PART>
+__device__ __forceinline__ void mma_part(const AFrag<POOL> &a, const BFrag &b, f32x4 &acc) {
+    if constexpr (POOL == LF_POOL_F32) {
+        const f32x4 b0 = __builtin_bit_cast(f32x4, b.p0), b1 = __builtin_bit_cast(f32x4, b.p1);
+        if (PART == 0) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            bh[t] = *reinterpret_cast<const f16x8 *>(brow + (tile_slot(T0 + t) * 2 + 0) * 1024);
-            bl[t] = *reinterpret_cast<const f16x8 *>(brow + (tile_slot(T0 + t) * 2 + 1) * 1024);
+            for (int e = 0; e < 3; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[e], b0[e], acc, 0, 0, 0);
+        } else if (PART == 1) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[3], b0[3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[4], b1[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[5], b1[1], acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[6], b1[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[7], b1[3], acc, 0, 0, 0);
         }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[T0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[t], acc[T0 + t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[T0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[t], acc[T0 + t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[T0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[t], acc[T0 + t], 0, 0, 0);
-#ifdef LF_EXP_NOP
-        asm volatile("s_nop %0" ::"n"(LF_EXP_NOP));
-#endif
+    } else {
+        const f16x8 bh = __builtin_bit_cast(f16x8, b.p0), bl = __builtin_bit_cast(f16x8, b.p1);
+        const f16x8 ah = __builtin_bit_cast(f16x8, a.hi), al = __builtin_bit_cast(f16x8, a.lo);
+        if (PART == 0) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+        else if (PART == 1) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
     }
 }
 
-// Per-pixel base values of one patch row (8 pixels of this lane).
-template <int ANGLE>
-__device__ __forceinline__ void row_base(const float (&gx)[8], const float (&gy)[8], float (&m)[8], float (&c1)[8],
-                                         float (&s1)[8]) {
+// cos and sin streams of one harmonic against the NT tiles they share
+template <int POOL, int NT>
+__device__ __forceinline__ void mma_pair(const AFrag<POOL> &ac, const AFrag<POOL> &as, const BFrag (&b)[NT],
+                                         f32x4 *acc_c, f32x4 *acc_s) {
 #pragma unroll
-    for (int x = 0; x < 8; ++x) {
-        // patch_gradients.glsl:98-100: mag = sqrt(sqrt(gx^2 + gy^2 + eps))
-        m[x] = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(gx[x] * gx[x] + gy[x] * gy[x] + 1e-8f));
-        gradient_direction<ANGLE>(gx[x], gy[x], c1[x], s1[x]);
-    }
-}
-
-// Streams m cos(k t), m sin(k t), k = 1..3, for one orientation family (angle addition), against
-// TC tiles per cos stream starting at tile C0 and per sin stream starting at tile S0.
-template <int POOL, int C0, int S0, int NT>
-__device__ __forceinline__ void pool_family(const float (&m)[8], const float (&c1)[8], const float (&s1)[8],
-                                            const unsigned char *brow, f32x4 (&acc)[kTiles]) {
-    float ck[8], sk[8], v[8];
+    for (int t = 0; t < NT; ++t) { mma_part<POOL, 0>(ac, b[t], acc_c[t]); mma_part<POOL, 0>(as, b[t], acc_s[t]); }
 #pragma unroll
-    for (int x = 0; x < 8; ++x) { ck[x] = c1[x]; sk[x] = s1[x]; }
+    for (int t = 0; t < NT; ++t) { mma_part<POOL, 1>(ac, b[t], acc_c[t]); mma_part<POOL, 1>(as, b[t], acc_s[t]); }
 #pragma unroll
-    for (int x = 0; x < 8; ++x) v[x] = m[x] * ck[x];
-    emit_stream<POOL, C0, NT>(v, brow, acc);
-#pragma unroll
-    for (int x = 0; x < 8; ++x) v[x] = m[x] * sk[x];
-    emit_stream<POOL, S0, NT>(v, brow, acc);
-#pragma unroll
-    for (int x = 0; x < 8; ++x) { const float c = ck[x] * c1[x] - sk[x] * s1[x]; sk[x] = sk[x] * c1[x] + ck[x] * s1[x]; ck[x] = c; }
-#pragma unroll
-    for (int x = 0; x < 8; ++x) v[x] = m[x] * ck[x];
-    emit_stream<POOL, C0 + NT, NT>(v, brow, acc);
-#pragma unroll
-    for (int x = 0; x < 8; ++x) v[x] = m[x] * sk[x];
-    emit_stream<POOL, S0 + NT, NT>(v, brow, acc);
-#pragma unroll
-    for (int x = 0; x < 8; ++x) { const float c = ck[x] * c1[x] - sk[x] * s1[x]; sk[x] = sk[x] * c1[x] + ck[x] * s1[x]; ck[x] = c; }
-#pragma unroll
-    for (int x = 0; x < 8; ++x) v[x] = m[x] * ck[x];
-    emit_stream<POOL, C0 + 2 * NT, NT>(v, brow, acc);
-#pragma unroll
-    for (int x = 0; x < 8; ++x) v[x] = m[x] * sk[x];
-    emit_stream<POOL, S0 + 2 * NT, NT>(v, brow, acc);
+    for (int t = 0; t < NT; ++t) { mma_part<POOL, 2>(ac, b[t], acc_c[t]); mma_part<POOL, 2>(as, b[t], acc_s[t]); }
 }
 
 // Blurred row of this lane's segment from the raw-row ring (patch_gradients.glsl:72-92): vertical 5 taps over
@@ -411,20 +225,58 @@ __device__ __forceinline__ void blur_row(const unsigned char *ring_lane, int s0,
     out_r = has_r ? hr : out[7];
 }
 
+// One orientation family (absolute or relative angle): harmonics k = 1..3 by angle addition; harmonic k
+// uses unique LUT tiles [U0 + NT*(k-1), +NT) and accumulator tiles C0 + NT*(k-1).. (cos), S0 + NT*(k-1).. (sin).
+// `bnext` holds the fragments of harmonic 1 on entry (prefetched by the caller).
+template <int POOL, int NT, int U0, int C0, int S0>
+__device__ __forceinline__ void pool_family(const float (&m)[8], const float (&c1)[8], const float (&s1)[8],
+                                            const unsigned char *brow, BFrag (&b)[NT], f32x4 (&acc)[kTiles]) {
+    float ck[8], sk[8], v[8];
+    AFrag<POOL> ac, as;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) { ck[x] = c1[x]; sk[x] = s1[x]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) v[x] = m[x] * ck[x];
+        ac.set(v);
+#pragma unroll
+        for (int x = 0; x < 8; ++x) v[x] = m[x] * sk[x];
+        as.set(v);
+        BFrag bcur[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bcur[t] = b[t];
+        if (k < 2) {  // fragments of the next harmonic: in flight behind this harmonic's matrix work
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (k == 0) b[t] = load_b<U0 + NT>(brow + t * 2048);
+                else b[t] = load_b<U0 + 2 * NT>(brow + t * 2048);
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const float c = ck[x] * c1[x] - sk[x] * s1[x];
+                sk[x] = sk[x] * c1[x] + ck[x] * s1[x];
+                ck[x] = c;
+            }
+        }
+        mma_pair<POOL, NT>(ac, as, bcur, &acc[C0 + NT * k], &acc[S0 + NT * k]);
+    }
+}
+
 }  // namespace
 
 // grid = min(#batches, #CUs) persistent workgroups of 8 waves; a batch is 128 patches (16 per wave).
-// Per patch row g (32 per batch), two phases separated by barriers:
-//   A: LUT pieces of the m stream and the absolute-angle family      (while B's pieces are landing)
-//   B: LUT pieces of the relative-angle family                        (while A's pieces of row g+1 land)
-// Raw patch rows arrive by LDS-DMA into a 6-slot ring private to each wave, one row per step, so the
-// main loop holds no patch data in VGPRs beyond the three blurred rows of the gradient stencil.
+// Per patch row g (32 per batch): one barrier, after which the LUT row g is in LDS (issued a whole row
+// earlier, double-buffered) and every wave has left row g-1.  Raw patch rows arrive by LDS-DMA into a
+// 6-slot ring private to each wave, one row per step, so the main loop holds no patch data in VGPRs beyond
+// the three blurred rows of the gradient stencil.
+// Algorithmic HBM bytes per patch: 4096 read (+ 952 written: pooled sums handed to mkd_whiten).
 template <int ANGLE, int POOL>
-__global__ __launch_bounds__(512) void mkd_pool_lds(const float *__restrict__ patches, long n,
-                                                    const unsigned char *__restrict__ lut_rows,
-                                                    const float *__restrict__ phi_cs,
-                                                    const short *__restrict__ colmap,
-                                                    float *__restrict__ pooled) {
+__global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patches, long n,
+                                                const unsigned char *__restrict__ lut_rows,
+                                                const float *__restrict__ phi_cs,
+                                                const short *__restrict__ colmap,
+                                                float *__restrict__ pooled) {
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kPoolLds];
     float *s_phi = reinterpret_cast<float *>(s_mem + kPhiOff);
     for (int i = threadIdx.x; i < 2048; i += 512) s_phi[i] = phi_cs[i];
@@ -439,7 +291,6 @@ __global__ __launch_bounds__(512) void mkd_pool_lds(const float *__restrict__ pa
     // DMA writes are lane-linear (lane l -> bytes [16l, 16l+16) of a 1 KiB piece): lane (p, q) moves the 16-B
     // chunk q of its patch's half-row; the reader (p, q) needs chunks 2(q&1), 2(q&1)+1 of half q>>1.
     const unsigned char *ring_lane = ring + (q >> 1) * 1024 + ((2 * (q & 1)) * 16 + p) * 16;
-    const unsigned char *brow = s_mem + lane * 16;
 
     auto lane_src = [&](long batch) {
         const long b0 = batch * 128 + wave * 16;
@@ -453,8 +304,9 @@ __global__ __launch_bounds__(512) void mkd_pool_lds(const float *__restrict__ pa
         const float *src = lane_src(batch);
 #pragma unroll
         for (int r = -2; r <= 3; ++r) issue_raw_row(src, r, ring, r + 2);
-        issue_lut_pieces(lut_rows, 0, 0, kPiecesA, s_mem, wave, lane);
+        issue_lut_row(lut_rows, 0, s_mem, wave, lane);
     }
+    unsigned par = 0;  // LUT row buffer holding the row about to be consumed
 
     for (; batch < nbatch; batch += gridDim.x) {
         const long base = batch * 128 + wave * 16;
@@ -470,10 +322,14 @@ __global__ __launch_bounds__(512) void mkd_pool_lds(const float *__restrict__ pa
 
 #pragma unroll 1
         for (int g = 0; g < 32; ++g) {
-            // ---- phase A: everyone is done with phase B of the previous row; A pieces + ring row g+3 landed
+            // LUT row g and ring row g+3 have landed (own DMA: vmcnt; everyone's: barrier); row g-1 is done
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            issue_lut_pieces(lut_rows, g, kPiecesA, kPiecesB, s_mem, wave, lane);
+            const unsigned char *brow = s_mem + par * kRowBytes + lane * 16;
+            if (g < 31 || more) issue_lut_row(lut_rows, (g + 1) & 31, s_mem + (par ^ 1) * kRowBytes, wave, lane);
+            par ^= 1;
+            BFrag bm[3] = {load_b<0>(brow), load_b<1>(brow), load_b<2>(brow)};   // m-stream fragments
+
             if (g == 0) {  // first blurred row of the batch: rows -2..2 sit in slots 0..4
                 blur_row(ring_lane, 0, addr_l, addr_r, has_l, has_r, cur, cur_l, cur_r);
 #pragma unroll
@@ -497,17 +353,15 @@ __global__ __launch_bounds__(512) void mkd_pool_lds(const float *__restrict__ pa
                 for (int r = -2; r <= 3; ++r) issue_raw_row(src_next, r, ring, r + 2);  // next batch's first rows
             }
             s0 = s0 == kRingSlots - 1 ? 0 : s0 + 1;
+
             float m[8], c1[8], s1[8];
-            {
-                float gx[8], gy[8];
 #pragma unroll
-                for (int x = 0; x < 8; ++x) {  // patch_gradients.glsl:94-96: left - right, down - up
-                    const float left = x == 0 ? cur_l : cur[x - 1];
-                    const float right = x == 7 ? cur_r : cur[x + 1];
-                    gx[x] = left - right;
-                    gy[x] = nxt[x] - prv[x];
-                }
-                row_base<ANGLE>(gx, gy, m, c1, s1);
+            for (int x = 0; x < 8; ++x) {  // patch_gradients.glsl:94-100
+                const float left = x == 0 ? cur_l : cur[x - 1];
+                const float right = x == 7 ? cur_r : cur[x + 1];
+                const float gx = left - right, gy = nxt[x] - prv[x];   // left - right, down - up
+                m[x] = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(gx * gx + gy * gy + 1e-8f));
+                gradient_direction<ANGLE>(gx, gy, c1[x], s1[x]);
             }
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
@@ -516,15 +370,28 @@ __global__ __launch_bounds__(512) void mkd_pool_lds(const float *__restrict__ pa
             }
             cur_l = nxt_l;
             cur_r = nxt_r;
-            emit_stream<POOL, 0, 3>(m, brow, acc);
-            pool_family<POOL, 15, 18, 1>(m, c1, s1, brow, acc);   // absolute angle x cartesian kernels
 
-            // ---- phase B: B pieces of this row landed; everyone is done with the A pieces
+            // m stream x (polar | cartesian) kernels: accumulator tiles 0-2
+            BFrag babs[1] = {load_b<3>(brow)};
+            {
+                AFrag<POOL> am;
+                am.set(m);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) mma_part<POOL, 0>(am, bm[t], acc[t]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) mma_part<POOL, 1>(am, bm[t], acc[t]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) mma_part<POOL, 2>(am, bm[t], acc[t]);
+            }
+            // absolute angle x cartesian kernels: unique tiles 3-5, accumulators 15-17 (cos), 18-20 (sin)
+            BFrag brel[2] = {load_b<6>(brow), load_b<7>(brow)};
+            pool_family<POOL, 1, 3, 15, 18>(m, c1, s1, brow, babs, acc);
+            // angle + gradient_angle(px) (embedding.glsl:70-72) x polar kernels: unique tiles 6-11
             float d1[8], e1[8];
             {
                 const f32x4 *pp = reinterpret_cast<const f32x4 *>(&s_phi[(g * 32 + 8 * q) * 2]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {  // angle + gradient_angle(px), embedding.glsl:70-72
+                for (int i = 0; i < 4; ++i) {
                     const f32x4 t4 = pp[i];
                     d1[2 * i] = c1[2 * i] * t4[0] - s1[2 * i] * t4[1];
                     e1[2 * i] = s1[2 * i] * t4[0] + c1[2 * i] * t4[1];
@@ -532,10 +399,7 @@ __global__ __launch_bounds__(512) void mkd_pool_lds(const float *__restrict__ pa
                     e1[2 * i + 1] = s1[2 * i + 1] * t4[2] + c1[2 * i + 1] * t4[3];
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (g < 31 || more) issue_lut_pieces(lut_rows, (g + 1) & 31, 0, kPiecesA, s_mem, wave, lane);
-            pool_family<POOL, 3, 9, 2>(m, d1, e1, brow, acc);     // relative angle x polar kernels
+            pool_family<POOL, 2, 6, 3, 9>(m, d1, e1, brow, brel, acc);
         }
         // C layout of the 16x16 MFMA: lane holds column (lane & 15) of rows 4*(lane >> 4) + i.
 #pragma unroll
@@ -741,28 +605,15 @@ __global__ __launch_bounds__(1024) void sample_patches(const float *__restrict__
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-void launch_pool_f32(const float *patches, long n, const DeviceConsts &dc, int angle_mode, float *pooled,
-                     hipStream_t stream) {
-    if (n <= 0) return;
-    const unsigned grid = (unsigned)((n + 63) / 64);
-    const f32x4 *lut = reinterpret_cast<const f32x4 *>(dc.pool_b_f32);
-    if (angle_mode == LF_ANGLE_EXACT)
-        hipLaunchKernelGGL(mkd_pool_f32<LF_ANGLE_EXACT>, dim3(grid), dim3(256), 0, stream, patches, n, lut,
-                           dc.phi_cs, dc.colmap, pooled);
-    else
-        hipLaunchKernelGGL(mkd_pool_f32<LF_ANGLE_SHADER>, dim3(grid), dim3(256), 0, stream, patches, n, lut,
-                           dc.phi_cs, dc.colmap, pooled);
-}
-
-void launch_pool_lds(const float *patches, long n, const DeviceConsts &dc, int angle_mode, int pool_mode,
-                     float *pooled, int num_cus, hipStream_t stream) {
+void launch_pool(const float *patches, long n, const DeviceConsts &dc, int angle_mode, int pool_mode,
+                 float *pooled, int num_cus, hipStream_t stream) {
     if (n <= 0) return;
     const long nbatch = (n + 127) / 128;
-    const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);  // one 94 KiB-LDS workgroup per CU
+    const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);  // one 152 KiB-LDS workgroup per CU
     const unsigned char *lut = pool_mode == LF_POOL_F16X3 ? reinterpret_cast<const unsigned char *>(dc.pool_b_f16)
                                                           : reinterpret_cast<const unsigned char *>(dc.pool_b_f32);
 #define LF_LAUNCH(A, P)                                                                                           \
-    hipLaunchKernelGGL((mkd_pool_lds<A, P>), dim3(grid), dim3(512), 0, stream, patches, n, lut, dc.phi_cs, dc.colmap, pooled)
+    hipLaunchKernelGGL((mkd_pool<A, P>), dim3(grid), dim3(512), 0, stream, patches, n, lut, dc.phi_cs, dc.colmap, pooled)
     if (pool_mode == LF_POOL_F16X3) {
         if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH(LF_ANGLE_EXACT, LF_POOL_F16X3);
         else LF_LAUNCH(LF_ANGLE_SHADER, LF_POOL_F16X3);

@@ -150,3 +150,39 @@ def test_full_size_properties(lfp, torch):
     h.describe_patches_device(sub.data_ptr(), 512, out2.data_ptr())
     h.synchronize()
     assert torch.equal(out2, out[idx])      # a descriptor depends on its own patch only
+
+
+def test_exact_angle_mode_stays_inside_the_gate_of_the_shader_reference(lfp, oracle):
+    """ANGLE_EXACT replaces the shader's polynomial atan2 (max error 1e-5 rad) by the exact direction;
+    its descriptors must still match the shader-faithful oracle within the north-star tolerance."""
+    rng = np.random.default_rng(77)
+    p = rng.random((512, 32, 32)).astype(np.float32)
+    ref = oracle.describe_patches(p, nthreads=8)          # shader-faithful
+    for pool in (lfp.POOL_F32, lfp.POOL_F16X3):
+        d = lfp.MkdHandle(max_features=512, angle_mode=lfp.ANGLE_EXACT, pool_mode=pool).describe_patches(p)
+        e = rel_l2(d, ref)
+        assert e.max() < GATE, (pool, e.max())
+        assert e.max() < 5e-5, (pool, e.max())
+
+
+def test_f16x3_pooling_agrees_with_f32_at_full_size_and_is_deterministic(lfp, torch):
+    """2^18 patches: the split-f16 MFMA pooling against the exact-f32 MFMA pooling, per descriptor,
+    and two runs of each against each other bit for bit (no data race in the LDS pipeline)."""
+    n = 1 << 18
+    gen = torch.Generator(device="cuda").manual_seed(123)
+    p = torch.rand((n, 32, 32), device="cuda", generator=gen)
+    outs = {}
+    for angle in (lfp.ANGLE_SHADER, lfp.ANGLE_EXACT):
+        for pool in (lfp.POOL_F32, lfp.POOL_F16X3):
+            h = lfp.MkdHandle(max_features=n, angle_mode=angle, pool_mode=pool)
+            a = torch.empty((n, 128), device="cuda")
+            b = torch.empty((n, 128), device="cuda")
+            h.describe_patches_device(p.data_ptr(), n, a.data_ptr())
+            h.describe_patches_device(p.data_ptr(), n, b.data_ptr())
+            h.synchronize()
+            assert torch.equal(a, b), (angle, pool)
+            outs[(angle, pool)] = a
+    for angle in (lfp.ANGLE_SHADER, lfp.ANGLE_EXACT):
+        d = outs[(angle, lfp.POOL_F16X3)] - outs[(angle, lfp.POOL_F32)]
+        e = d.norm(dim=1) / outs[(angle, lfp.POOL_F32)].norm(dim=1)
+        assert e.max().item() < 2e-5, (angle, e.max().item())
