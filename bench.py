@@ -8,9 +8,10 @@ driver launches one process per GPU (torch.distributed, backend nccl = RCCL); pa
 with no data-path collective, so scaling is "weak".
 
 Extra objects on the line:
-  roofline      dominant kernel (pooling) vs the 8 TB/s HBM roof: algorithmic bytes per launch
-                (4608 B x descriptors) / its mean launch time from HIP events recorded
-                by the library on the launch stream (lf_mkd_kernel_times)
+  roofline      the describe kernel (mkd_pool: blur .. whitening .. L2 fused in one launch) vs the
+                8 TB/s HBM roof: algorithmic bytes per launch (4608 B x descriptors) /
+                its mean launch time from HIP events recorded by the library on the launch stream
+                (lf_mkd_kernel_times)
   cpu_baseline  the CPU oracle (a port of the reference's algorithm) timed on this host, rank 0, N=1,
                 on a bounded sample of the same workload
 """
@@ -51,7 +52,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--patches", type=int, default=1 << 20, help="patches per GPU per step")
     ap.add_argument("--angle", choices=["shader", "exact"], default="shader")
-    ap.add_argument("--pool", choices=["f32", "f16x3"], default=os.environ.get("LF_MKD_POOL", "f32"))
+    ap.add_argument("--pool", choices=["f32", "f16x3"], default=os.environ.get("LF_MKD_POOL", "f16x3"))
     ap.add_argument("--cpu-sample", type=int, default=-1, help="patches for the CPU baseline (0: skip)")
     args = ap.parse_args()
 
@@ -138,7 +139,6 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mkd_pool", "kernel_ms": kern_s * 1e3,
-                         "whiten_kernel_ms": whiten_ms / max(launches, 1),
                          "algorithmic_bytes_per_launch": BYTES_PER_DESC * n},
         }
         if world == 1:

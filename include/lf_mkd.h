@@ -137,8 +137,9 @@ int lf_mkd_build_constants(const float *mean, const float *eigvals, const float 
                            float *embedding_cartesian, float *w_t);
 
 /* With LF_MKD_FLAG_KERNEL_TIMING: waits for the recorded launches, returns the summed device time
- * (ms) of the pooling and of the whitening kernel and the number of batches since the previous
- * call, then resets the sums.  Any output pointer may be NULL. */
+ * (ms) of the describe kernel (pool_ms; whiten_ms is 0 since the whitening stage was fused into it)
+ * and the number of batches since the previous call, then resets the sums.  Any output pointer may
+ * be NULL. */
 int lf_mkd_kernel_times(lf_mkd *h, double *pool_ms, double *whiten_ms, uint64_t *launches);
 
 /* Blocks until everything enqueued on the handle's own stream has finished. */

@@ -22,7 +22,6 @@ struct lf_mkd {
     hipStream_t stream = nullptr;
     DeviceConsts dc;
     uint64_t batch = 0;         // descriptors per internal batch (multiple of 64)
-    float *d_pooled = nullptr;  // [batch][238]  pooled sums between the two kernels
     float *d_patches = nullptr; // [batch][1024] staging: host patches / sampled patches
     float *d_out = nullptr;     // [batch][128]  staging for host output
     float *d_kps = nullptr;     // [batch][5]
@@ -31,7 +30,7 @@ struct lf_mkd {
     float *d_image = nullptr, *d_pyr = nullptr, *d_tmp_a = nullptr, *d_tmp_b = nullptr;
     bool have_image = false;
     int num_cus = 256;
-    // LF_MKD_FLAG_KERNEL_TIMING: (start, after pooling, after whitening) per batch
+    // LF_MKD_FLAG_KERNEL_TIMING: (start, end) of the describe kernel per batch
     std::vector<hipEvent_t> ev_pending, ev_free;
     std::string err;
 };
@@ -123,9 +122,9 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     LF_CREATE_HIP(upload(&h->dc.colmap, hc.colmap.data(), hc.colmap.size() * 2));
     LF_CREATE_HIP(upload(&h->dc.pool_b_f32, hc.pool_b_f32.data(), hc.pool_b_f32.size() * 4));
     LF_CREATE_HIP(upload(&h->dc.pool_b_f16, hc.pool_b_f16.data(), hc.pool_b_f16.size() * 2));
-    LF_CREATE_HIP(upload(&h->dc.white_b_f32, hc.white_b_f32.data(), hc.white_b_f32.size() * 4));
-    LF_CREATE_HIP(upload(&h->dc.mean_pad, hc.mean_pad.data(), hc.mean_pad.size() * 4));
-    LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_pooled), h->batch * kRaw * 4));
+    LF_CREATE_HIP(upload(&h->dc.white_a_f16, hc.white_a_f16.data(), hc.white_a_f16.size() * 2));
+    LF_CREATE_HIP(upload(&h->dc.white_a_f32, hc.white_a_f32.data(), hc.white_a_f32.size() * 4));
+    LF_CREATE_HIP(upload(&h->dc.white_bias, hc.white_bias.data(), hc.white_bias.size() * 4));
     LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_patches), h->batch * kPx * 4));
     LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_out), h->batch * kOut * 4));
     LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_kps), h->batch * 5 * 4));
@@ -159,10 +158,8 @@ int mark(lf_mkd *h, hipStream_t s) {
 
 int run_batch(lf_mkd *h, const float *d_patches, uint64_t n, float *d_out, float *d_raw, hipStream_t s) {
     if (int rc = mark(h, s)) return rc;
-    launch_pool(d_patches, long(n), h->dc, h->params.angle_mode, h->params.pool_mode, h->d_pooled, h->num_cus, s);
-    LF_HIP(h, hipGetLastError());
-    if (int rc = mark(h, s)) return rc;
-    launch_whiten_f32(h->d_pooled, long(n), h->dc, d_out ? d_out : h->d_out, d_raw, s);
+    launch_describe(d_patches, long(n), h->dc, h->params.angle_mode, h->params.pool_mode, d_out ? d_out : h->d_out,
+                    d_raw, h->num_cus, s);
     LF_HIP(h, hipGetLastError());
     if (int rc = mark(h, s)) return rc;
     return LF_MKD_OK;
@@ -216,9 +213,9 @@ void lf_mkd_destroy(lf_mkd *h) {
     if (!h) return;
     (void)hipSetDevice(h->params.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *ptrs[] = {h->dc.phi_cs, h->dc.colmap, h->dc.pool_b_f32, h->dc.pool_b_f16, h->dc.white_b_f32,
-                    h->dc.mean_pad, h->d_pooled,  h->d_patches,    h->d_out,         h->d_kps,
-                    h->d_image,   h->d_pyr,     h->d_tmp_a,      h->d_tmp_b};
+    void *ptrs[] = {h->dc.phi_cs,      h->dc.colmap,     h->dc.pool_b_f32, h->dc.pool_b_f16, h->dc.white_a_f16,
+                    h->dc.white_a_f32, h->dc.white_bias, h->d_patches,     h->d_out,         h->d_kps,
+                    h->d_image,        h->d_pyr,         h->d_tmp_a,       h->d_tmp_b};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev_pending) (void)hipEventDestroy(e);
@@ -233,14 +230,12 @@ int lf_mkd_kernel_times(lf_mkd *h, double *pool_ms, double *whiten_ms, uint64_t 
     if (!h) return LF_MKD_ERR_BAD_ARG;
     LF_HIP(h, hipSetDevice(h->params.device));
     double tp = 0, tw = 0;
-    const size_t nb = h->ev_pending.size() / 3;
+    const size_t nb = h->ev_pending.size() / 2;
     for (size_t i = 0; i < nb; ++i) {
-        float a = 0, b = 0;
-        LF_HIP(h, hipEventSynchronize(h->ev_pending[3 * i + 2]));
-        LF_HIP(h, hipEventElapsedTime(&a, h->ev_pending[3 * i], h->ev_pending[3 * i + 1]));
-        LF_HIP(h, hipEventElapsedTime(&b, h->ev_pending[3 * i + 1], h->ev_pending[3 * i + 2]));
+        float a = 0;
+        LF_HIP(h, hipEventSynchronize(h->ev_pending[2 * i + 1]));
+        LF_HIP(h, hipEventElapsedTime(&a, h->ev_pending[2 * i], h->ev_pending[2 * i + 1]));
         tp += a;
-        tw += b;
     }
     h->ev_free.insert(h->ev_free.end(), h->ev_pending.begin(), h->ev_pending.end());
     h->ev_pending.clear();

@@ -198,16 +198,32 @@ void build_host_consts(const PcaModel &pca, HostConsts &hc) {
                     hc.pool_b_f16[(((size_t(y) * kUniqueTiles + ut) * 2 + 1) * 64 + lane) * 8 + e] = lo;
                 }
             }
-    constexpr int kKSteps = 60;  // 238 -> 240
-    hc.white_b_f32.assign(size_t(kKSteps) * 8 * 64, 0.f);
-    for (int ks = 0; ks < kKSteps; ++ks)
-        for (int t = 0; t < 8; ++t)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int k = 4 * ks + (lane >> 4), n = 16 * t + (lane & 15);
-                if (k < kRaw) hc.white_b_f32[(size_t(ks) * 8 + t) * 64 + lane] = hc.w_t[size_t(n) * kRaw + k];
-            }
-    hc.mean_pad.assign(240, 0.f);
-    for (int c = 0; c < kRaw; ++c) hc.mean_pad[c] = pca.mean[c];
+    auto w_packed = [&](int n, int packed_col) -> float {
+        const int d = packed_col < kPackedCols ? hc.colmap[packed_col] : -1;
+        return d < 0 ? 0.f : hc.w_t[size_t(n) * kRaw + d];
+    };
+    hc.white_a_f16.assign(size_t(11) * 8 * 2 * 64 * 8, 0);
+    hc.white_a_f32.assign(size_t(kTiles) * 4 * 8 * 64, 0.f);
+    for (int r = 0; r < 8; ++r)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int n = 16 * r + (lane & 15), q = lane >> 4;
+            for (int s = 0; s < 11; ++s)
+                for (int j = 0; j < 8; ++j) {
+                    const float v = w_packed(n, 16 * (2 * s + (j >> 2)) + 4 * q + (j & 3));
+                    const uint16_t hi = f16_bits(v);
+                    hc.white_a_f16[(((size_t(s) * 8 + r) * 2 + 0) * 64 + lane) * 8 + j] = hi;
+                    hc.white_a_f16[(((size_t(s) * 8 + r) * 2 + 1) * 64 + lane) * 8 + j] = f16_bits(v - f16_value(hi));
+                }
+            for (int t = 0; t < kTiles; ++t)
+                for (int i = 0; i < 4; ++i)
+                    hc.white_a_f32[((size_t(t) * 4 + i) * 8 + r) * 64 + lane] = w_packed(n, 16 * t + 4 * q + i);
+        }
+    hc.white_bias.assign(kOut, 0.f);
+    for (int n = 0; n < kOut; ++n) {
+        double b = 0.0;
+        for (int d = 0; d < kRaw; ++d) b -= double(hc.w_t[size_t(n) * kRaw + d]) * double(pca.mean[d]);
+        hc.white_bias[n] = float(b);
+    }
 }
 
 }  // namespace lfmkd

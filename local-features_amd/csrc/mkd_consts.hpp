@@ -62,10 +62,14 @@ struct HostConsts {
     // f16 hi/lo pooling fragments for v_mfma_f32_16x16x32_f16 (B[k][col], k = 8*(lane>>4)+e):
     //   [row y 32][unique tile 12][hi|lo 2][lane 64][e 8] (uint16 bit patterns); v = hi + lo, both f16
     std::vector<uint16_t> pool_b_f16;
-    // whitening fragments for v_mfma_f32_16x16x4_f32: [ks 60][tile 8][lane 64]
-    //   = W_T[16*tile + (lane&15)][4*ks + (lane>>4)] (0 beyond 238)
-    std::vector<float> white_b_f32;
-    std::vector<float> mean_pad;    // [240]
+    // Whitening as out^T = W_T x raw with the pooling accumulators as B operand: a lane (patch p, q) holds
+    // packed columns 16t + 4q + i in accumulator (t, i).  A fragments = rows of W_T, K ordered to match:
+    //   f16 (16x16x32): [step 11][row tile 8][hi|lo 2][lane 64][j 8], lane = (row n = lane&15, q = lane>>4),
+    //        value W_T[16r + n][desc(16*(2s + (j>>2)) + 4q + (j&3))], 0 for padding columns
+    //   f32 (16x16x4):  [tile 21][i 4][row tile 8][lane 64] = W_T[16r + n][desc(16t + 4q + i)]
+    std::vector<uint16_t> white_a_f16;
+    std::vector<float> white_a_f32;
+    std::vector<float> white_bias;  // [128] = -sum_d W_T[n][d] mean[d]  (whitening.glsl subtracts the mean first)
 };
 
 void build_host_consts(const PcaModel &pca, HostConsts &out);

@@ -25,14 +25,14 @@ struct DeviceConsts {
     short *colmap = nullptr;        // [336]
     float *pool_b_f32 = nullptr;    // [32][12][2][64][4]
     uint16_t *pool_b_f16 = nullptr; // [32][12][2][64][8]
-    float *white_b_f32 = nullptr;   // [60][8][64]
-    float *mean_pad = nullptr;      // [240]
+    uint16_t *white_a_f16 = nullptr; // [11][8][2][64][8]
+    float *white_a_f32 = nullptr;    // [21][4][8][64]
+    float *white_bias = nullptr;     // [128]  -W mean
 };
 
-void launch_pool(const float *patches, long n, const DeviceConsts &dc, int angle_mode, int pool_mode,
-                 float *pooled, int num_cus, hipStream_t stream);
-void launch_whiten_f32(const float *pooled, long n, const DeviceConsts &dc, float *out, float *raw_out,
-                       hipStream_t stream);
+// patches [n][32][32] -> out [n][128] (and, when raw_out != nullptr, the un-whitened [n][238])
+void launch_describe(const float *patches, long n, const DeviceConsts &dc, int angle_mode, int pool_mode, float *out,
+                     float *raw_out, int num_cus, hipStream_t stream);
 void launch_sample_patches(const float *pyr, const PyramidDesc &pd, const float *kps, long n, float psf,
                            float *patches, hipStream_t stream);
 void launch_build_pyramid(const float *image, float *pyr, float *tmp_a, float *tmp_b, const PyramidDesc &pd,

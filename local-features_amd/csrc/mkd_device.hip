@@ -2,7 +2,7 @@
 //
 // Kernels (reference stage each one replaces; paths under local_features/src/vulkan/shaders/):
 //   mkd_pool          mkd/patch_gradients.glsl:72-104 + mkd/embedding.glsl:53-121 (both variants)
-//   mkd_whiten_f32    mkd/normalize.glsl:22-142 + mkd/whitening.glsl:22-77 + mkd/normalize_final.glsl
+//                     + mkd/normalize.glsl:22-142 + mkd/whitening.glsl:22-77 + mkd/normalize_final.glsl
 //   sample_patches    mkd/patch_gradients.glsl:42-70
 //   pyr_*             blur.glsl, swt.glsl (level 0), blur_pyramid.glsl, patch_pyramid.rs blits
 //
@@ -145,29 +145,32 @@ template <> struct AFrag<LF_POOL_F16X3> {
     }
 };
 
-// acc += A x B for one (stream, tile); part selects one third of the f16 split so callers can interleave
-// independent accumulators between the dependent MFMAs of one tile.
+// acc += LUT^T x stream for one (stream, tile): the LUT fragment is the MFMA's A operand (rows = packed
+// columns), the stream its B operand (columns = patches), so a lane ends up holding packed columns
+// 16t + 4(lane >> 4) + i of ITS OWN patch (lane & 15) -- which is what the fused epilogue needs.
+// `part` selects one third of the f16 split so callers can interleave independent accumulators between the
+// dependent MFMAs of one tile.
 template <int POOL, int PART>
 __device__ __forceinline__ void mma_part(const AFrag<POOL> &a, const BFrag &b, f32x4 &acc) {
     if constexpr (POOL == LF_POOL_F32) {
         const f32x4 b0 = __builtin_bit_cast(f32x4, b.p0), b1 = __builtin_bit_cast(f32x4, b.p1);
         if (PART == 0) {
 #pragma unroll
-            for (int e = 0; e < 3; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[e], b0[e], acc, 0, 0, 0);
+            for (int e = 0; e < 3; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[e], a.v[e], acc, 0, 0, 0);
         } else if (PART == 1) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[3], b0[3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[4], b1[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[5], b1[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[3], a.v[3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[0], a.v[4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[1], a.v[5], acc, 0, 0, 0);
         } else {
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[6], b1[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[7], b1[3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[2], a.v[6], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[3], a.v[7], acc, 0, 0, 0);
         }
     } else {
         const f16x8 bh = __builtin_bit_cast(f16x8, b.p0), bl = __builtin_bit_cast(f16x8, b.p1);
         const f16x8 ah = __builtin_bit_cast(f16x8, a.hi), al = __builtin_bit_cast(f16x8, a.lo);
-        if (PART == 0) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
-        else if (PART == 1) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
-        else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+        if (PART == 0) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acc, 0, 0, 0);
+        else if (PART == 1) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc, 0, 0, 0);
     }
 }
 
@@ -263,6 +266,154 @@ __device__ __forceinline__ void pool_family(const float (&m)[8], const float (&c
     }
 }
 
+// Epilogue, per wave and batch: acc[t][i] holds the pooled sum of packed column 16t + 4q + i for the lane's
+// own patch.  normalize.glsl:22-142 (polar | cartesian | all), whitening.glsl:22-77 as an MFMA with the
+// accumulators as B operand (out^T = W_T x raw, the mean folded into a bias), normalize_final.glsl.
+// Whitening fragments (host: mkd_consts.cpp): f16: [step 11][row tile 8][hi|lo][lane][8], step s covers
+// accumulator tiles 2s, 2s+1; f32: [tile 21][i 4][row tile 8][lane].
+template <int POOL>
+__device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lane, bool valid, long patch,
+                                                   const short *__restrict__ colmap,
+                                                   const unsigned char *__restrict__ wfrag,
+                                                   const float *__restrict__ bias, float *__restrict__ out,
+                                                   float *__restrict__ raw_out) {
+    const int q = lane >> 4;
+    // tile 1 mixes polar (packed columns 0-8 of the tile) and cartesian (9-15) kernels of the m stream
+    bool t1_polar[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t1_polar[i] = 4 * q + i < 9;
+    float sp = 0.f, sc = 0.f;
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v2 = acc[t][i] * acc[t][i];
+            const bool polar = t == 0 || (t >= 3 && t <= 14) || (t == 1 && t1_polar[i]);
+            if (t == 1) { sp += polar ? v2 : 0.f; sc += polar ? 0.f : v2; }
+            else if (polar) sp += v2;
+            else sc += v2;
+        }
+    sp += __shfl_xor(sp, 16); sp += __shfl_xor(sp, 32);
+    sc += __shfl_xor(sc, 16); sc += __shfl_xor(sc, 32);
+    const float inv_p = 1.f / __builtin_amdgcn_sqrtf(sp), inv_c = 1.f / __builtin_amdgcn_sqrtf(sc);
+    float sa = 0.f;
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool polar = t == 0 || (t >= 3 && t <= 14) || (t == 1 && t1_polar[i]);
+            acc[t][i] *= polar ? inv_p : inv_c;
+            sa = fmaf(acc[t][i], acc[t][i], sa);
+        }
+    sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);
+    const float inv_a = 1.f / __builtin_amdgcn_sqrtf(sa);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] *= inv_a;
+    if (raw_out) {  // verification tap: the 238-D descriptor before whitening
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = colmap[t * 16 + 4 * q + i];
+                if (valid && d >= 0) raw_out[patch * 238 + d] = acc[t][i];
+            }
+    }
+    f32x4 o[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // W fragments stream from L2 one unit ahead of the MFMAs that use them (two register buffers); the
+    // scheduling barriers keep hipcc from hoisting all 176 loads to the top (which spills).
+    if constexpr (POOL == LF_POOL_F16X3) {
+        // uniform base + (constant + lane) index: lets hipcc address with SGPR base + one VGPR offset; a
+        // per-lane base pointer instead makes it precompute (and spill) one 64-bit address per load
+        const u32x4 *w = reinterpret_cast<const u32x4 *>(wfrag);
+        u32x4 wbuf[2][8];   // unit = (step s, 4 row tiles): [row tile rr][hi|lo]
+        auto load_unit = [&](int u, u32x4 (&dst)[8]) {
+            const int s = u >> 1, r0 = (u & 1) * 4;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                dst[2 * rr] = w[((s * 8 + r0 + rr) * 2 + 0) * 64 + lane];
+                dst[2 * rr + 1] = w[((s * 8 + r0 + rr) * 2 + 1) * 64 + lane];
+            }
+        };
+        load_unit(0, wbuf[0]);
+        f16x8 yh, yl;
+#pragma unroll
+        for (int u = 0; u < 22; ++u) {
+            if (u + 1 < 22) load_unit(u + 1, wbuf[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int s = u >> 1;
+            if ((u & 1) == 0) {
+                float y[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    y[i] = acc[2 * s][i];
+                    y[4 + i] = 2 * s + 1 < kTiles ? acc[(2 * s + 1 < kTiles) ? 2 * s + 1 : 0][i] : 0.f;
+                }
+                AFrag<LF_POOL_F16X3> yb;
+                yb.set(y);
+                yh = __builtin_bit_cast(f16x8, yb.hi);
+                yl = __builtin_bit_cast(f16x8, yb.lo);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = (u & 1) * 4 + rr;
+                const f16x8 wh = __builtin_bit_cast(f16x8, wbuf[u & 1][2 * rr]);
+                const f16x8 wl = __builtin_bit_cast(f16x8, wbuf[u & 1][2 * rr + 1]);
+                o[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, yh, o[r], 0, 0, 0);
+                o[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, yl, o[r], 0, 0, 0);
+                o[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, yh, o[r], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        const float *w = reinterpret_cast<const float *>(wfrag);
+        float wbuf[2][16];  // unit = two (tile, i) steps x 8 row tiles
+        auto load_unit = [&](int u, float (&dst)[16]) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) dst[k * 8 + r] = w[((2 * u + k) * 8 + r) * 64 + lane];
+        };
+        load_unit(0, wbuf[0]);
+#pragma unroll
+        for (int u = 0; u < 42; ++u) {
+            if (u + 1 < 42) load_unit(u + 1, wbuf[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int ti = 2 * u + k;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    o[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wbuf[u & 1][k * 8 + r], acc[ti >> 2][ti & 3], o[r], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // lane holds outputs 16r + 4q + i of its patch: add the bias (-W mean), L2-normalise, store
+    float ss = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + 16 * r + 4 * q);
+        o[r] += b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ss = fmaf(o[r][i], o[r][i], ss);
+    }
+    ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+    const float nrm = __builtin_amdgcn_sqrtf(ss);
+    if (valid) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = o[r][i] / nrm;
+            *reinterpret_cast<f32x4 *>(out + patch * 128 + 16 * r + 4 * q) = v;
+        }
+    }
+}
+
 }  // namespace
 
 // grid = min(#batches, #CUs) persistent workgroups of 8 waves; a batch is 128 patches (16 per wave).
@@ -270,13 +421,15 @@ __device__ __forceinline__ void pool_family(const float (&m)[8], const float (&c
 // earlier, double-buffered) and every wave has left row g-1.  Raw patch rows arrive by LDS-DMA into a
 // 6-slot ring private to each wave, one row per step, so the main loop holds no patch data in VGPRs beyond
 // the three blurred rows of the gradient stencil.
-// Algorithmic HBM bytes per patch: 4096 read (+ 952 written: pooled sums handed to mkd_whiten).
+// Algorithmic HBM bytes per patch: 4096 read + 512 written; the kernel moves nothing else.
 template <int ANGLE, int POOL>
 __global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patches, long n,
                                                 const unsigned char *__restrict__ lut_rows,
                                                 const float *__restrict__ phi_cs,
                                                 const short *__restrict__ colmap,
-                                                float *__restrict__ pooled) {
+                                                const unsigned char *__restrict__ wfrag,
+                                                const float *__restrict__ bias,
+                                                float *__restrict__ out, float *__restrict__ raw_out) {
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kPoolLds];
     float *s_phi = reinterpret_cast<float *>(s_mem + kPhiOff);
     for (int i = threadIdx.x; i < 2048; i += 512) s_phi[i] = phi_cs[i];
@@ -401,96 +554,12 @@ __global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patche
             }
             pool_family<POOL, 2, 6, 3, 9>(m, d1, e1, brow, brel, acc);
         }
-        // C layout of the 16x16 MFMA: lane holds column (lane & 15) of rows 4*(lane >> 4) + i.
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t) {
-            const int d = colmap[t * 16 + p];
-            if (d < 0) continue;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const long row = base + 4 * q + i;
-                if (row < n) pooled[row * 238 + d] = acc[t][i];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Normalise (polar | cartesian | all), subtract mean, whiten 238 -> 128 on f32 MFMA, L2.
-// One wave per 16 patches.  normalize.glsl:22-142, whitening.glsl:22-77, normalize_final.glsl.
-// raw_out (optional): the 238-D un-whitened descriptor.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void mkd_whiten_f32(const float *__restrict__ pooled, long n,
-                                                     const float *__restrict__ wfrag,
-                                                     const float *__restrict__ mean,
-                                                     float *__restrict__ out,
-                                                     float *__restrict__ raw_out) {
-    __shared__ float s_v[16 * 241];
-    const int lane = threadIdx.x;
-    const long base = (long)blockIdx.x * 16;
-    const int rows = (n - base) < 16 ? int(n - base) : 16;
-    for (int i = lane; i < 16 * 238; i += 64) {
-        const int pr = i / 238, c = i - pr * 238;
-        s_v[pr * 241 + c] = pr < rows ? pooled[base * 238 + i] : 1.f;
-    }
-    __syncthreads();
-    const int p = lane & 15, q = lane >> 4;
-    // each lane owns columns q, q+4, ... of patch p: the A-operand map of the 16x16x4 MFMA
-    float v[60];
-    float sp = 0.f, sc = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 60; ++ks) {
-        const int c = 4 * ks + q;
-        const float x = c < 238 ? s_v[p * 241 + c] : 0.f;
-        v[ks] = x;
-        if (c < 175) sp = fmaf(x, x, sp);
-        else sc = fmaf(x, x, sc);
-    }
-    sp += __shfl_xor(sp, 16); sp += __shfl_xor(sp, 32);
-    sc += __shfl_xor(sc, 16); sc += __shfl_xor(sc, 32);
-    const float np = __builtin_amdgcn_sqrtf(sp), nc = __builtin_amdgcn_sqrtf(sc);
-    float sa = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 60; ++ks) {
-        const int c = 4 * ks + q;
-        v[ks] = c < 175 ? v[ks] / np : v[ks] / nc;
-        sa = fmaf(v[ks], v[ks], sa);
-    }
-    sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);
-    const float na = __builtin_amdgcn_sqrtf(sa);
-#pragma unroll
-    for (int ks = 0; ks < 60; ++ks) {
-        const int c = 4 * ks + q;
-        const float raw = v[ks] / na;
-        if (raw_out && c < 238 && p < rows) raw_out[(base + p) * 238 + c] = raw;
-        v[ks] = c < 238 ? raw - mean[c] : 0.f;
-    }
-    f32x4 acc[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 60; ++ks)
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[ks], wfrag[(ks * 8 + t) * 64 + lane], acc[t], 0, 0, 0);
-    // lane holds out[patch 4q+i][16t + p]; norm over the 128 columns of each patch
-    float ss[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ss[i] = fmaf(acc[t][i], acc[t][i], ss[i]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ss[i] += __shfl_xor(ss[i], 1); ss[i] += __shfl_xor(ss[i], 2);
-        ss[i] += __shfl_xor(ss[i], 4); ss[i] += __shfl_xor(ss[i], 8);
-        ss[i] = __builtin_amdgcn_sqrtf(ss[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int pr = 4 * q + i;
-        if (pr >= rows) continue;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) out[(base + pr) * 128 + 16 * t + p] = acc[t][i] / ss[i];
+        // launder the (uniform) table pointers once per batch: otherwise hipcc hoists one 64-bit VGPR address per
+        // whitening-fragment load out of the batch loop and spills 1.4 KB of them per lane
+        const unsigned char *wf = wfrag;
+        const float *bs = bias;
+        asm volatile("" : "+s"(wf), "+s"(bs));
+        finish_descriptors<POOL>(acc, lane, base + p < n, base + p, colmap, wf, bs, out, raw_out);
     }
 }
 
@@ -605,16 +674,20 @@ __global__ __launch_bounds__(1024) void sample_patches(const float *__restrict__
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-void launch_pool(const float *patches, long n, const DeviceConsts &dc, int angle_mode, int pool_mode,
-                 float *pooled, int num_cus, hipStream_t stream) {
+void launch_describe(const float *patches, long n, const DeviceConsts &dc, int angle_mode, int pool_mode, float *out,
+                     float *raw_out, int num_cus, hipStream_t stream) {
     if (n <= 0) return;
     const long nbatch = (n + 127) / 128;
     const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);  // one 152 KiB-LDS workgroup per CU
-    const unsigned char *lut = pool_mode == LF_POOL_F16X3 ? reinterpret_cast<const unsigned char *>(dc.pool_b_f16)
-                                                          : reinterpret_cast<const unsigned char *>(dc.pool_b_f32);
-#define LF_LAUNCH(A, P)                                                                                           \
-    hipLaunchKernelGGL((mkd_pool<A, P>), dim3(grid), dim3(512), 0, stream, patches, n, lut, dc.phi_cs, dc.colmap, pooled)
-    if (pool_mode == LF_POOL_F16X3) {
+    const bool f16 = pool_mode == LF_POOL_F16X3;
+    const unsigned char *lut = f16 ? reinterpret_cast<const unsigned char *>(dc.pool_b_f16)
+                                   : reinterpret_cast<const unsigned char *>(dc.pool_b_f32);
+    const unsigned char *wf = f16 ? reinterpret_cast<const unsigned char *>(dc.white_a_f16)
+                                  : reinterpret_cast<const unsigned char *>(dc.white_a_f32);
+#define LF_LAUNCH(A, P)                                                                                        \
+    hipLaunchKernelGGL((mkd_pool<A, P>), dim3(grid), dim3(512), 0, stream, patches, n, lut, dc.phi_cs, dc.colmap, \
+                       wf, dc.white_bias, out, raw_out)
+    if (f16) {
         if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH(LF_ANGLE_EXACT, LF_POOL_F16X3);
         else LF_LAUNCH(LF_ANGLE_SHADER, LF_POOL_F16X3);
     } else {
@@ -622,13 +695,6 @@ void launch_pool(const float *patches, long n, const DeviceConsts &dc, int angle
         else LF_LAUNCH(LF_ANGLE_SHADER, LF_POOL_F32);
     }
 #undef LF_LAUNCH
-}
-
-void launch_whiten_f32(const float *pooled, long n, const DeviceConsts &dc, float *out, float *raw_out,
-                       hipStream_t stream) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(mkd_whiten_f32, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, stream, pooled, n,
-                       dc.white_b_f32, dc.mean_pad, out, raw_out);
 }
 
 void launch_sample_patches(const float *pyr, const PyramidDesc &pd, const float *kps, long n, float psf,

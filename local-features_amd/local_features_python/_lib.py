@@ -171,7 +171,8 @@ class MkdHandle:
                     "lf_mkd_sample_patches_device")
 
     def kernel_times(self):
-        """(pool_ms, whiten_ms, batches) summed since the previous call; needs FLAG_KERNEL_TIMING."""
+        """(kernel_ms, 0.0, batches) summed since the previous call; needs FLAG_KERNEL_TIMING.
+        (The second value was the separate whitening kernel before it was fused into mkd_pool.)"""
         a, b, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint64()
         self._check(self.L.lf_mkd_kernel_times(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)),
                     "lf_mkd_kernel_times")
