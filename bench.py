@@ -28,12 +28,25 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_DESC = 4608          # 4096 B patch read + 512 B descriptor write
 
 
+def host_cores():
+    """Threads for the CPU baseline: the affinity mask, capped by the cgroup CPU quota and by the GPU box's
+    per-GPU CPU share (16; its affinity mask shows all 256 host cores but the job only gets 16 of them)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("LF_BENCH_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(n_sample, seed):
     """Oracle (oracle/mkd_oracle.c) on the host cores; the only place bench.py touches oracle/."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle import MkdOracle
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     o = MkdOracle(os.path.join(ROOT, "local-features_amd", "models", "mkd", "concat-pca-liberty.safetensors"))
     p = np.random.default_rng(seed).random((n_sample, 32, 32), dtype=np.float32)
     o.describe_patches(p[:256], nthreads=cores)                    # warm
@@ -102,10 +115,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     pool_ms, whiten_ms, launches = h.kernel_times()
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from local_features_python import sharding
+    dt = sharding.max_over_ranks(dt, "cuda")
 
     # sanity on the timed output: finite, unit norm (a wrong-but-fast kernel must not pass silently)
     nrm = out.norm(dim=1)

@@ -1,0 +1,71 @@
+"""CPU rehearsal of the N>1 path: two gloo ranks shard frames/patches and all-gather descriptor shards."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "local-features_amd"))
+    from local_features_python import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # shard 7 frames of different keypoint counts by image
+    kp_per_frame = [5, 0, 3, 9, 1, 4, 2]
+    mine = sharding.frames_of_rank(len(kp_per_frame), rank, world)
+    rng = np.random.default_rng(1234)
+    all_desc = [rng.random((k, 128)).astype(np.float32) for k in kp_per_frame]   # same on every rank
+    local = torch.from_numpy(np.concatenate([all_desc[f] for f in mine] or [np.zeros((0, 128), np.float32)]))
+    gathered, counts = sharding.all_gather_descriptors(local)
+    expect = np.concatenate([np.concatenate([all_desc[f] for f in sharding.frames_of_rank(7, r, world)])
+                             for r in range(world)])
+    ok = gathered.shape == (sum(kp_per_frame), 128) and np.array_equal(gathered.numpy(), expect)
+    ok = ok and counts == [sum(kp_per_frame[f] for f in sharding.frames_of_rank(7, r, world)) for r in range(world)]
+    tmax = sharding.max_over_ranks(1.0 + rank, "cpu")
+    ok = ok and tmax == float(world)
+    a, b = sharding.patch_slice_of_rank(1001, rank, world)
+    q.put((rank, ok, a, b))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_and_all_gather():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res)
+    assert [(a, b) for _, _, a, b in res] == [(0, 501), (501, 1001)]
+
+
+def test_slices_cover_everything():
+    sys.path.insert(0, os.path.join(ROOT, "local-features_amd"))
+    from local_features_python import sharding
+    for n in (0, 1, 7, 1 << 20):
+        for world in (1, 2, 3, 8):
+            cuts = [sharding.patch_slice_of_rank(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            frames = sorted(f for r in range(world) for f in sharding.frames_of_rank(n % 97, r, world))
+            assert frames == list(range(n % 97))
