@@ -26,6 +26,11 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Two adjacent pixels per register pair: arithmetic on f32x2 compiles to v_pk_{mul,add,fma}_f32, which issue
+// in the time of one scalar-f32 VALU instruction (tools/micro/valu_rate.hip) -- the kernel is VALU-issue-bound.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_set(float v) { return f32x2{v, v}; }
 
 constexpr int kTiles = 21;   // accumulator tiles (16 packed columns each), see mkd_consts.hpp
 // Accumulator tile numbering: m 0-2 | rel cos k 3+2(k-1).. | rel sin k 9+2(k-1).. | abs cos k 14+k | abs sin k 17+k.
@@ -69,39 +74,53 @@ __device__ __forceinline__ void issue_raw_row(const float *__restrict__ src_lane
     lds_dma16(src_lane + y * 32 + 16, ring + slot * 2048 + 1024);
 }
 
-// cos/sin of the gradient angle theta = -atan2(gy over gx).
+// cos/sin of the gradient angle theta = -atan2(gy over gx), for a pair of pixels.
 template <int ANGLE>
-__device__ __forceinline__ void gradient_direction(float gx, float gy, float &ct, float &st) {
+__device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 &ct, f32x2 &st) {
     if (ANGLE == LF_ANGLE_EXACT) {
-        const float r2 = fmaf(gx, gx, gy * gy);
-        const float inv = __builtin_amdgcn_rsqf(r2);
-        const bool zero = r2 == 0.f;
-        ct = zero ? 1.f : gx * inv;
-        st = zero ? 0.f : -gy * inv;
+        const f32x2 r2 = pk_fma(gx, gx, gy * gy);
+        const f32x2 inv = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+        const f32x2 c = gx * inv, s = -gy * inv;
+        ct = f32x2{r2.x == 0.f ? 1.f : c.x, r2.y == 0.f ? 1.f : c.y};
+        st = f32x2{r2.x == 0.f ? 0.f : s.x, r2.y == 0.f ? 0.f : s.y};
     } else {
         // atan2.glsl:19-46 called as atan2(x = gx, y = gy).  With p = poly(a), |a| <= 1, the
         // branches of the shader are quadrant symmetries of (cos p, sin p):
         //   swap:  res = sign(a) pi/2 - p  -> (cos, sin) = sign(a) (sin p, cos p); a == 0 -> res = 0
         //   x < 0: res += +-pi              -> both negated
-        const float ax = fabsf(gx), ay = fabsf(gy);
-        const bool swap = ax < ay;
-        const float num = swap ? gx : gy, den = swap ? gy : gx;
-        const float a = num * __builtin_amdgcn_rcpf(den);
-        const float s = a * a;
-        const float p = a * (0.99997726f + s * (-0.33262347f + s * (0.19354346f + s * (-0.11643287f +
-                             s * (0.05265332f + s * -0.0117212f)))));
-        const float p2 = p * p;  // |p| <= 0.7854: Taylor to p^9 / p^8 is below 1e-8
-        const float sn = p * (1.f + p2 * (-1.6666667e-1f + p2 * (8.3333333e-3f + p2 * (-1.9841270e-4f +
-                              p2 * 2.7557319e-6f))));
-        const float cs = 1.f + p2 * (-0.5f + p2 * (4.1666667e-2f + p2 * (-1.3888889e-3f + p2 * 2.4801587e-5f)));
-        const float sa = a > 0.f ? 1.f : -1.f;
-        float cr = swap ? sa * sn : cs;
-        float sr = swap ? sa * cs : sn;
-        if (swap && a == 0.f) { cr = 1.f; sr = 0.f; }  // the atan2(0, y != 0) == 0 quirk
-        if (gx < 0.f) { cr = -cr; sr = -sr; }
-        if (ax == 0.f && ay == 0.f) { cr = 1.f; sr = 0.f; }
-        ct = cr;   // theta = -res
-        st = -sr;
+        const bool sw0 = fabsf(gx.x) < fabsf(gy.x), sw1 = fabsf(gx.y) < fabsf(gy.y);
+        const f32x2 num = {sw0 ? gx.x : gy.x, sw1 ? gx.y : gy.y};
+        const f32x2 den = {sw0 ? gy.x : gx.x, sw1 ? gy.y : gx.y};
+        const f32x2 a = num * f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        const f32x2 s = a * a;
+        f32x2 p = pk_fma(s, pk_set(-0.0117212f), pk_set(0.05265332f));
+        p = pk_fma(s, p, pk_set(-0.11643287f));
+        p = pk_fma(s, p, pk_set(0.19354346f));
+        p = pk_fma(s, p, pk_set(-0.33262347f));
+        p = pk_fma(s, p, pk_set(0.99997726f));
+        p = a * p;
+        const f32x2 p2 = p * p;  // |p| <= 0.7854: Taylor to p^9 / p^8 is below 1e-8
+        f32x2 sn = pk_fma(p2, pk_set(2.7557319e-6f), pk_set(-1.9841270e-4f));
+        sn = pk_fma(p2, sn, pk_set(8.3333333e-3f));
+        sn = pk_fma(p2, sn, pk_set(-1.6666667e-1f));
+        sn = pk_fma(p2, sn, pk_set(1.f));
+        sn = p * sn;
+        f32x2 cs = pk_fma(p2, pk_set(2.4801587e-5f), pk_set(-1.3888889e-3f));
+        cs = pk_fma(p2, cs, pk_set(4.1666667e-2f));
+        cs = pk_fma(p2, cs, pk_set(-0.5f));
+        cs = pk_fma(p2, cs, pk_set(1.f));
+        const f32x2 sa = {a.x > 0.f ? 1.f : -1.f, a.y > 0.f ? 1.f : -1.f};
+        const f32x2 ssn = sa * sn, scs = sa * cs;
+        float cr0 = sw0 ? ssn.x : cs.x, sr0 = sw0 ? scs.x : sn.x;
+        float cr1 = sw1 ? ssn.y : cs.y, sr1 = sw1 ? scs.y : sn.y;
+        if (sw0 && a.x == 0.f) { cr0 = 1.f; sr0 = 0.f; }  // the atan2(0, y != 0) == 0 quirk
+        if (sw1 && a.y == 0.f) { cr1 = 1.f; sr1 = 0.f; }
+        if (gx.x < 0.f) { cr0 = -cr0; sr0 = -sr0; }
+        if (gx.y < 0.f) { cr1 = -cr1; sr1 = -sr1; }
+        if (gx.x == 0.f && gy.x == 0.f) { cr0 = 1.f; sr0 = 0.f; }
+        if (gx.y == 0.f && gy.y == 0.f) { cr1 = 1.f; sr1 = 0.f; }
+        ct = f32x2{cr0, cr1};   // theta = -res
+        st = f32x2{-sr0, -sr1};
     }
 }
 
@@ -113,6 +132,9 @@ struct BFrag { u32x4 p0, p1; };
 template <int UT>
 __device__ __forceinline__ BFrag load_b(const unsigned char *brow) {
     BFrag b;
+#ifdef LF_ABLATE_BLOAD  // timing-only build: no LUT fragment reads
+    b.p0 = u32x4{(unsigned)UT, 1u, 2u, 3u}; b.p1 = b.p0; return b;
+#endif
     b.p0 = *reinterpret_cast<const u32x4 *>(brow + (UT * 2 + 0) * 1024);
     b.p1 = *reinterpret_cast<const u32x4 *>(brow + (UT * 2 + 1) * 1024);
     return b;
@@ -126,21 +148,43 @@ __device__ __forceinline__ unsigned pack_rtz(float a, float b) {
 template <int POOL> struct AFrag;
 template <> struct AFrag<LF_POOL_F32> {
     float v[8];
-    __device__ __forceinline__ void set(const float (&a)[8]) {
+    __device__ __forceinline__ void set(const f32x2 (&a)[4]) {
 #pragma unroll
-        for (int x = 0; x < 8; ++x) v[x] = a[x];
+        for (int e = 0; e < 4; ++e) { v[2 * e] = a[e].x; v[2 * e + 1] = a[e].y; }
+    }
+    __device__ __forceinline__ void set_product(const f32x2 (&m)[4], const f32x2 (&t)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const f32x2 p = m[e] * t[e]; v[2 * e] = p.x; v[2 * e + 1] = p.y; }
     }
 };
 template <> struct AFrag<LF_POOL_F16X3> {
     u32x4 hi, lo;
-    __device__ __forceinline__ void set(const float (&a)[8]) {
+    __device__ __forceinline__ void set(const f32x2 (&a)[4]) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const unsigned h = pack_rtz(a[2 * e], a[2 * e + 1]);
+            const unsigned h = pack_rtz(a[e].x, a[e].y);
             const float h0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xffffu));
             const float h1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h >> 16));
             hi[e] = h;
-            lo[e] = pack_rtz(a[2 * e] - h0, a[2 * e + 1] - h1);
+            lo[e] = pack_rtz(a[e].x - h0, a[e].y - h1);
+        }
+    }
+    // stream value = m * t: hi from the packed product, lo = fma(m, t, -hi) so that each residual is ONE
+    // v_fma_mix_f32 (f32 x f32 - f16) instead of an unpack plus a subtract
+    __device__ __forceinline__ void set_product(const f32x2 (&m)[4], const f32x2 (&t)[4]) {
+#ifdef LF_ABLATE_SPLIT  // timing-only build: no product / hi-lo split
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = __float_as_uint(m[e].x); lo[e] = __float_as_uint(t[e].y); }
+        return;
+#endif
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x2 p = m[e] * t[e];
+            const unsigned h = pack_rtz(p.x, p.y);
+            const float h0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xffffu));
+            const float h1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h >> 16));
+            hi[e] = h;
+            lo[e] = pack_rtz(__builtin_fmaf(m[e].x, t[e].x, -h0), __builtin_fmaf(m[e].y, t[e].y, -h1));
         }
     }
 };
@@ -152,6 +196,9 @@ template <> struct AFrag<LF_POOL_F16X3> {
 // dependent MFMAs of one tile.
 template <int POOL, int PART>
 __device__ __forceinline__ void mma_part(const AFrag<POOL> &a, const BFrag &b, f32x4 &acc) {
+#ifdef LF_ABLATE_MMA   // timing-only build: no matrix instructions, operands kept alive
+    if constexpr (POOL == LF_POOL_F16X3) { asm volatile("" ::"v"(a.hi), "v"(a.lo), "v"(b.p0), "v"(b.p1)); return; }
+#endif
     if constexpr (POOL == LF_POOL_F32) {
         const f32x4 b0 = __builtin_bit_cast(f32x4, b.p0), b1 = __builtin_bit_cast(f32x4, b.p1);
         if (PART == 0) {
@@ -192,18 +239,21 @@ __device__ __forceinline__ void mma_pair(const AFrag<POOL> &ac, const AFrag<POOL
 __device__ __forceinline__ void blur_row(const unsigned char *ring_lane, int s0, int addr_l, int addr_r, bool has_l,
                                          bool has_r, float (&out)[8], float &out_l, float &out_r) {
     float vb[8];
-    const float kk[5] = {kB0, kB1, kB2, kB1, kB0};
+    {
+        const float kk[5] = {kB0, kB1, kB2, kB1, kB0};
+        f32x2 v2[4];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        int sl = s0 + i;
-        sl = sl >= kRingSlots ? sl - kRingSlots : sl;
-        const f32x4 lo = *reinterpret_cast<const f32x4 *>(ring_lane + sl * 2048);
-        const f32x4 hi = *reinterpret_cast<const f32x4 *>(ring_lane + sl * 2048 + 256);
+        for (int i = 0; i < 5; ++i) {
+            int sl = s0 + i;
+            sl = sl >= kRingSlots ? sl - kRingSlots : sl;
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(ring_lane + sl * 2048);
+            const f32x4 hi = *reinterpret_cast<const f32x4 *>(ring_lane + sl * 2048 + 256);
+            const f32x2 r[4] = {{lo[0], lo[1]}, {lo[2], lo[3]}, {hi[0], hi[1]}, {hi[2], hi[3]}};
 #pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            const float r = x < 4 ? lo[x & 3] : hi[x & 3];
-            vb[x] = i == 0 ? kk[0] * r : fmaf(kk[i], r, vb[x]);
+            for (int e = 0; e < 4; ++e) v2[e] = i == 0 ? pk_set(kk[0]) * r[e] : pk_fma(pk_set(kk[i]), r[e], v2[e]);
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vb[2 * e] = v2[e].x; vb[2 * e + 1] = v2[e].y; }
     }
     float ext[12];
     const float l0 = lane_fetch(addr_l, vb[6]), l1 = lane_fetch(addr_l, vb[7]);
@@ -232,20 +282,16 @@ __device__ __forceinline__ void blur_row(const unsigned char *ring_lane, int s0,
 // uses unique LUT tiles [U0 + NT*(k-1), +NT) and accumulator tiles C0 + NT*(k-1).. (cos), S0 + NT*(k-1).. (sin).
 // `bnext` holds the fragments of harmonic 1 on entry (prefetched by the caller).
 template <int POOL, int NT, int U0, int C0, int S0>
-__device__ __forceinline__ void pool_family(const float (&m)[8], const float (&c1)[8], const float (&s1)[8],
+__device__ __forceinline__ void pool_family(const f32x2 (&m)[4], const f32x2 (&c1)[4], const f32x2 (&s1)[4],
                                             const unsigned char *brow, BFrag (&b)[NT], f32x4 (&acc)[kTiles]) {
-    float ck[8], sk[8], v[8];
+    f32x2 ck[4], sk[4];
     AFrag<POOL> ac, as;
 #pragma unroll
-    for (int x = 0; x < 8; ++x) { ck[x] = c1[x]; sk[x] = s1[x]; }
+    for (int e = 0; e < 4; ++e) { ck[e] = c1[e]; sk[e] = s1[e]; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-#pragma unroll
-        for (int x = 0; x < 8; ++x) v[x] = m[x] * ck[x];
-        ac.set(v);
-#pragma unroll
-        for (int x = 0; x < 8; ++x) v[x] = m[x] * sk[x];
-        as.set(v);
+        ac.set_product(m, ck);
+        as.set_product(m, sk);
         BFrag bcur[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) bcur[t] = b[t];
@@ -256,10 +302,10 @@ __device__ __forceinline__ void pool_family(const float (&m)[8], const float (&c
                 else b[t] = load_b<U0 + 2 * NT>(brow + t * 2048);
             }
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const float c = ck[x] * c1[x] - sk[x] * s1[x];
-                sk[x] = sk[x] * c1[x] + ck[x] * s1[x];
-                ck[x] = c;
+            for (int e = 0; e < 4; ++e) {  // angle addition: (ck, sk) <- (ck, sk) * (c1, s1)
+                const f32x2 c = pk_fma(ck[e], c1[e], -(sk[e] * s1[e]));
+                sk[e] = pk_fma(sk[e], c1[e], ck[e] * s1[e]);
+                ck[e] = c;
             }
         }
         mma_pair<POOL, NT>(ac, as, bcur, &acc[C0 + NT * k], &acc[S0 + NT * k]);
@@ -346,12 +392,9 @@ __device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lan
             __builtin_amdgcn_sched_barrier(0);
             const int s = u >> 1;
             if ((u & 1) == 0) {
-                float y[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    y[i] = acc[2 * s][i];
-                    y[4 + i] = 2 * s + 1 < kTiles ? acc[(2 * s + 1 < kTiles) ? 2 * s + 1 : 0][i] : 0.f;
-                }
+                const f32x4 y0 = acc[2 * s];
+                const f32x4 y1 = 2 * s + 1 < kTiles ? acc[(2 * s + 1 < kTiles) ? 2 * s + 1 : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x2 y[4] = {{y0[0], y0[1]}, {y0[2], y0[3]}, {y1[0], y1[1]}, {y1[2], y1[3]}};
                 AFrag<LF_POOL_F16X3> yb;
                 yb.set(y);
                 yh = __builtin_bit_cast(f16x8, yb.hi);
@@ -476,13 +519,18 @@ __global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patche
 #pragma unroll 1
         for (int g = 0; g < 32; ++g) {
             // LUT row g and ring row g+3 have landed (own DMA: vmcnt; everyone's: barrier); row g-1 is done
+#ifndef LF_ABLATE_SYNC
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+#endif
             const unsigned char *brow = s_mem + par * kRowBytes + lane * 16;
             if (g < 31 || more) issue_lut_row(lut_rows, (g + 1) & 31, s_mem + (par ^ 1) * kRowBytes, wave, lane);
             par ^= 1;
             BFrag bm[3] = {load_b<0>(brow), load_b<1>(brow), load_b<2>(brow)};   // m-stream fragments
 
+#ifdef LF_ABLATE_FRONT  // timing-only build: no blur, no gradient direction
+#define blur_row(rl, s, al, ar, hl, hr, o, ol, or_) do { const f32x4 a_ = *reinterpret_cast<const f32x4 *>(rl + (s) * 2048); const f32x4 b_ = *reinterpret_cast<const f32x4 *>(rl + (s) * 2048 + 256); for (int x_ = 0; x_ < 4; ++x_) { o[x_] = a_[x_]; o[4 + x_] = b_[x_]; } ol = o[0]; or_ = o[7]; } while (0)
+#endif
             if (g == 0) {  // first blurred row of the batch: rows -2..2 sit in slots 0..4
                 blur_row(ring_lane, 0, addr_l, addr_r, has_l, has_r, cur, cur_l, cur_r);
 #pragma unroll
@@ -507,14 +555,22 @@ __global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patche
             }
             s0 = s0 == kRingSlots - 1 ? 0 : s0 + 1;
 
-            float m[8], c1[8], s1[8];
+            f32x2 m[4], c1[4], s1[4];
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {  // patch_gradients.glsl:94-100
-                const float left = x == 0 ? cur_l : cur[x - 1];
-                const float right = x == 7 ? cur_r : cur[x + 1];
-                const float gx = left - right, gy = nxt[x] - prv[x];   // left - right, down - up
-                m[x] = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(gx * gx + gy * gy + 1e-8f));
-                gradient_direction<ANGLE>(gx, gy, c1[x], s1[x]);
+            for (int e = 0; e < 4; ++e) {  // patch_gradients.glsl:94-100, two pixels at a time
+                const int x = 2 * e;
+                const f32x2 left = {x == 0 ? cur_l : cur[x - 1], cur[x]};
+                const f32x2 right = {cur[x + 1], x == 6 ? cur_r : cur[x + 2]};
+                const f32x2 gx = left - right;                                   // left - right
+                const f32x2 gy = f32x2{nxt[x], nxt[x + 1]} - f32x2{prv[x], prv[x + 1]};   // down - up
+                const f32x2 r2 = gx * gx + gy * gy + pk_set(1e-8f);
+                m[e] = f32x2{__builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(r2.x)),
+                             __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(r2.y))};
+#ifdef LF_ABLATE_FRONT
+                c1[e] = gx; s1[e] = gy;
+#else
+                gradient_direction<ANGLE>(gx, gy, c1[e], s1[e]);
+#endif
             }
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
@@ -540,16 +596,15 @@ __global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patche
             BFrag brel[2] = {load_b<6>(brow), load_b<7>(brow)};
             pool_family<POOL, 1, 3, 15, 18>(m, c1, s1, brow, babs, acc);
             // angle + gradient_angle(px) (embedding.glsl:70-72) x polar kernels: unique tiles 6-11
-            float d1[8], e1[8];
+            f32x2 d1[4], e1[4];
             {
                 const f32x4 *pp = reinterpret_cast<const f32x4 *>(&s_phi[(g * 32 + 8 * q) * 2]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 t4 = pp[i];
-                    d1[2 * i] = c1[2 * i] * t4[0] - s1[2 * i] * t4[1];
-                    e1[2 * i] = s1[2 * i] * t4[0] + c1[2 * i] * t4[1];
-                    d1[2 * i + 1] = c1[2 * i + 1] * t4[2] - s1[2 * i + 1] * t4[3];
-                    e1[2 * i + 1] = s1[2 * i + 1] * t4[2] + c1[2 * i + 1] * t4[3];
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 t4 = pp[e];   // cos, sin of phi for pixels 2e, 2e+1
+                    const f32x2 cp = {t4[0], t4[2]}, sp = {t4[1], t4[3]};
+                    d1[e] = pk_fma(c1[e], cp, -(s1[e] * sp));
+                    e1[e] = pk_fma(s1[e], cp, c1[e] * sp);
                 }
             }
             pool_family<POOL, 2, 6, 3, 9>(m, d1, e1, brow, brel, acc);
@@ -559,7 +614,12 @@ __global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patche
         const unsigned char *wf = wfrag;
         const float *bs = bias;
         asm volatile("" : "+s"(wf), "+s"(bs));
+#ifdef LF_ABLATE_EPILOGUE  // timing-only build
+        { f32x4 sum = acc[0]; for (int t = 1; t < kTiles; ++t) sum += acc[t];
+          if (base + p < n) *reinterpret_cast<f32x4 *>(out + (base + p) * 128 + 4 * q) = sum; }
+#else
         finish_descriptors<POOL>(acc, lane, base + p < n, base + p, colmap, wf, bs, out, raw_out);
+#endif
     }
 }
 
