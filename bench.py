@@ -118,6 +118,23 @@ def main():
     from local_features_python import sharding
     dt = sharding.max_over_ranks(dt, "cuda")
 
+    # secondary figure: the same workload with the exact gradient direction instead of the shader's polynomial
+    # atan2 (lf_mkd_angle_mode; both are inside the 1e-4 gate, tests/test_gpu_parity.py)
+    alt = None
+    if world == 1 and args.angle == "shader":
+        h2 = lfp.MkdHandle(pca="liberty", max_features=n, device=local_rank, angle_mode=lfp.ANGLE_EXACT,
+                           pool_mode=lfp.POOL_F32 if args.pool == "f32" else lfp.POOL_F16X3)
+        out2 = torch.empty_like(out)
+        for _ in range(2):
+            h2.describe_patches_device(patches.data_ptr(), n, out2.data_ptr(), stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            h2.describe_patches_device(patches.data_ptr(), n, out2.data_ptr(), stream)
+        torch.cuda.synchronize()
+        alt = n * args.steps / (time.perf_counter() - t1)
+        del out2
+
     # sanity on the timed output: finite, unit norm (a wrong-but-fast kernel must not pass silently)
     nrm = out.norm(dim=1)
     ok = bool(torch.isfinite(out).all().item()) and float((nrm - 1).abs().max().item()) < 1e-4
@@ -147,6 +164,7 @@ def main():
                                    "(per-GPU share of BASELINE configs[3]; SURVEY 8(d) headline), PCA=liberty",
                        "patches_per_gpu": n, "angle_mode": args.angle, "pool_mode": args.pool,
                        "parallelism": f"shard-by-rank x{world}, no collective"},
+            "exact_angle_mode_value": alt,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mkd_pool", "kernel_ms": kern_s * 1e3,

@@ -9,7 +9,7 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned pk(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b)); }
 
-template <int DIST, int NV, bool MFMA, bool LDSB = false, int NACC = 4>
+template <int DIST, int NV, bool MFMA, int LDSB = 0, int NACC = 4>
 __global__ void k(float *out, int iters, float a, float b) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[24576];
     for (int i = threadIdx.x; i < 24576 / 4; i += blockDim.x) reinterpret_cast<unsigned *>(lds)[i] = 0x3C003C00u;
@@ -22,6 +22,7 @@ __global__ void k(float *out, int iters, float a, float b) {
     f4 c[NACC];
     for (int i = 0; i < NACC; ++i) c[i] = f4{0, 0, 0, 0};
     u4 fr[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    h8 Bnext = B, Bnext2 = B;
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -29,7 +30,9 @@ __global__ void k(float *out, int iters, float a, float b) {
             fr[u & 1] = f;
             const u4 use = DIST == 0 ? f : fr[(u + 1) & 1];
             h8 Bv = B;
-            if (LDSB) Bv = *reinterpret_cast<const h8 *>(brow + ((u * 3 + i) % 24) * 1024);
+            if (LDSB == 1) Bv = *reinterpret_cast<const h8 *>(brow + ((u * 3 + i) % 24) * 1024);
+            if (LDSB == 2) { Bv = Bnext; Bnext = *reinterpret_cast<const h8 *>(brow + ((u * 3 + i + 1) % 24) * 1024); }
+            if (LDSB == 3) { Bv = Bnext; Bnext = Bnext2; Bnext2 = *reinterpret_cast<const h8 *>(brow + ((u * 3 + i + 2) % 24) * 1024); }
             if (MFMA) c[u % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, use), Bv, c[u % NACC], 0, 0, 0);
             else if (LDSB) asm volatile("" ::"v"(Bv));
             else asm volatile("" ::"v"(use));
@@ -43,7 +46,7 @@ __global__ void k(float *out, int iters, float a, float b) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int DIST, int NV, bool MFMA, bool LDSB = false, int NACC = 4>
+template <int DIST, int NV, bool MFMA, int LDSB = 0, int NACC = 4>
 void run(int threads, float *d) {
     const int iters = 4000, blocks = 256;
     hipEvent_t e0, e1;
@@ -54,7 +57,7 @@ void run(int threads, float *d) {
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-    printf("%s dist=%d NV=%2d ldsB=%d nacc=%d %4d thr/CU: %.2f ns per group per SIMD\n", MFMA ? "MFMA   " : "no-MFMA", DIST, NV, (int)LDSB, NACC, threads,
+    printf("%s dist=%d NV=%2d ldsB=%d nacc=%d %4d thr/CU: %.2f ns per group per SIMD\n", MFMA ? "MFMA   " : "no-MFMA", DIST, NV, LDSB, NACC, threads,
            ms * 1e6 / ((double)iters * 8 * (threads / 256.0)));
 }
 
@@ -63,8 +66,7 @@ int main() {
     for (int thr : {256, 512}) {
         run<0, 12, false>(thr, d); run<0, 12, true>(thr, d); run<1, 12, true>(thr, d);
         run<0, 24, false>(thr, d); run<0, 24, true>(thr, d); run<1, 24, true>(thr, d);
-        run<0, 12, false, true>(thr, d); run<0, 12, true, true>(thr, d); run<0, 12, true, true, 8>(thr, d);
-        run<0, 8, false, true>(thr, d); run<0, 8, true, true, 8>(thr, d);
+        run<0, 12, false, 1>(thr, d); run<0, 12, true, 1>(thr, d); run<0, 12, false, 2>(thr, d); run<0, 12, true, 2>(thr, d); run<0, 12, false, 3>(thr, d); run<0, 12, true, 3>(thr, d);
     }
     return 0;
 }
