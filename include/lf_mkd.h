@@ -69,7 +69,9 @@ typedef struct {
     int32_t angle_mode;         /* lf_mkd_angle_mode                                           */
     int32_t pool_mode;          /* lf_mkd_pool_mode                                            */
     uint32_t flags;             /* LF_MKD_FLAG_*                                               */
-    uint32_t reserved[4];
+    uint32_t max_frames;        /* frames of max_image_* size the pyramid store holds for the
+                                   multi-frame entry points (default 1)                         */
+    uint32_t reserved[3];
 } lf_mkd_params;
 
 /* Keypoint as the path consumes it: struct Keypoint, lib.rs:17-24 (angle in DEGREES,
@@ -116,11 +118,24 @@ int lf_mkd_set_image(lf_mkd *h, const float *image, uint32_t width, uint32_t hei
 int lf_mkd_set_image_device(lf_mkd *h, const float *d_image, uint32_t width, uint32_t height,
                             void *stream);
 
+/* Multi-frame form of step 1 (BASELINE configs[2], [3]: hundreds of small frames): n_frames frames of one
+ * size, contiguous [n_frames][height][width] in device memory, all pyramids built by one set of launches.
+ * n_frames <= max_frames. */
+int lf_mkd_set_images_device(lf_mkd *h, const float *d_images, uint32_t n_frames, uint32_t width,
+                             uint32_t height, void *stream);
+
 /* Keypoint mode, step 2: sample + describe (patch_gradients.glsl:42-70 onwards).
  * out: [n][128].  Host pointers; synchronous. */
 int lf_mkd_describe_keypoints(lf_mkd *h, const lf_mkd_keypoint *kps, uint64_t n, float *out);
 int lf_mkd_describe_keypoints_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64_t n,
                                      float *d_out, void *stream);
+
+/* Multi-frame form of step 2: d_frame_of_kp[i] (device, may be NULL = all frame 0) names the frame of
+ * keypoint i among those given to lf_mkd_set_images_device.  One sampling launch + one describe launch
+ * per internal batch, whatever the number of frames. */
+int lf_mkd_describe_keypoints_frames_device(lf_mkd *h, const lf_mkd_keypoint *d_kps,
+                                            const uint32_t *d_frame_of_kp, uint64_t n, float *d_out,
+                                            void *stream);
 
 /* Verification taps for keypoint mode (device pointers). */
 int lf_mkd_sample_patches_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64_t n,

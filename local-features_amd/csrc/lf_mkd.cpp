@@ -29,6 +29,8 @@ struct lf_mkd {
     PyramidDesc pd{};
     float *d_image = nullptr, *d_pyr = nullptr, *d_tmp_a = nullptr, *d_tmp_b = nullptr;
     bool have_image = false;
+    uint32_t max_frames = 1, n_frames = 0;  // frames held by the pyramid store / currently loaded
+    long pyr_stride = 0;                    // floats between the pyramids of consecutive frames
     int num_cus = 256;
     // LF_MKD_FLAG_KERNEL_TIMING: (start, end) of the describe kernel per batch
     std::vector<hipEvent_t> ev_pending, ev_free;
@@ -129,12 +131,13 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_out), h->batch * kOut * 4));
     LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_kps), h->batch * 5 * 4));
     if (params->max_image_width && params->max_image_height) {
-        const size_t px = size_t(params->max_image_width) * params->max_image_height;
+        h->max_frames = params->max_frames ? params->max_frames : 1;
+        const size_t px = size_t(params->max_image_width) * params->max_image_height * h->max_frames;
+        h->pyr_stride = pyramid_floats(params->max_image_width, params->max_image_height);
         LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_image), px * 4));
         LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_tmp_a), px * 4));
         LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_tmp_b), px * 4));
-        LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_pyr),
-                                size_t(pyramid_floats(params->max_image_width, params->max_image_height)) * 4));
+        LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_pyr), size_t(h->pyr_stride) * h->max_frames * 4));
     }
 #undef LF_CREATE_HIP
     *out = h;
@@ -296,20 +299,30 @@ int lf_mkd_describe_patches(lf_mkd *h, const float *patches, uint64_t n, float *
     return LF_MKD_OK;
 }
 
-int lf_mkd_set_image_device(lf_mkd *h, const float *d_image, uint32_t width, uint32_t height, void *stream) {
+int lf_mkd_set_images_device(lf_mkd *h, const float *d_images, uint32_t n_frames, uint32_t width, uint32_t height,
+                             void *stream) {
     if (!h) return LF_MKD_ERR_BAD_ARG;
-    if (!d_image || width < 2 || height < 2) return fail(h, LF_MKD_ERR_BAD_ARG, "set_image: bad image");
+    if (!d_images || width < 2 || height < 2 || n_frames == 0) return fail(h, LF_MKD_ERR_BAD_ARG, "set_image: bad image");
     if (!h->d_pyr || width > h->params.max_image_width || height > h->params.max_image_height)
         return fail(h, LF_MKD_ERR_BAD_ARG,
                     "set_image: image " + std::to_string(width) + "x" + std::to_string(height) +
                         " exceeds max_image_width/height given at creation");
+    if (n_frames > h->max_frames)
+        return fail(h, LF_MKD_ERR_BAD_ARG, "set_images: " + std::to_string(n_frames) + " frames exceed max_frames = " +
+                                               std::to_string(h->max_frames) + " given at creation");
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     describe_pyramid(width, height, h->pd);
-    launch_build_pyramid(d_image, h->d_pyr, h->d_tmp_a, h->d_tmp_b, h->pd, s);
+    launch_build_pyramid(d_images, long(width) * height, h->d_pyr, h->pyr_stride, h->d_tmp_a, h->d_tmp_b, h->pd,
+                         int(n_frames), s);
     LF_HIP(h, hipGetLastError());
     h->have_image = true;
+    h->n_frames = n_frames;
     return LF_MKD_OK;
+}
+
+int lf_mkd_set_image_device(lf_mkd *h, const float *d_image, uint32_t width, uint32_t height, void *stream) {
+    return lf_mkd_set_images_device(h, d_image, 1, width, height, stream);
 }
 
 int lf_mkd_set_image(lf_mkd *h, const float *image, uint32_t width, uint32_t height) {
@@ -333,14 +346,14 @@ int lf_mkd_sample_patches_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64
     if (!d_kps || !d_patches) return fail(h, LF_MKD_ERR_BAD_ARG, "sample_patches: null pointer");
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
-    launch_sample_patches(h->d_pyr, h->pd, reinterpret_cast<const float *>(d_kps), long(n),
+    launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_kps), nullptr, long(n),
                           h->params.patch_scale_factor, d_patches, s);
     LF_HIP(h, hipGetLastError());
     return LF_MKD_OK;
 }
 
-int lf_mkd_describe_keypoints_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64_t n, float *d_out,
-                                     void *stream) {
+int lf_mkd_describe_keypoints_frames_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, const uint32_t *d_frame_of_kp,
+                                            uint64_t n, float *d_out, void *stream) {
     if (!h) return LF_MKD_ERR_BAD_ARG;
     if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "describe_keypoints: call lf_mkd_set_image first");
     if (n == 0) return LF_MKD_OK;
@@ -349,13 +362,19 @@ int lf_mkd_describe_keypoints_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, ui
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     for (uint64_t off = 0; off < n; off += h->batch) {
         const uint64_t m = std::min<uint64_t>(h->batch, n - off);
-        launch_sample_patches(h->d_pyr, h->pd, reinterpret_cast<const float *>(d_kps + off), long(m),
-                              h->params.patch_scale_factor, h->d_patches, s);
+        launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_kps + off),
+                              d_frame_of_kp ? d_frame_of_kp + off : nullptr, long(m), h->params.patch_scale_factor,
+                              h->d_patches, s);
         LF_HIP(h, hipGetLastError());
         const int rc = run_batch(h, h->d_patches, m, d_out + off * kOut, nullptr, s);
         if (rc) return rc;
     }
     return LF_MKD_OK;
+}
+
+int lf_mkd_describe_keypoints_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64_t n, float *d_out,
+                                     void *stream) {
+    return lf_mkd_describe_keypoints_frames_device(h, d_kps, nullptr, n, d_out, stream);
 }
 
 int lf_mkd_describe_keypoints(lf_mkd *h, const lf_mkd_keypoint *kps, uint64_t n, float *out) {
@@ -367,8 +386,8 @@ int lf_mkd_describe_keypoints(lf_mkd *h, const lf_mkd_keypoint *kps, uint64_t n,
     for (uint64_t off = 0; off < n; off += h->batch) {
         const uint64_t m = std::min<uint64_t>(h->batch, n - off);
         LF_HIP(h, hipMemcpyAsync(h->d_kps, kps + off, m * sizeof(lf_mkd_keypoint), hipMemcpyHostToDevice, h->stream));
-        launch_sample_patches(h->d_pyr, h->pd, h->d_kps, long(m), h->params.patch_scale_factor, h->d_patches,
-                              h->stream);
+        launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, h->d_kps, nullptr, long(m), h->params.patch_scale_factor,
+                              h->d_patches, h->stream);
         LF_HIP(h, hipGetLastError());
         const int rc = run_batch(h, h->d_patches, m, h->d_out, nullptr, h->stream);
         if (rc) return rc;

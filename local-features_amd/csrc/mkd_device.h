@@ -33,9 +33,10 @@ struct DeviceConsts {
 // patches [n][32][32] -> out [n][128] (and, when raw_out != nullptr, the un-whitened [n][238])
 void launch_describe(const float *patches, long n, const DeviceConsts &dc, int angle_mode, int pool_mode, float *out,
                      float *raw_out, int num_cus, hipStream_t stream);
-void launch_sample_patches(const float *pyr, const PyramidDesc &pd, const float *kps, long n, float psf,
-                           float *patches, hipStream_t stream);
-void launch_build_pyramid(const float *image, float *pyr, float *tmp_a, float *tmp_b, const PyramidDesc &pd,
-                          hipStream_t stream);
+// frame_of_kp == nullptr: every keypoint belongs to frame 0
+void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
+                           const unsigned *frame_of_kp, long n, float psf, float *patches, hipStream_t stream);
+void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,
+                          float *tmp_b, const PyramidDesc &pd, int frames, hipStream_t stream);
 
 }  // namespace lfmkd

@@ -651,12 +651,16 @@ __device__ __forceinline__ float tex_bilinear(const float *__restrict__ img, int
 
 }  // namespace
 
+// All pyramid kernels work on a batch of frames of one size: blockIdx.z = frame, consecutive frames are
+// in_stride / out_stride floats apart.
 // blur.glsl:34-65 (sigma 0.6) and blur_pyramid.glsl horizontal pass share this shape:
 // out = w0 * tex(c) + w1 * (tex(c - off) + tex(c + off)) along one axis.
-__global__ void pyr_sep3(const float *__restrict__ in, float *__restrict__ out, int w, int h, float w0,
-                         float w1, float off, int vertical) {
+__global__ void pyr_sep3(const float *__restrict__ in, float *__restrict__ out, long in_stride, long out_stride, int w,
+                         int h, float w0, float w1, float off, int vertical) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
+    in += blockIdx.z * in_stride;
+    out += blockIdx.z * out_stride;
     const float cx = (float)x + 0.5f, cy = (float)y + 0.5f;
     const float dx = vertical ? 0.f : off, dy = vertical ? off : 0.f;
     float s = tex_bilinear(in, w, h, cx, cy) * w0;
@@ -665,9 +669,12 @@ __global__ void pyr_sep3(const float *__restrict__ in, float *__restrict__ out, 
 }
 
 // swt.glsl:24-58 with in_level = 0: [1 4 6 4 1]/16 at texel centres, mirrored.
-__global__ void pyr_swt0(const float *__restrict__ in, float *__restrict__ out, int w, int h, int vertical) {
+__global__ void pyr_swt0(const float *__restrict__ in, float *__restrict__ out, long in_stride, long out_stride, int w,
+                         int h, int vertical) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
+    in += blockIdx.z * in_stride;
+    out += blockIdx.z * out_stride;
     const float k0 = 6.f / 16.f, k1 = 4.f / 16.f, k2 = 1.f / 16.f;
     float s;
     if (!vertical) {
@@ -688,9 +695,12 @@ __global__ void pyr_swt0(const float *__restrict__ in, float *__restrict__ out, 
 }
 
 // Nearest blit [0,w)x[0,h) -> [0,w/2)x[0,h/2): patch_pyramid.rs:251-285.
-__global__ void pyr_decimate(const float *__restrict__ in, float *__restrict__ out, int w, int h, int ow, int oh) {
+__global__ void pyr_decimate(const float *__restrict__ in, float *__restrict__ out, long in_stride, long out_stride,
+                             int w, int h, int ow, int oh) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= ow || y >= oh) return;
+    in += blockIdx.z * in_stride;
+    out += blockIdx.z * out_stride;
     int sx = (int)floorf(((float)x + 0.5f) * (float)w / (float)(w / 2));
     int sy = (int)floorf(((float)y + 0.5f) * (float)h / (float)(h / 2));
     sx = sx > w - 1 ? w - 1 : sx;
@@ -699,21 +709,27 @@ __global__ void pyr_decimate(const float *__restrict__ in, float *__restrict__ o
 }
 
 // blur_pyramid.glsl:36-49 vertical pass: binomial taps centred on texel (2x, 2y) of the H result.
-__global__ void pyr_down_v(const float *__restrict__ in, float *__restrict__ out, int w, int h, int ow, int oh) {
+__global__ void pyr_down_v(const float *__restrict__ in, float *__restrict__ out, long in_stride, long out_stride,
+                           int w, int h, int ow, int oh) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= ow || y >= oh) return;
+    in += blockIdx.z * in_stride;
+    out += blockIdx.z * out_stride;
     const float cx = 2.f * (float)x + 0.5f, cy = 2.f * (float)y + 0.5f;
     float s = tex_bilinear(in, w, h, cx, cy) * 0.375f;
     s += (tex_bilinear(in, w, h, cx, cy - 1.2f) + tex_bilinear(in, w, h, cx, cy + 1.2f)) * 0.3125f;
     out[(size_t)y * ow + x] = s;
 }
 
-// patch_gradients.glsl:42-70.  One 1024-thread block per keypoint; thread = patch pixel.
-__global__ __launch_bounds__(1024) void sample_patches(const float *__restrict__ pyr, PyramidDesc pd,
-                                                       const float *__restrict__ kps /*[n][5]*/, long n,
-                                                       float psf, float *__restrict__ patches) {
+// patch_gradients.glsl:42-70.  One 1024-thread block per keypoint; thread = patch pixel.  frame_of_kp (optional)
+// selects the keypoint's pyramid among the frames of the batch (pyr_stride floats apart).
+__global__ __launch_bounds__(1024) void sample_patches(const float *__restrict__ pyr, long pyr_stride, PyramidDesc pd,
+                                                       const float *__restrict__ kps /*[n][5]*/,
+                                                       const unsigned *__restrict__ frame_of_kp, long n, float psf,
+                                                       float *__restrict__ patches) {
     const long k = blockIdx.x;
     if (k >= n) return;
+    if (frame_of_kp) pyr += (long)frame_of_kp[k] * pyr_stride;
     const float *kp = kps + k * 5;
     const float scale = kp[2] * psf / 32.f;
     const float l2 = log2f(scale);
@@ -757,35 +773,40 @@ void launch_describe(const float *patches, long n, const DeviceConsts &dc, int a
 #undef LF_LAUNCH
 }
 
-void launch_sample_patches(const float *pyr, const PyramidDesc &pd, const float *kps, long n, float psf,
-                           float *patches, hipStream_t stream) {
+void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
+                           const unsigned *frame_of_kp, long n, float psf, float *patches, hipStream_t stream) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(sample_patches, dim3((unsigned)n), dim3(1024), 0, stream, pyr, pd, kps, n, psf, patches);
+    hipLaunchKernelGGL(sample_patches, dim3((unsigned)n), dim3(1024), 0, stream, pyr, pyr_stride, pd, kps, frame_of_kp, n,
+                       psf, patches);
 }
 
-void launch_build_pyramid(const float *image, float *pyr, float *tmp_a, float *tmp_b, const PyramidDesc &pd,
-                          hipStream_t stream) {
+// Builds the pyramids of `frames` frames (image_stride floats apart) into pyr (pyr_stride apart); tmp_a and tmp_b
+// hold frames x w x h floats each.
+void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,
+                          float *tmp_b, const PyramidDesc &pd, int frames, hipStream_t stream) {
     const int w = pd.w[0], h = pd.h[0];
+    const long ts = (long)w * h;
     const dim3 blk(32, 8);
-    auto grid = [&](int gw, int gh) { return dim3((gw + 31) / 32, (gh + 7) / 8); };
+    auto grid = [&](int gw, int gh) { return dim3((gw + 31) / 32, (gh + 7) / 8, frames); };
     // level 0: sigma-0.6 blur, H then V (tasks_detect.rs:150-161, mod.rs:1043-1067)
-    hipLaunchKernelGGL(pyr_sep3, grid(w, h), blk, 0, stream, image, tmp_a, w, h, 0.66381836f, 0.16809084f,
-                       1.015267163f, 0);
-    hipLaunchKernelGGL(pyr_sep3, grid(w, h), blk, 0, stream, (const float *)tmp_a, pyr + pd.offset[0], w, h,
-                       0.66381836f, 0.16809084f, 1.015267163f, 1);
+    hipLaunchKernelGGL(pyr_sep3, grid(w, h), blk, 0, stream, image, tmp_a, image_stride, ts, w, h, 0.66381836f,
+                       0.16809084f, 1.015267163f, 0);
+    hipLaunchKernelGGL(pyr_sep3, grid(w, h), blk, 0, stream, (const float *)tmp_a, pyr + pd.offset[0], ts, pyr_stride, w,
+                       h, 0.66381836f, 0.16809084f, 1.015267163f, 1);
     if (pd.levels < 2) return;
     // level 1: one a-trous pass over level 0, nearest-decimated
-    hipLaunchKernelGGL(pyr_swt0, grid(w, h), blk, 0, stream, (const float *)(pyr + pd.offset[0]), tmp_a, w, h, 0);
-    hipLaunchKernelGGL(pyr_swt0, grid(w, h), blk, 0, stream, (const float *)tmp_a, tmp_b, w, h, 1);
-    hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)tmp_b,
-                       pyr + pd.offset[1], w, h, pd.w[1], pd.h[1]);
+    hipLaunchKernelGGL(pyr_swt0, grid(w, h), blk, 0, stream, (const float *)(pyr + pd.offset[0]), tmp_a, pyr_stride, ts,
+                       w, h, 0);
+    hipLaunchKernelGGL(pyr_swt0, grid(w, h), blk, 0, stream, (const float *)tmp_a, tmp_b, ts, ts, w, h, 1);
+    hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)tmp_b, pyr + pd.offset[1],
+                       ts, pyr_stride, w, h, pd.w[1], pd.h[1]);
     // levels >= 2: binomial H at the resolution of level l-1, then V with 2x decimation
     for (int l = 2; l < pd.levels; ++l) {
         const int pw = pd.w[l - 1], ph = pd.h[l - 1];
         hipLaunchKernelGGL(pyr_sep3, grid(pw, ph), blk, 0, stream, (const float *)(pyr + pd.offset[l - 1]), tmp_a,
-                           pw, ph, 0.375f, 0.3125f, 1.2f, 0);
-        hipLaunchKernelGGL(pyr_down_v, grid(pd.w[l], pd.h[l]), blk, 0, stream, (const float *)tmp_a,
-                           pyr + pd.offset[l], pw, ph, pd.w[l], pd.h[l]);
+                           pyr_stride, ts, pw, ph, 0.375f, 0.3125f, 1.2f, 0);
+        hipLaunchKernelGGL(pyr_down_v, grid(pd.w[l], pd.h[l]), blk, 0, stream, (const float *)tmp_a, pyr + pd.offset[l],
+                           ts, pyr_stride, pw, ph, pd.w[l], pd.h[l]);
     }
 }
 

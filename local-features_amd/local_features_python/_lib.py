@@ -19,7 +19,8 @@ PCA_NAMES = ("liberty", "notredame", "yosemite")   # enum MKDPCA, lib.rs:26-32
 SYMBOLS = (
     "lf_mkd_create", "lf_mkd_create_from_file", "lf_mkd_destroy", "lf_mkd_last_error",
     "lf_mkd_describe_patches", "lf_mkd_describe_patches_device", "lf_mkd_raw_descriptors_device",
-    "lf_mkd_set_image", "lf_mkd_set_image_device", "lf_mkd_describe_keypoints",
+    "lf_mkd_set_image", "lf_mkd_set_image_device", "lf_mkd_set_images_device", "lf_mkd_describe_keypoints",
+    "lf_mkd_describe_keypoints_frames_device",
     "lf_mkd_describe_keypoints_device", "lf_mkd_sample_patches_device", "lf_mkd_get_pyramid_level",
     "lf_mkd_build_constants", "lf_mkd_kernel_times", "lf_mkd_synchronize", "lf_mkd_version",
 )
@@ -30,7 +31,7 @@ class Params(ctypes.Structure):
         ("max_image_width", ctypes.c_uint32), ("max_image_height", ctypes.c_uint32),
         ("max_features", ctypes.c_uint32), ("patch_scale_factor", ctypes.c_float),
         ("device", ctypes.c_int32), ("angle_mode", ctypes.c_int32), ("pool_mode", ctypes.c_int32),
-        ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 4),
+        ("flags", ctypes.c_uint32), ("max_frames", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 3),
     ]
 
 
@@ -75,6 +76,8 @@ def load_library():
     L.lf_mkd_raw_descriptors_device.argtypes = [vp, vp, u64, vp, vp]
     L.lf_mkd_set_image.argtypes = [vp, vp, u32, u32]
     L.lf_mkd_set_image_device.argtypes = [vp, vp, u32, u32, vp]
+    L.lf_mkd_set_images_device.argtypes = [vp, vp, u32, u32, u32, vp]
+    L.lf_mkd_describe_keypoints_frames_device.argtypes = [vp, vp, vp, u64, vp, vp]
     L.lf_mkd_describe_keypoints.argtypes = [vp, vp, u64, vp]
     L.lf_mkd_describe_keypoints_device.argtypes = [vp, vp, u64, vp, vp]
     L.lf_mkd_sample_patches_device.argtypes = [vp, vp, u64, vp, vp]
@@ -92,12 +95,14 @@ class MkdHandle:
     pointers (ints), e.g. torch.Tensor.data_ptr()."""
 
     def __init__(self, pca="liberty", max_features=2000, max_image_width=0, max_image_height=0,
-                 patch_scale_factor=24.0, device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_F32, flags=0):
+                 patch_scale_factor=24.0, device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_F32, flags=0,
+                 max_frames=1):
         self._h = None
         self.L = load_library()
         p = Params(max_image_width=max_image_width, max_image_height=max_image_height,
                    max_features=max_features, patch_scale_factor=patch_scale_factor,
-                   device=device, angle_mode=angle_mode, pool_mode=pool_mode, flags=flags)
+                   device=device, angle_mode=angle_mode, pool_mode=pool_mode, flags=flags,
+                   max_frames=max_frames)
         h = ctypes.c_void_p()
         rc = self.L.lf_mkd_create_from_file(ctypes.byref(p), model_path(pca).encode(), ctypes.byref(h))
         if rc != 0:
@@ -161,6 +166,14 @@ class MkdHandle:
     def set_image_device(self, d_image, width, height, stream=None):
         self._check(self.L.lf_mkd_set_image_device(self._h, d_image, width, height, stream),
                     "lf_mkd_set_image_device")
+
+    def set_images_device(self, d_images, n_frames, width, height, stream=None):
+        self._check(self.L.lf_mkd_set_images_device(self._h, d_images, n_frames, width, height, stream),
+                    "lf_mkd_set_images_device")
+
+    def describe_keypoints_frames_device(self, d_kps, d_frame_of_kp, n, d_out, stream=None):
+        self._check(self.L.lf_mkd_describe_keypoints_frames_device(self._h, d_kps, d_frame_of_kp, n, d_out, stream),
+                    "lf_mkd_describe_keypoints_frames_device")
 
     def describe_keypoints_device(self, d_kps, n, d_out, stream=None):
         self._check(self.L.lf_mkd_describe_keypoints_device(self._h, d_kps, n, d_out, stream),

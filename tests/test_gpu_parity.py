@@ -186,3 +186,38 @@ def test_f16x3_pooling_agrees_with_f32_at_full_size_and_is_deterministic(lfp, to
         d = outs[(angle, lfp.POOL_F16X3)] - outs[(angle, lfp.POOL_F32)]
         e = d.norm(dim=1) / outs[(angle, lfp.POOL_F32)].norm(dim=1)
         assert e.max().item() < 2e-5, (angle, e.max().item())
+
+
+def test_multi_frame_entry_points_match_single_frame_and_oracle(lfp, torch, oracle):
+    """configs[2]-style batch: several frames of one size, keypoints tagged with their frame."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_golden import random_keypoints, smooth_image
+    w, hgt, nf = 160, 120, 3
+    frames = np.ascontiguousarray(np.stack([smooth_image(hgt, w, 40 + f) for f in range(nf)]))   # device API: contiguous
+    counts = [37, 0, 90]
+    kps = [np.concatenate([random_keypoints(c, w, hgt, 50 + f), np.zeros((c, 1), np.float32)], axis=1)
+           for f, c in enumerate(counts)]
+    allk = np.concatenate(kps).astype(np.float32)
+    fid = np.concatenate([np.full(c, f, np.uint32) for f, c in enumerate(counts)])
+    n = len(allk)
+    h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt, max_frames=nf)
+    d_frames = torch.from_numpy(frames).cuda().contiguous()
+    d_k, d_f = torch.from_numpy(allk).cuda(), torch.from_numpy(fid.astype(np.int32)).cuda()
+    out = torch.empty((n, 128), device="cuda")
+    h.set_images_device(d_frames.data_ptr(), nf, w, hgt)
+    h.describe_keypoints_frames_device(d_k.data_ptr(), d_f.data_ptr(), n, out.data_ptr())
+    h.synchronize()
+    got = out.cpu().numpy()
+    single = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt)
+    ref_parts, one_parts = [], []
+    for f in range(nf):
+        if counts[f] == 0:
+            continue
+        single.set_image(frames[f])
+        one_parts.append(single.describe_keypoints(kps[f]))
+        ref_parts.append(oracle.describe_keypoints(frames[f], kps[f][:, :4]))
+    assert np.array_equal(got, np.concatenate(one_parts))
+    assert rel_l2(got, np.concatenate(ref_parts)).max() < GATE
+    with pytest.raises(RuntimeError, match="max_frames"):
+        single.set_images_device(d_frames.data_ptr(), nf, w, hgt)

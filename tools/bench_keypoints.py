@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Keypoint-mode timings for BASELINE.json configs[1] (10k keypoints, one 1920x1080 frame) and configs[2]
+(256 frames of 640x480, 2k keypoints each).  Development aid; bench.py is the contract."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "local-features_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np, torch
+import local_features_python as lfp
+from gen_golden import random_keypoints
+
+
+def frame(h, w, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.rand((1, 1, h, w), device="cuda", generator=g)
+    k = torch.exp(-0.5 * (torch.arange(-6, 7, device="cuda") / 2.0) ** 2); k /= k.sum()
+    x = torch.nn.functional.conv2d(x, k.view(1, 1, 1, -1), padding=(0, 6))
+    x = torch.nn.functional.conv2d(x, k.view(1, 1, -1, 1), padding=(6, 0))
+    x = (x - x.min()) / (x.max() - x.min())
+    return x[0, 0].contiguous()
+
+
+def run(w, h, nk, frames, tag):
+    hnd = lfp.MkdHandle(max_features=max(nk, 64), max_image_width=w, max_image_height=h, pool_mode=lfp.POOL_F16X3)
+    s = torch.cuda.current_stream().cuda_stream
+    imgs = [frame(h, w, 100 + f) for f in range(min(frames, 8))]
+    kps = [torch.from_numpy(np.concatenate([random_keypoints(nk, w, h, 200 + f, margin=64.0 if min(w, h) > 200 else 8.0),
+                                            np.zeros((nk, 1), np.float32)], axis=1)).cuda() for f in range(min(frames, 8))]
+    out = torch.empty((nk, 128), device="cuda")
+    def one(f):
+        hnd.set_image_device(imgs[f % len(imgs)].data_ptr(), w, h, s)
+        hnd.describe_keypoints_device(kps[f % len(kps)].data_ptr(), nk, out.data_ptr(), s)
+    for f in range(3): one(f)
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t0 = time.perf_counter()
+    pyr_ms = desc_ms = 0.0
+    for f in range(frames):
+        e[0].record(); hnd.set_image_device(imgs[f % len(imgs)].data_ptr(), w, h, s)
+        e[1].record(); hnd.describe_keypoints_device(kps[f % len(kps)].data_ptr(), nk, out.data_ptr(), s)
+        e[2].record()
+        if f < 16:
+            torch.cuda.synchronize(); pyr_ms += e[0].elapsed_time(e[1]); desc_ms += e[1].elapsed_time(e[2])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    m = min(frames, 16)
+    print(f"{tag}: {frames} frames {w}x{h}, {nk} kpts/frame: {dt/frames*1e3:.3f} ms/frame  {frames*nk/dt/1e6:.2f} M desc/s  "
+          f"(pyramid {pyr_ms/m:.3f} ms, sample+describe {desc_ms/m:.3f} ms per frame)", flush=True)
+
+
+def run_batched(w, h, nk, frames, tag):
+    """all frames in one set_images + one describe_keypoints_frames call"""
+    n = nk * frames
+    hnd = lfp.MkdHandle(max_features=n, max_image_width=w, max_image_height=h, pool_mode=lfp.POOL_F16X3, max_frames=frames)
+    s = torch.cuda.current_stream().cuda_stream
+    imgs = torch.stack([frame(h, w, 100 + (f % 8)) for f in range(frames)]).contiguous()
+    base = [np.concatenate([random_keypoints(nk, w, h, 200 + f, margin=8.0), np.zeros((nk, 1), np.float32)], axis=1) for f in range(8)]
+    kps = torch.from_numpy(np.concatenate([base[f % 8] for f in range(frames)]).astype(np.float32)).cuda()
+    fid = torch.arange(frames, device="cuda", dtype=torch.int32).repeat_interleave(nk).contiguous()
+    out = torch.empty((n, 128), device="cuda")
+    def one():
+        hnd.set_images_device(imgs.data_ptr(), frames, w, h, s)
+        hnd.describe_keypoints_frames_device(kps.data_ptr(), fid.data_ptr(), n, out.data_ptr(), s)
+    one(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); it = 5
+    for _ in range(it): one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / it
+    print(f"{tag}: {frames} frames {w}x{h} x {nk} kpts in ONE batch: {dt*1e3:.3f} ms  {n/dt/1e6:.1f} M desc/s", flush=True)
+
+
+run(1920, 1080, 10000, 50, "configs[1]")
+run_batched(640, 480, 2000, 256, "configs[2] batched")
+run(640, 480, 2000, 256, "configs[2]")
+run(3840, 2160, 8000, 30, "configs[4] (describe part)")
