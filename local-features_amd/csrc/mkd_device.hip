@@ -629,11 +629,15 @@ __global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patche
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+// MirroredRepeat: t = i mod 2n, index = min(t, 2n-1-t).  Branch-free, float reciprocal instead of an integer
+// division (|i| stays far below 2^23, so the float arithmetic is exact up to the +-1 fix-ups).
 __device__ __forceinline__ int mirror_idx(int i, int n) {
     const int pp = 2 * n;
-    int m = i % pp;
-    if (m < 0) m += pp;
-    return m < n ? m : pp - 1 - m;
+    const float q = floorf((float)i * (1.f / (float)pp));
+    int t = i - (int)q * pp;
+    t = t < 0 ? t + pp : t;
+    t = t >= pp ? t - pp : t;
+    return t < n ? t : pp - 1 - t;
 }
 
 __device__ __forceinline__ float tex_bilinear(const float *__restrict__ img, int w, int h, float u, float v) {
@@ -642,8 +646,9 @@ __device__ __forceinline__ float tex_bilinear(const float *__restrict__ img, int
     const float ax = fu - x0f, ay = fv - y0f;
     const int x0 = mirror_idx((int)x0f, w), x1 = mirror_idx((int)x0f + 1, w);
     const int y0 = mirror_idx((int)y0f, h), y1 = mirror_idx((int)y0f + 1, h);
-    const float t00 = img[(size_t)y0 * w + x0], t10 = img[(size_t)y0 * w + x1];
-    const float t01 = img[(size_t)y1 * w + x0], t11 = img[(size_t)y1 * w + x1];
+    const float *r0 = img + y0 * w, *r1 = img + y1 * w;   // a level holds < 2^31 texels
+    const float t00 = r0[x0], t10 = r0[x1];
+    const float t01 = r1[x0], t11 = r1[x1];
     const float top = t00 * (1.f - ax) + t10 * ax;
     const float bot = t01 * (1.f - ax) + t11 * ax;
     return top * (1.f - ay) + bot * ay;
@@ -721,14 +726,17 @@ __global__ void pyr_down_v(const float *__restrict__ in, float *__restrict__ out
     out[(size_t)y * ow + x] = s;
 }
 
-// patch_gradients.glsl:42-70.  One 1024-thread block per keypoint; thread = patch pixel.  frame_of_kp (optional)
-// selects the keypoint's pyramid among the frames of the batch (pyr_stride floats apart).
-__global__ __launch_bounds__(1024) void sample_patches(const float *__restrict__ pyr, long pyr_stride, PyramidDesc pd,
-                                                       const float *__restrict__ kps /*[n][5]*/,
-                                                       const unsigned *__restrict__ frame_of_kp, long n, float psf,
-                                                       float *__restrict__ patches) {
-    const long k = blockIdx.x;
+// patch_gradients.glsl:42-70.  One wave per keypoint (4 per block): the per-keypoint scale/level/rotation math is
+// done once per wave instruction, each lane then samples 16 pixels (two patch rows per step, so every store
+// instruction writes 256 contiguous bytes).  frame_of_kp (optional) selects the keypoint's pyramid among the
+// frames of the batch (pyr_stride floats apart).
+__global__ __launch_bounds__(256) void sample_patches(const float *__restrict__ pyr, long pyr_stride, PyramidDesc pd,
+                                                      const float *__restrict__ kps /*[n][5]*/,
+                                                      const unsigned *__restrict__ frame_of_kp, long n, float psf,
+                                                      float *__restrict__ patches) {
+    const long k = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= n) return;
+    const int lane = threadIdx.x & 63;
     if (frame_of_kp) pyr += (long)frame_of_kp[k] * pyr_stride;
     const float *kp = kps + k * 5;
     const float scale = kp[2] * psf / 32.f;
@@ -740,11 +748,19 @@ __global__ __launch_bounds__(1024) void sample_patches(const float *__restrict__
     const float ang = kp[3] * (3.14159265358979323846f / 180.f);
     const float ca = cosf(ang), sa = sinf(ang);
     const float inv = 1.f / exp2f(lvl);
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const float dx = (float)lx - 16.f, dy = (float)ly - 16.f;
-    const float xx = dx * ca - dy * sa, yy = dx * sa + dy * ca;
-    const float sx = xx * rem + kp[0] * inv, sy = yy * rem + kp[1] * inv;
-    patches[k * 1024 + threadIdx.x] = tex_bilinear(pyr + pd.offset[l], pd.w[l], pd.h[l], sx + 0.5f, sy + 0.5f);
+    const float *img = pyr + pd.offset[l];
+    const int w = pd.w[l], h = pd.h[l];
+    const int lx = lane & 31;
+    const float dx = (float)lx - 16.f;
+    float *dst = patches + k * 1024 + lane;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int ly = 2 * i + (lane >> 5);
+        const float dy = (float)ly - 16.f;
+        const float xx = dx * ca - dy * sa, yy = dx * sa + dy * ca;
+        const float sx = xx * rem + kp[0] * inv, sy = yy * rem + kp[1] * inv;
+        dst[i * 64] = tex_bilinear(img, w, h, sx + 0.5f, sy + 0.5f);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -776,8 +792,8 @@ void launch_describe(const float *patches, long n, const DeviceConsts &dc, int a
 void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                            const unsigned *frame_of_kp, long n, float psf, float *patches, hipStream_t stream) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(sample_patches, dim3((unsigned)n), dim3(1024), 0, stream, pyr, pyr_stride, pd, kps, frame_of_kp, n,
-                       psf, patches);
+    hipLaunchKernelGGL(sample_patches, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, pyr, pyr_stride, pd, kps,
+                       frame_of_kp, n, psf, patches);
 }
 
 // Builds the pyramids of `frames` frames (image_stride floats apart) into pyr (pyr_stride apart); tmp_a and tmp_b
