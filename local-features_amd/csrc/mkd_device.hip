@@ -109,18 +109,24 @@ __device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 &ct
         cs = pk_fma(p2, cs, pk_set(4.1666667e-2f));
         cs = pk_fma(p2, cs, pk_set(-0.5f));
         cs = pk_fma(p2, cs, pk_set(1.f));
-        const f32x2 sa = {a.x > 0.f ? 1.f : -1.f, a.y > 0.f ? 1.f : -1.f};
-        const f32x2 ssn = sa * sn, scs = sa * cs;
-        float cr0 = sw0 ? ssn.x : cs.x, sr0 = sw0 ? scs.x : sn.x;
-        float cr1 = sw1 ? ssn.y : cs.y, sr1 = sw1 ? scs.y : sn.y;
-        if (sw0 && a.x == 0.f) { cr0 = 1.f; sr0 = 0.f; }  // the atan2(0, y != 0) == 0 quirk
-        if (sw1 && a.y == 0.f) { cr1 = 1.f; sr1 = 0.f; }
-        if (gx.x < 0.f) { cr0 = -cr0; sr0 = -sr0; }
-        if (gx.y < 0.f) { cr1 = -cr1; sr1 = -sr1; }
-        if (gx.x == 0.f && gy.x == 0.f) { cr0 = 1.f; sr0 = 0.f; }
-        if (gx.y == 0.f && gy.y == 0.f) { cr1 = 1.f; sr1 = 0.f; }
-        ct = f32x2{cr0, cr1};   // theta = -res
-        st = f32x2{-sr0, -sr1};
+        // sign(a) (sin p, cos p) for the swapped octants: flip the sign bits where a < 0.  (a == 0 needs no care: it
+        // only matters together with swap, i.e. gx == 0, which the last line overrides.)
+        const unsigned na0 = __float_as_uint(a.x) & 0x80000000u, na1 = __float_as_uint(a.y) & 0x80000000u;
+        float cr0 = sw0 ? __uint_as_float(__float_as_uint(sn.x) ^ na0) : cs.x;
+        float sr0 = sw0 ? __uint_as_float(__float_as_uint(cs.x) ^ na0) : sn.x;
+        float cr1 = sw1 ? __uint_as_float(__float_as_uint(sn.y) ^ na1) : cs.y;
+        float sr1 = sw1 ? __uint_as_float(__float_as_uint(cs.y) ^ na1) : sn.y;
+        // x < 0: res +- pi negates both; theta = -res negates the sine once more
+        const unsigned nx0 = __float_as_uint(gx.x) & 0x80000000u, nx1 = __float_as_uint(gx.y) & 0x80000000u;
+        cr0 = __uint_as_float(__float_as_uint(cr0) ^ nx0);
+        cr1 = __uint_as_float(__float_as_uint(cr1) ^ nx1);
+        sr0 = __uint_as_float(__float_as_uint(sr0) ^ nx0 ^ 0x80000000u);
+        sr1 = __uint_as_float(__float_as_uint(sr1) ^ nx1 ^ 0x80000000u);
+        // gx == 0: the shader returns 0 both for atan2(0, 0) and (its quirk) for atan2(0, y != 0)
+        if (gx.x == 0.f) { cr0 = 1.f; sr0 = 0.f; }
+        if (gx.y == 0.f) { cr1 = 1.f; sr1 = 0.f; }
+        ct = f32x2{cr0, cr1};
+        st = f32x2{sr0, sr1};
     }
 }
 
