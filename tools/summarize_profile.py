@@ -13,11 +13,15 @@ for l in open(os.path.join(src, "stats.log")):
         bench = json.loads(l)
 stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 kern_ms = None
+# the timed kernel variant: mkd_pool<ANGLE, POOL>; bench.py also runs the exact-angle variant once as a
+# secondary figure, which must not be mixed into the headline kernel's numbers
+variant = "mkd_pool<%d, %d>" % (0 if (not bench or bench["config"]["angle_mode"] == "shader") else 1,
+                                1 if (not bench or bench["config"]["pool_mode"] == "f16x3") else 0)
 if stats:
     lines += ["## `--kernel-trace --stats` (kernel_stats.csv)", "", "| kernel | calls | avg ms | min ms | max ms | % |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(stats[0])):
         lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.4f} | {float(r['MinNs'])/1e6:.4f} | {float(r['MaxNs'])/1e6:.4f} | {r['Percentage']} |")
-        if "mkd_pool" in r["Name"]:
+        if variant in r["Name"]:
             kern_ms = float(r["AverageNs"]) / 1e6
     lines.append("")
 def pmc(sub):
@@ -25,7 +29,7 @@ def pmc(sub):
     agg = collections.defaultdict(list)
     if f:
         for r in csv.DictReader(open(f[0])):
-            if "mkd_pool" in r["Kernel_Name"]:
+            if variant in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 fetch, write = pmc("fetch"), pmc("write")
@@ -38,7 +42,7 @@ if fetch and write:
     fb = fetch["FETCH_SIZE"] * 1024 * 2
     wb = write["WRITE_SIZE"] * 1024
     traffic = fb + wb
-    lines += ["## HBM traffic of `mkd_pool` per launch (separate `--pmc` passes)", "",
+    lines += [f"## HBM traffic of `{variant}` per launch (separate `--pmc` passes)", "",
               f"- FETCH_SIZE = {fetch['FETCH_SIZE']:.0f} KiB -> x1024 x2 (gfx950 wide-read correction) = {fb/1e9:.3f} GB",
               f"- WRITE_SIZE = {write['WRITE_SIZE']:.0f} KiB -> x1024 = {wb/1e9:.3f} GB",
               f"- total {traffic/1e9:.3f} GB per launch; algorithmic {4608*n/1e9:.3f} GB ({n} descriptors x 4608 B) "
@@ -49,7 +53,7 @@ if fetch and write:
               open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
 sq = {**pmc("sq"), **pmc("sq2")}
 if sq:
-    lines += ["## SQ counters of `mkd_pool` per launch", "", "| counter | value |", "|---|---|"]
+    lines += [f"## SQ counters of `{variant}` per launch", "", "| counter | value |", "|---|---|"]
     lines += [f"| {k} | {v:.4g} |" for k, v in sorted(sq.items())]
     if "SQ_WAVE_CYCLES" in sq:
         w = sq["SQ_WAVE_CYCLES"]
