@@ -221,3 +221,77 @@ def test_multi_frame_entry_points_match_single_frame_and_oracle(lfp, torch, orac
     assert rel_l2(got, np.concatenate(ref_parts)).max() < GATE
     with pytest.raises(RuntimeError, match="max_frames"):
         single.set_images_device(d_frames.data_ptr(), nf, w, hgt)
+
+
+def test_keypoint_edge_cases_vs_oracle(lfp, oracle):
+    """Keypoints whose sampling window leaves the image (MirroredRepeat), the smallest and largest sizes
+    the detector emits, sizes below and above the pyramid range (level clamp), angles 0 / 360 / negative."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_golden import smooth_image
+    w, hgt = 640, 480     # large enough that the coarse levels still carry structure (a 6x4-texel level
+    img = smooth_image(hgt, w, 9)   # gives near-flat patches whose descriptors are rounding noise in any f32 code)
+    kps = np.array([
+        [0.0, 0.0, 4.0, 0.0],          # corner: three quarters of the window mirrored
+        [639.0, 479.0, 10.0, 45.0],    # opposite corner, rotated
+        [320.0, 2.0, 30.0, 200.0],     # top edge, coarse level
+        [3.5, 70.25, 1.64, 359.99],    # smallest detector size
+        [320.0, 240.0, 52.0, 360.0],   # largest detector size, angle == 360
+        [50.0, 50.0, 0.5, 10.0],       # below the pyramid range: level clamped to 0
+        [150.0, 90.0, 160.0, -30.0],   # above the detector's range, negative angle
+        [10.0, 400.0, 2.6667, 90.0],   # scale exactly 2.0 -> level boundary
+    ], np.float32)
+    k5 = np.concatenate([kps, np.zeros((len(kps), 1), np.float32)], axis=1)
+    h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt)
+    h.set_image(img)
+    d = h.describe_keypoints(k5)
+    ref = oracle.describe_keypoints(img, kps)
+    assert np.all(np.isfinite(d))
+    assert rel_l2(d, ref).max() < GATE
+
+
+def test_non_square_and_odd_sized_frames(lfp, oracle):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_golden import random_keypoints, smooth_image
+    for (w, hgt) in ((799, 533), (65, 301)):       # bird.jpg's size; a tall odd frame
+        img = smooth_image(hgt, w, w)
+        kps = random_keypoints(40, w, hgt, hgt)
+        k5 = np.concatenate([kps, np.zeros((len(kps), 1), np.float32)], axis=1)
+        h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt)
+        h.set_image(img)
+        # pyramid levels of odd sizes: floor halving, as patch_pyramid.rs:179-180
+        pyr = oracle.split_pyramid(oracle.build_pyramid(img), w, hgt)
+        for l in (1, 2, 4):
+            assert np.abs(h.pyramid_level(l) - pyr[l]).max() < 2e-6
+        assert rel_l2(h.describe_keypoints(k5), oracle.describe_keypoints(img, kps)).max() < GATE
+
+
+def test_smaller_image_than_max_and_reuse_of_a_handle(lfp, oracle):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_golden import random_keypoints, smooth_image
+    h = lfp.MkdHandle(max_features=64, max_image_width=320, max_image_height=240)
+    for (w, hgt, seed) in ((320, 240, 1), (160, 120, 2), (320, 240, 3)):   # image < max: mirror at the content edge
+        img = smooth_image(hgt, w, seed)
+        kps = random_keypoints(30, w, hgt, seed + 10)
+        k5 = np.concatenate([kps, np.zeros((len(kps), 1), np.float32)], axis=1)
+        h.set_image(img)
+        assert rel_l2(h.describe_keypoints(k5), oracle.describe_keypoints(img, kps)).max() < GATE
+
+
+def test_extreme_patch_values(lfp, oracle):
+    """Patches far outside [0,1], small contrasts, one hot pixel.  (A contrast of 1e-5 on a 0.5 pedestal is below
+    what f32 pixels resolve -- any f32 implementation, the oracle included, returns rounding noise there -- so that
+    case is only checked for finiteness and unit norm.)"""
+    rng = np.random.default_rng(99)
+    base = rng.random((6, 32, 32)).astype(np.float32)
+    p = np.stack([base[0] * 255.0, base[1] * 1e-3, 0.5 + base[2] * 0.02, -base[3], base[4] * 1e4,
+                  np.zeros((32, 32), np.float32), 0.5 + base[5] * 1e-5])
+    p[5, 13, 17] = 1.0
+    for pool in (lfp.POOL_F32, lfp.POOL_F16X3):
+        d = lfp.MkdHandle(max_features=64, pool_mode=pool).describe_patches(p)
+        ref = oracle.describe_patches(p)
+        assert np.all(np.isfinite(d))
+        assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-5)
+        assert rel_l2(d[:6], ref[:6]).max() < GATE, (pool, rel_l2(d, ref))
