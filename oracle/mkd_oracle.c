@@ -604,3 +604,134 @@ void mkd_oracle_sample_patches(const float *pyr, int w, int h, const float *kps 
 }
 
 unsigned long mkd_oracle_sizeof_consts(void) { return sizeof(mkd_consts); }
+
+/* ------------------------------------------------------------------------- */
+/* Keypoint orientation: shaders/keypoint_orientation.glsl */
+/* ------------------------------------------------------------------------- */
+
+/* Coarse stack: layer 0 = sigma-0.6 blur of the input (shaders/blur.glsl), layer l+1 = B3-spline a-trous
+ * pass with dilation 2^l over layer l (shaders/swt.glsl:24-58, H then V; vulkan/mod.rs:1093-1130).
+ * stack: [n_layers][h][w]. */
+void mkd_oracle_build_coarse_stack(const float *img, int w, int h, int n_layers, float *stack)
+{
+    float *tmp = (float *)malloc(sizeof(float) * w * h);
+    blur_sigma06(img, w, h, tmp, stack);
+    const float K0 = 6.f / 16.f, K1 = 4.f / 16.f, K2 = 1.f / 16.f;
+    for (int l = 0; l + 1 < n_layers; l++) {
+        const float *in = stack + (long)l * w * h;
+        float *out = stack + (long)(l + 1) * w * h;
+        const int d = 1 << l;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                float sum = in[y * w + x] * K0;
+                sum += in[y * w + mirror(x - 2 * d, w)] * K2;
+                sum += in[y * w + mirror(x - d, w)] * K1;
+                sum += in[y * w + mirror(x + d, w)] * K1;
+                sum += in[y * w + mirror(x + 2 * d, w)] * K2;
+                tmp[y * w + x] = sum;
+            }
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                float sum = tmp[y * w + x] * K0;
+                sum += tmp[mirror(y - d, h) * w + x] * K1;
+                sum += tmp[mirror(y - 2 * d, h) * w + x] * K2;
+                sum += tmp[mirror(y + 2 * d, h) * w + x] * K2;
+                sum += tmp[mirror(y + d, h) * w + x] * K1;
+                out[y * w + x] = sum;
+            }
+    }
+    free(tmp);
+}
+
+/* One extremum {x, y, size}: angles (degrees, 360 - 10*bin) of every histogram peak >= 0.8 max, in ascending
+ * bin order.  Returns the number of angles written (<= max_out).  keypoint_orientation.glsl:36-171.
+ * Out-of-image loads return 0 (the shader's valid_px admits y == height; robust image access yields 0). */
+int mkd_oracle_orient_one(const float *stack, int w, int h, int n_layers, const float *ex, float *angles,
+                          int max_out)
+{
+    const float SIGMA_RADIUS = sqrtf(2.0f), FIRST = 0.82f, PI_F = 3.1415927f;
+    const int R = 7, PS15 = 15, NB = 36;
+    const int kx = (int)ex[0], ky = (int)ex[1];
+    const float size = ex[2];
+    int level = (int)roundf(log2f(size / (FIRST * SIGMA_RADIUS)));
+    if (level < 0) level = 0;
+    if (level > n_layers - 1) level = n_layers - 1;
+    const int step = 1 << level;
+    const int radius = (int)roundf(3.f * 1.5f * size / SIGMA_RADIUS);
+    const float sigma = 1.5f * size / SIGMA_RADIUS;
+    const float *img = stack + (long)level * w * h;
+    float patch[15 * 15], weight[15 * 15];
+    int bins[15 * 15], ingrad[15 * 15];
+    for (int ly = 0; ly < PS15; ly++)
+        for (int lx = 0; lx < PS15; lx++) {
+            const int xd = (lx - R) * step, yd = (ly - R) * step;
+            const int xi = kx + xd, yi = ky + yd;
+            const int valid = 0 <= xi && xi < w && 0 <= yi && yi <= h;
+            ingrad[ly * PS15 + lx] = valid && abs(xd) <= radius && abs(yd) <= radius;
+            patch[ly * PS15 + lx] = (valid && yi < h) ? img[yi * w + xi] : 0.f;
+        }
+    for (int ly = 0; ly < PS15; ly++)
+        for (int lx = 0; lx < PS15; lx++) {
+            const int i = ly * PS15 + lx;
+            bins[i] = NB + 1;
+            weight[i] = 0.f;
+            if (!ingrad[i] || lx == 0 || lx == PS15 - 1 || ly == 0 || ly == PS15 - 1) continue;
+            const float gx = patch[i + 1] - patch[i - 1];
+            const float gy = patch[i - PS15] - patch[i + PS15];
+            if (gx == 0.f && gy == 0.f) continue;
+            const float mag = sqrtf(gx * gx + gy * gy);
+            const float fx = (float)(lx - R) * (float)step, fy = (float)(ly - R) * (float)step;
+            const float dist = fx * fx + fy * fy;
+            weight[i] = expf(-dist / (2.f * sigma * sigma)) * mag;
+            const float ang = mkd_oracle_atan2_shader(gx, gy);
+            const int rb = (int)roundf(ang * ((float)NB / (2.f * PI_F)));
+            bins[i] = rb < 0 ? rb + NB : (rb >= NB ? rb - NB : rb);
+        }
+    float raw[36 + 4] = {0}, hist[36];
+    for (int i = 0; i < PS15 * PS15; i++) /* one thread, row-major: lines 114-124 */
+        if (bins[i] < NB) raw[2 + bins[i]] += weight[i];
+    raw[1] = raw[NB + 1];
+    raw[0] = raw[NB];
+    raw[NB + 2] = raw[2];
+    raw[NB + 3] = raw[3];
+    float mx = 0.f;
+    for (int b = 0; b < NB; b++) {
+        const int rb = b + 2;
+        hist[b] = (raw[rb - 2] + raw[rb + 2]) * (1.0f / 16.0f) + (raw[rb - 1] + raw[rb + 1]) * (4.0f / 16.0f) +
+                  raw[rb] * (6.0f / 16.0f);
+        if (hist[b] > mx) mx = hist[b];
+    }
+    const float thresh = mx * 0.8f;
+    int n = 0;
+    for (int b = 0; b < NB; b++) {
+        const float hv = hist[b], left = hist[b > 0 ? b - 1 : NB - 1], right = hist[(b + 1) % NB];
+        if (left < hv && right < hv && thresh <= hv) {
+            const float interp = (left - right) / (left - 2.f * hv + right);
+            const float rbin = (float)b + interp / 2.0f;
+            const float bin = rbin < 0.f ? rbin + NB : (rbin > NB ? rbin - NB : rbin);
+            if (n < max_out) angles[n] = 360.0f - (360.0f / (float)NB) * bin;
+            n++;
+        }
+    }
+    return n < max_out ? n : max_out;
+}
+
+/* extrema [n][4] (x, y, size, response) -> keypoints [..][5] (x, y, size, angle, response), ordered by
+ * extremum then bin (the reference appends atomically, i.e. in no particular order).  Returns the count. */
+long mkd_oracle_orient(const float *stack, int w, int h, int n_layers, const float *extrema, long n,
+                       float *kps, long max_kps)
+{
+    long m = 0;
+    for (long i = 0; i < n; i++) {
+        float ang[36];
+        const int c = mkd_oracle_orient_one(stack, w, h, n_layers, extrema + 4 * i, ang, 36);
+        for (int j = 0; j < c && m < max_kps; j++, m++) {
+            kps[5 * m + 0] = extrema[4 * i + 0];
+            kps[5 * m + 1] = extrema[4 * i + 1];
+            kps[5 * m + 2] = extrema[4 * i + 2];
+            kps[5 * m + 3] = ang[j];
+            kps[5 * m + 4] = extrema[4 * i + 3];
+        }
+    }
+    return m;
+}

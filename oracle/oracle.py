@@ -50,6 +50,10 @@ class MkdOracle:
             _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_long, ctypes.c_float, _fp]
         L.mkd_oracle_build_pyramid.argtypes = [_fp, ctypes.c_int, ctypes.c_int, _fp]
         L.mkd_oracle_patch_gradients.argtypes = [_fp, _fp, _fp, ctypes.c_int]
+        L.mkd_oracle_build_coarse_stack.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]
+        L.mkd_oracle_orient.restype = ctypes.c_long
+        L.mkd_oracle_orient.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_long, _fp,
+                                        ctypes.c_long]
         self.mean = np.zeros(238, np.float32)
         self.eigvals = np.zeros(238, np.float32)
         self.eigvecs = np.zeros((238, 238), np.float32)
@@ -131,6 +135,22 @@ class MkdOracle:
         self.L.mkd_oracle_sample_patches(_ptr(pyr), w, h, _ptr(k), n, patch_scale_factor,
                                          _ptr(patches))
         return patches
+
+    def build_coarse_stack(self, img, n_scales=4):
+        """[n_scales+3][h][w]: the a-trous stack keypoint orientation reads (vulkan/mod.rs:1093)."""
+        img = _f32(img)
+        h, w = img.shape
+        stack = np.zeros((n_scales + 3, h, w), np.float32)
+        self.L.mkd_oracle_build_coarse_stack(_ptr(img), w, h, n_scales + 3, _ptr(stack))
+        return stack
+
+    def orient(self, stack, extrema):
+        """extrema [n,4] (x, y, size, response) -> keypoints [m,5] (x, y, size, angle_deg, response)."""
+        e = _f32(extrema).reshape(-1, 4)
+        nl, h, w = stack.shape
+        out = np.zeros((36 * max(len(e), 1), 5), np.float32)
+        m = self.L.mkd_oracle_orient(_ptr(stack), w, h, nl, _ptr(e), len(e), _ptr(out), len(out))
+        return out[:m].copy()
 
     def describe_keypoints(self, img, kps, patch_scale_factor=24.0, **kw):
         img = _f32(img)

@@ -113,3 +113,40 @@ def test_threads_agree(oracle):
     rng = np.random.default_rng(5)
     p = rng.random((37, 32, 32)).astype(np.float32)
     assert np.array_equal(oracle.describe_patches(p, nthreads=1), oracle.describe_patches(p, nthreads=4))
+
+
+def test_orientation_matches_float64_goldens(oracle):
+    """Coarse a-trous stack + keypoint orientation (vulkan/mod.rs:1093-1130, keypoint_orientation.glsl)
+    against the separately written float64 restatement (tools/gen_golden.py)."""
+    g = golden("orientation.npz")
+    st = oracle.build_coarse_stack(g["image"])
+    assert st.shape == (7,) + g["image"].shape
+    assert np.abs(st[2] - g["layer2"]).max() < 1e-6
+    assert np.abs(st[5] - g["layer5"]).max() < 1e-6
+    k = oracle.orient(st, g["extrema"])
+    assert k.shape == g["keypoints"].shape                       # same peaks found, same order
+    assert np.array_equal(k[:, [0, 1, 2, 4]], g["keypoints"][:, [0, 1, 2, 4]])
+    d = np.abs(k[:, 3] - g["keypoints"][:, 3])
+    assert np.minimum(d, 360 - d).max() < 1e-3                   # degrees
+
+
+def test_orientation_properties(oracle):
+    """A linear ramp has one gradient direction: the histogram has one peak at that direction, for every size."""
+    h, w = 96, 128
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    for deg in (0.0, 40.0, 90.0, 200.0, 270.0, 310.0):                # bin centres (10 degree bins)
+        t = np.deg2rad(deg)
+        # gx = left... the shader's gradient is (right-left, up-down); its angle is 360 - keypoint angle
+        img = (0.5 + 0.002 * (np.cos(t) * (xx - w / 2) - np.sin(t) * (yy - h / 2))).astype(np.float32)
+        st = np.broadcast_to(img, (7, h, w)).copy()              # bypass the blur: same ramp on every layer
+        ex = np.array([[64.3, 48.7, s, 0.1] for s in (2.5, 5.0, 9.0)], np.float32)
+        k = oracle.orient(st, ex)
+        assert len(k) == 3
+        # atan2.glsl returns 0 when x == 0 (exactly vertical gradient): the reference's quirk, kept
+        want = 0.0 if deg in (90.0, 270.0) else (360.0 - deg) % 360.0
+        d = np.abs(k[:, 3] - want)
+        assert np.minimum(d, 360 - d).max() < 1e-3, (deg, k[:, 3])
+    # flat image: no gradient, no histogram mass -> no peaks (left < hist fails on 0 < 0)
+    assert len(oracle.orient(np.full((7, h, w), 0.3, np.float32), ex)) == 0
+    # empty input
+    assert oracle.orient(st, np.zeros((0, 4), np.float32)).shape == (0, 5)

@@ -180,6 +180,73 @@ def sample(lv, kps, psf=24.0):
     return np.stack(out)
 
 
+# ---------------------------------------------------------------- keypoint orientation
+def coarse_stack(img, n_scales=4):
+    """vulkan/mod.rs:1093-1130: layer 0 = sigma-0.6 blur, layer l+1 = a-trous [1 4 6 4 1]/16 with dilation 2^l."""
+    img = np.asarray(img, np.float64)
+    h, w = img.shape
+    W0, W1, OFF = (float(np.float32(v)) for v in (0.66381836, 0.16809084, 0.015267163))
+    layers = [sep3(img, W0, W1, 1.0 + OFF)]
+    k = np.array([1, 4, 6, 4, 1]) / 16.0
+    for l in range(n_scales + 2):
+        d, a = 1 << l, layers[-1]
+        t = sum(k[i] * a[:, mirror(np.arange(w) + (i - 2) * d, w)] for i in range(5))
+        layers.append(sum(k[i] * t[mirror(np.arange(h) + (i - 2) * d, h), :] for i in range(5)))
+    return np.stack(layers)
+
+
+def orient(stack, extrema):
+    """shaders/keypoint_orientation.glsl:36-171 in float64; returns [m,5] (x, y, size, angle_deg, response)."""
+    nl, h, w = stack.shape
+    out = []
+    for x, y, size, resp in np.asarray(extrema, np.float64):
+        level = int(np.clip(np.floor(np.log2(size / (float(np.float32(0.82)) * np.sqrt(2.0))) + 0.5), 0, nl - 1))
+        step = 1 << level
+        radius = int(np.floor(3 * 1.5 * size / np.sqrt(2.0) + 0.5))
+        sigma = 1.5 * size / np.sqrt(2.0)
+        kx, ky = int(x), int(y)
+        off = (np.arange(15) - 7) * step
+        xi, yi = kx + off[None, :], ky + off[:, None]
+        valid = (xi >= 0) & (xi < w) & (yi >= 0) & (yi <= h)
+        patch = np.where(valid & (yi < h), stack[level][np.clip(yi, 0, h - 1), np.clip(xi, 0, w - 1)], 0.0)
+        ingrad = valid & (np.abs(off[None, :]) <= radius) & (np.abs(off[:, None]) <= radius)
+        raw = np.zeros(40)
+        for ly in range(1, 14):
+            for lx in range(1, 14):
+                if not ingrad[ly, lx]:
+                    continue
+                gx = patch[ly, lx + 1] - patch[ly, lx - 1]
+                gy = patch[ly - 1, lx] - patch[ly + 1, lx]
+                if gx == 0 and gy == 0:
+                    continue
+                dist = float(off[lx]) ** 2 + float(off[ly]) ** 2
+                wgt = np.exp(-dist / (2 * sigma * sigma)) * np.hypot(gx, gy)
+                ang = float(atan2_shader(np.float64(gx), np.float64(gy)))
+                rb = int(np.floor(ang * 36 / (2 * float(np.float32(3.1415927))) + 0.5))
+                raw[2 + (rb + 36 if rb < 0 else rb - 36 if rb >= 36 else rb)] += wgt
+        raw[1], raw[0], raw[38], raw[39] = raw[37], raw[36], raw[2], raw[3]
+        hist = np.array([(raw[b] + raw[b + 4]) / 16 + (raw[b + 1] + raw[b + 3]) * 4 / 16 + raw[b + 2] * 6 / 16
+                         for b in range(36)])
+        th = hist.max() * float(np.float32(0.8))
+        for b in range(36):
+            hv, le, ri = hist[b], hist[b - 1], hist[(b + 1) % 36]
+            if le < hv and ri < hv and th <= hv:
+                rbin = b + (le - ri) / (le - 2 * hv + ri) / 2
+                rbin = rbin + 36 if rbin < 0 else rbin - 36 if rbin > 36 else rbin
+                out.append((x, y, size, 360.0 - 10.0 * rbin, resp))
+    return np.array(out, np.float64).reshape(-1, 5)
+
+
+def random_extrema(n, w, h, seed, n_scales=4):
+    """sizes as the detector emits them: 0.82 sqrt2 2^(z+delta), z in [1, n_scales] (scan_extrema.glsl:229)."""
+    rng = np.random.default_rng(seed)
+    z = rng.uniform(1.0, n_scales + 0.45, n)
+    size = 0.82 * np.sqrt(2.0) * 2.0 ** z
+    x = rng.uniform(4.0, w - 4.0, n)
+    y = rng.uniform(4.0, h - 4.0, n)
+    return np.stack([x, y, size, rng.uniform(0.04, 0.4, n)], axis=1).astype(np.float32)
+
+
 # ---------------------------------------------------------------- inputs
 def structured_patches():
     y, x = np.mgrid[0:32, 0:32].astype(np.float64)
@@ -242,6 +309,14 @@ def main():
         level1=lv[1].astype(np.float32), level3=lv[3].astype(np.float32),
         patches=sp.astype(np.float32), desc_shader=d.astype(np.float32))
     print("keypoint goldens:", img.shape, kps.shape, "->", d.shape)
+    # keypoint orientation on the same frame: coarse stack + angles for 80 extrema (some touch the border)
+    st = coarse_stack(img)
+    ex = random_extrema(80, w, h, 13)
+    ok = orient(st, ex)
+    np.savez_compressed(os.path.join(GOLDEN, "orientation.npz"), image=img, extrema=ex,
+                        layer2=st[2].astype(np.float32), layer5=st[5].astype(np.float32),
+                        keypoints=ok.astype(np.float32))
+    print("orientation goldens:", ex.shape, "->", ok.shape)
     phi, ep, ec = luts()
     np.savez_compressed(os.path.join(GOLDEN, "luts.npz"), gradient_angle=phi.astype(np.float32),
                         embedding_polar=ep.astype(np.float32), embedding_cartesian=ec.astype(np.float32))
