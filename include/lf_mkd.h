@@ -3,9 +3,9 @@
  *
  * This is the drop-in boundary for ONE path of tnibler/local-features: the
  * "describe" half of LocalFeaturesVulkan::detect (local_features/src/vulkan/mod.rs:435-453),
- * i.e. the extract task graph (mod.rs:1277-1572) minus keypoint orientation:
- *   patch sampling -> blur/gradients -> von-Mises x spatial-kernel pooling
- *   -> normalise -> PCA whitening -> L2.
+ * i.e. the extract task graph (mod.rs:1277-1572):
+ *   keypoint orientation -> patch sampling -> blur/gradients -> von-Mises x spatial-kernel
+ *   pooling -> normalise -> PCA whitening -> L2.
  * Plain pointers and sizes only; no C++/torch types.  Each entry point cites the
  * reference interface it replaces.  The Rust-side binding a maintainer would add
  * is shown in INTEGRATION.md.
@@ -71,7 +71,9 @@ typedef struct {
     uint32_t flags;             /* LF_MKD_FLAG_*                                               */
     uint32_t max_frames;        /* frames of max_image_* size the pyramid store holds for the
                                    multi-frame entry points (default 1)                         */
-    uint32_t reserved[3];
+    uint32_t n_scales;          /* BuildTimeParams.n_scales (lib.rs:60, default 4): keypoint orientation
+                                   reads an a-trous stack of n_scales + 3 layers                */
+    uint32_t reserved[2];
 } lf_mkd_params;
 
 /* Keypoint as the path consumes it: struct Keypoint, lib.rs:17-24 (angle in DEGREES,
@@ -79,6 +81,15 @@ typedef struct {
 typedef struct {
     float x, y, size, angle, response;
 } lf_mkd_keypoint;
+
+/* Refined scale-space extremum as keypoint orientation reads it: the {x, y, scale, contrast} floats of
+ * ExtremumLocations (shaders/common.glsl:45-81) for one index of FilteredExtrema (common.glsl:83-89),
+ * gathered into an array of structs.  size = the interpolated scale written by refine_extrema. */
+typedef struct {
+    float x, y, size, response;
+} lf_mkd_extremum;
+
+#define LF_MKD_MAX_ANGLES_PER_EXTREMUM 18 /* strict local maxima of a circular 36-bin histogram */
 
 typedef struct lf_mkd lf_mkd; /* opaque; owns all device memory */
 
@@ -136,6 +147,32 @@ int lf_mkd_describe_keypoints_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, ui
 int lf_mkd_describe_keypoints_frames_device(lf_mkd *h, const lf_mkd_keypoint *d_kps,
                                             const uint32_t *d_frame_of_kp, uint64_t n, float *d_out,
                                             void *stream);
+
+/* Keypoint orientation: the first node of the extract graph (keypoint_orientation.glsl:36-171,
+ * dispatched from mod.rs:1277-1344), i.e. what turns the detector's extrema into the keypoints the
+ * describe entry points take.  Needs lf_mkd_set_image*: the first call after it extends the frame's
+ * sigma-0.6 level into the a-trous stack of n_scales + 3 full-resolution layers (swt.glsl, mod.rs:1093-1130).
+ * Every histogram peak >= 0.8 max yields one keypoint {x, y, size, angle = 360 - 10 bin, response}.
+ * Output ORDER is defined here (the reference appends with an atomic counter, in no particular order):
+ * by extremum index, then by ascending histogram bin.  At most max_out keypoints are written; *n_out
+ * receives the number written and *n_dropped (may be NULL) how many more there were (the reference's
+ * dropped_features, mod.rs:585).  Host pointers; synchronous. */
+int lf_mkd_orient_keypoints(lf_mkd *h, const lf_mkd_extremum *extrema, uint64_t n,
+                            lf_mkd_keypoint *out, uint64_t max_out, uint64_t *n_out,
+                            uint64_t *n_dropped);
+
+/* Same with DEVICE arrays.  d_frame_of_extremum (may be NULL = frame 0) names each extremum's frame
+ * among those given to lf_mkd_set_images_device; d_frame_of_kp (may be NULL) receives the frame of
+ * every keypoint written, ready for lf_mkd_describe_keypoints_frames_device.  n_out / n_dropped are
+ * HOST pointers: the call waits for `stream` before returning so that the count is valid. */
+int lf_mkd_orient_keypoints_device(lf_mkd *h, const lf_mkd_extremum *d_extrema,
+                                   const uint32_t *d_frame_of_extremum, uint64_t n,
+                                   lf_mkd_keypoint *d_out, uint32_t *d_frame_of_kp, uint64_t max_out,
+                                   uint64_t *n_out, uint64_t *n_dropped, void *stream);
+
+/* Verification tap: copies layer `layer` (0 .. n_scales + 2) of frame 0's a-trous stack to a host
+ * buffer of width x height floats, building the stack first if needed. */
+int lf_mkd_get_coarse_layer(lf_mkd *h, uint32_t layer, float *out);
 
 /* Verification taps for keypoint mode (device pointers). */
 int lf_mkd_sample_patches_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64_t n,

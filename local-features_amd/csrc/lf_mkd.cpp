@@ -31,6 +31,16 @@ struct lf_mkd {
     bool have_image = false;
     uint32_t max_frames = 1, n_frames = 0;  // frames held by the pyramid store / currently loaded
     long pyr_stride = 0;                    // floats between the pyramids of consecutive frames
+    // keypoint orientation: a-trous layers 1 .. n_layers-1 per frame (layer 0 = pyramid level 0), allocated on first use
+    int n_layers = 7;
+    float *d_coarse = nullptr;
+    long layer_stride = 0, coarse_stride = 0;  // floats between layers / between frames
+    bool coarse_valid = false;
+    uint64_t orient_cap = 0;                   // extrema the scratch arrays below hold
+    float *d_extrema = nullptr, *d_angles = nullptr, *d_kps_out = nullptr;
+    unsigned *d_counts = nullptr;
+    uint64_t kps_out_cap = 0;
+    unsigned long long *d_totals = nullptr;
     int num_cus = 256;
     // LF_MKD_FLAG_KERNEL_TIMING: (start, end) of the describe kernel per batch
     std::vector<hipEvent_t> ev_pending, ev_free;
@@ -97,6 +107,7 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     h->params = *params;
     if (h->params.patch_scale_factor == 0.f) h->params.patch_scale_factor = 24.f;  // lib.rs:46
     const uint64_t mf = params->max_features ? params->max_features : 2000;        // lib.rs:69
+    h->n_layers = int(params->n_scales ? params->n_scales : 4) + 3;                // lib.rs:70, mod.rs:1093
     h->batch = (mf + 63) / 64 * 64;
     auto bail = [&](int code) {
         g_create_error = h->err;
@@ -130,6 +141,7 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_patches), h->batch * kPx * 4));
     LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_out), h->batch * kOut * 4));
     LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_kps), h->batch * 5 * 4));
+    LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_totals), 2 * sizeof(unsigned long long)));
     if (params->max_image_width && params->max_image_height) {
         h->max_frames = params->max_frames ? params->max_frames : 1;
         const size_t px = size_t(params->max_image_width) * params->max_image_height * h->max_frames;
@@ -165,6 +177,60 @@ int run_batch(lf_mkd *h, const float *d_patches, uint64_t n, float *d_out, float
                     d_raw, h->num_cus, s);
     LF_HIP(h, hipGetLastError());
     if (int rc = mark(h, s)) return rc;
+    return LF_MKD_OK;
+}
+
+// Extends the loaded frames' level 0 into the a-trous stack (once per set_image*), allocating it on first use.
+int ensure_coarse_stack(lf_mkd *h, hipStream_t s) {
+    if (h->coarse_valid) return LF_MKD_OK;
+    if (!h->d_coarse) {
+        h->layer_stride = long(h->params.max_image_width) * h->params.max_image_height;
+        h->coarse_stride = h->layer_stride * (h->n_layers - 1);
+        LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_coarse), size_t(h->coarse_stride) * h->max_frames * 4));
+    }
+    launch_build_coarse_stack(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride,
+                              h->d_tmp_a, h->n_layers, h->pd.w[0], h->pd.h[0], int(h->n_frames), s);
+    LF_HIP(h, hipGetLastError());
+    h->coarse_valid = true;
+    return LF_MKD_OK;
+}
+
+int ensure_orient_scratch(lf_mkd *h, uint64_t n, bool staging, uint64_t max_out) {
+    if (n > h->orient_cap) {
+        for (void *p : {static_cast<void *>(h->d_extrema), static_cast<void *>(h->d_angles),
+                        static_cast<void *>(h->d_counts)})
+            if (p) (void)hipFree(p);
+        h->d_extrema = h->d_angles = nullptr;
+        h->d_counts = nullptr;
+        h->orient_cap = 0;
+        const uint64_t cap = std::max<uint64_t>(n, h->batch);
+        LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_extrema), cap * sizeof(lf_mkd_extremum)));
+        LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_angles), cap * LF_MKD_MAX_ANGLES_PER_EXTREMUM * 4));
+        LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_counts), cap * 4));
+        h->orient_cap = cap;
+    }
+    if (staging && max_out > h->kps_out_cap) {
+        if (h->d_kps_out) (void)hipFree(h->d_kps_out);
+        h->d_kps_out = nullptr;
+        h->kps_out_cap = 0;
+        LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_kps_out), max_out * sizeof(lf_mkd_keypoint)));
+        h->kps_out_cap = max_out;
+    }
+    return LF_MKD_OK;
+}
+
+int orient_device(lf_mkd *h, const float *d_extrema, const uint32_t *d_frame_of, uint64_t n, float *d_out,
+                  uint32_t *d_frame_of_kp, uint64_t max_out, uint64_t *n_out, uint64_t *n_dropped, hipStream_t s) {
+    if (int rc = ensure_coarse_stack(h, s)) return rc;
+    launch_orient(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride, h->n_layers,
+                  h->pd.w[0], h->pd.h[0], d_extrema, d_frame_of, long(n), h->d_angles, h->d_counts, d_out, d_frame_of_kp,
+                  max_out, h->d_totals, s);
+    LF_HIP(h, hipGetLastError());
+    unsigned long long totals[2] = {0, 0};
+    LF_HIP(h, hipMemcpyAsync(totals, h->d_totals, sizeof(totals), hipMemcpyDeviceToHost, s));
+    LF_HIP(h, hipStreamSynchronize(s));
+    *n_out = totals[0];
+    if (n_dropped) *n_dropped = totals[1];
     return LF_MKD_OK;
 }
 
@@ -218,7 +284,8 @@ void lf_mkd_destroy(lf_mkd *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->dc.phi_cs,      h->dc.colmap,     h->dc.pool_b_f32, h->dc.pool_b_f16, h->dc.white_a_f16,
                     h->dc.white_a_f32, h->dc.white_bias, h->d_patches,     h->d_out,         h->d_kps,
-                    h->d_image,        h->d_pyr,         h->d_tmp_a,       h->d_tmp_b};
+                    h->d_image,        h->d_pyr,         h->d_tmp_a,       h->d_tmp_b,       h->d_coarse,
+                    h->d_extrema,      h->d_angles,      h->d_counts,      h->d_kps_out,     h->d_totals};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev_pending) (void)hipEventDestroy(e);
@@ -317,6 +384,7 @@ int lf_mkd_set_images_device(lf_mkd *h, const float *d_images, uint32_t n_frames
                          int(n_frames), s);
     LF_HIP(h, hipGetLastError());
     h->have_image = true;
+    h->coarse_valid = false;
     h->n_frames = n_frames;
     return LF_MKD_OK;
 }
@@ -394,6 +462,53 @@ int lf_mkd_describe_keypoints(lf_mkd *h, const lf_mkd_keypoint *kps, uint64_t n,
         LF_HIP(h, hipMemcpyAsync(out + off * kOut, h->d_out, m * kOut * 4, hipMemcpyDeviceToHost, h->stream));
         LF_HIP(h, hipStreamSynchronize(h->stream));
     }
+    return LF_MKD_OK;
+}
+
+int lf_mkd_orient_keypoints_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, const uint32_t *d_frame_of_extremum,
+                                   uint64_t n, lf_mkd_keypoint *d_out, uint32_t *d_frame_of_kp, uint64_t max_out,
+                                   uint64_t *n_out, uint64_t *n_dropped, void *stream) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!n_out) return fail(h, LF_MKD_ERR_BAD_ARG, "orient_keypoints_device: n_out is null");
+    *n_out = 0;
+    if (n_dropped) *n_dropped = 0;
+    if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "orient_keypoints: call lf_mkd_set_image first");
+    if (n == 0) return LF_MKD_OK;
+    if (!d_extrema || (!d_out && max_out)) return fail(h, LF_MKD_ERR_BAD_ARG, "orient_keypoints_device: null pointer");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    if (int rc = ensure_orient_scratch(h, n, false, 0)) return rc;
+    return orient_device(h, reinterpret_cast<const float *>(d_extrema), d_frame_of_extremum, n,
+                         reinterpret_cast<float *>(d_out), d_frame_of_kp, max_out, n_out, n_dropped, s);
+}
+
+int lf_mkd_orient_keypoints(lf_mkd *h, const lf_mkd_extremum *extrema, uint64_t n, lf_mkd_keypoint *out,
+                            uint64_t max_out, uint64_t *n_out, uint64_t *n_dropped) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!n_out) return fail(h, LF_MKD_ERR_BAD_ARG, "orient_keypoints: n_out is null");
+    *n_out = 0;
+    if (n_dropped) *n_dropped = 0;
+    if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "orient_keypoints: call lf_mkd_set_image first");
+    if (n == 0) return LF_MKD_OK;
+    if (!extrema || (!out && max_out)) return fail(h, LF_MKD_ERR_BAD_ARG, "orient_keypoints: null pointer");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    if (int rc = ensure_orient_scratch(h, n, true, std::max<uint64_t>(max_out, 1))) return rc;
+    LF_HIP(h, hipMemcpyAsync(h->d_extrema, extrema, n * sizeof(lf_mkd_extremum), hipMemcpyHostToDevice, h->stream));
+    if (int rc = orient_device(h, h->d_extrema, nullptr, n, h->d_kps_out, nullptr, max_out, n_out, n_dropped, h->stream))
+        return rc;
+    if (*n_out) LF_HIP(h, hipMemcpy(out, h->d_kps_out, *n_out * sizeof(lf_mkd_keypoint), hipMemcpyDeviceToHost));
+    return LF_MKD_OK;
+}
+
+int lf_mkd_get_coarse_layer(lf_mkd *h, uint32_t layer, float *out) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "get_coarse_layer: call lf_mkd_set_image first");
+    if (layer >= uint32_t(h->n_layers) || !out) return fail(h, LF_MKD_ERR_BAD_ARG, "get_coarse_layer: bad layer");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    if (int rc = ensure_coarse_stack(h, h->stream)) return rc;
+    LF_HIP(h, hipStreamSynchronize(h->stream));
+    const float *src = layer == 0 ? h->d_pyr + h->pd.offset[0] : h->d_coarse + long(layer - 1) * h->layer_stride;
+    LF_HIP(h, hipMemcpy(out, src, size_t(h->pd.w[0]) * h->pd.h[0] * 4, hipMemcpyDeviceToHost));
     return LF_MKD_OK;
 }
 

@@ -39,4 +39,15 @@ void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc 
 void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,
                           float *tmp_b, const PyramidDesc &pd, int frames, hipStream_t stream);
 
+// a-trous layers 1 .. n_layers-1 over layer0 (= pyramid level 0); tmp holds frames x w x h floats
+void launch_build_coarse_stack(const float *layer0, long layer0_stride, float *coarse, long coarse_stride,
+                               long layer_stride, float *tmp, int n_layers, int w, int h, int frames,
+                               hipStream_t stream);
+// extrema [n][4] -> kps [<= max_out][5] ordered by extremum then bin; angles [n][18], counts [n] are scratch;
+// totals[0] = written, totals[1] = dropped
+void launch_orient(const float *layer0, long layer0_stride, const float *coarse, long coarse_stride, long layer_stride,
+                   int n_layers, int w, int h, const float *extrema, const unsigned *frame_of, long n, float *angles,
+                   unsigned *counts, float *kps, unsigned *frame_of_kp, unsigned long long max_out,
+                   unsigned long long *totals, hipStream_t stream);
+
 }  // namespace lfmkd

@@ -5,8 +5,10 @@ The reference class exposes `detect` / `detect_top_n` (detector + describe in on
 python/src/lib.rs:86-149); there is no public describe-only call.  This build accelerates the
 describe half, so the class keeps the constructor signature, the Keypoint
 type and the `(list[Keypoint], ndarray[n,128] f32)` result shape, and adds `describe`, which takes
-the keypoint list the detector would have produced.  `detect*` raise: the detector is a "next"
-row, and nothing here falls back to a CPU path.
+the keypoint list the detector would have produced, and `orient` / `describe_extrema`, which take the
+detector's refined extrema and run keypoint orientation first (the whole extract graph, mod.rs:1277-1572).
+`detect*` raise: the scale-space detector is a "next" row, and nothing here falls back
+to a CPU path.
 """
 import threading
 
@@ -49,8 +51,8 @@ def _keypoints_to_array(keypoints):
 
 class LocalFeatures:
     """LocalFeatures(max_image_width, max_image_height, max_features, max_blobs, n_scales, pca)
-    -- python/src/lib.rs:43-84.  max_blobs and n_scales belong to the detector and are kept only
-    for signature compatibility."""
+    -- python/src/lib.rs:43-84.  n_scales sizes the a-trous stack keypoint orientation reads; max_blobs
+    belongs to the detector and is kept only for signature compatibility."""
 
     def __init__(self, max_image_width, max_image_height, max_features, max_blobs=8000, n_scales=4,
                  pca="liberty", device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_F32):
@@ -59,7 +61,7 @@ class LocalFeatures:
         try:
             self._inner = MkdHandle(pca=pca, max_features=max_features, max_image_width=max_image_width,
                                     max_image_height=max_image_height, device=device,
-                                    angle_mode=angle_mode, pool_mode=pool_mode)
+                                    angle_mode=angle_mode, pool_mode=pool_mode, n_scales=n_scales)
         except RuntimeError as e:   # python/src/lib.rs:77-82
             raise RuntimeError("Failed to initialize local features", str(e)) from e
         self._lock = threading.Lock()   # Mutex<LocalFeaturesVulkan>, python/src/lib.rs:38
@@ -81,15 +83,39 @@ class LocalFeatures:
         out_k = [Keypoint(*row) for row in kps.reshape(-1, 5)] if not isinstance(keypoints, list) else keypoints
         return out_k, desc
 
+    def orient(self, img, extrema):
+        """extrema: [n,4] array (x, y, size, response), the detector's refined extrema.  Returns the
+        list[Keypoint] keypoint orientation yields (one per histogram peak, keypoint_orientation.glsl:36-171),
+        ordered by extremum then bin."""
+        return self.describe_extrema(img, extrema, describe=False)[0]
+
+    def describe_extrema(self, img, extrema, describe=True):
+        """The whole extract graph: orientation, then sampling + description of every keypoint found.
+        Returns (list[Keypoint], ndarray[m,128] float32)."""
+        arr = np.asarray(img)
+        if arr.ndim != 2:
+            raise RuntimeError("Failed to extract features", "image must be 2-dimensional")
+        ex = np.ascontiguousarray(extrema, np.float32)
+        if ex.ndim != 2 or ex.shape[1] != 4:
+            raise RuntimeError("extrema array must be [n,4] (x, y, size, response)")
+        with self._lock:
+            try:
+                self._inner.set_image(arr)
+                kps, _ = self._inner.orient_keypoints(ex)
+                desc = self._inner.describe_keypoints(kps) if describe else None
+            except RuntimeError as e:
+                raise RuntimeError("Failed to extract features", str(e)) from e
+        return [Keypoint(*row) for row in kps], desc
+
     def describe_patches(self, patches):
         """patches: [n,32,32] float32 -> ndarray[n,128] (the CPU twin's Mkd::patch, mkd_ref.rs:57-77)."""
         with self._lock:
             return self._inner.describe_patches(patches)
 
     def detect(self, img):
-        raise NotImplementedError("detector (scan_extrema + orientation) is outside this build's hot path; "
-                                  "use describe(img, keypoints) -- SURVEY.md 8(f)")
+        raise NotImplementedError("the scale-space detector (scan/refine extrema) is outside this build's hot path; "
+                                  "use describe(img, keypoints) or describe_extrema(img, extrema) -- SURVEY.md 8(f)")
 
     def detect_top_n(self, img, n, min_size):
-        raise NotImplementedError("detector (scan_extrema + orientation) is outside this build's hot path; "
-                                  "use describe(img, keypoints) -- SURVEY.md 8(f)")
+        raise NotImplementedError("the scale-space detector (scan/refine extrema) is outside this build's hot path; "
+                                  "use describe(img, keypoints) or describe_extrema(img, extrema) -- SURVEY.md 8(f)")

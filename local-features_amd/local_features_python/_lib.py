@@ -23,6 +23,7 @@ SYMBOLS = (
     "lf_mkd_describe_keypoints_frames_device",
     "lf_mkd_describe_keypoints_device", "lf_mkd_sample_patches_device", "lf_mkd_get_pyramid_level",
     "lf_mkd_build_constants", "lf_mkd_kernel_times", "lf_mkd_synchronize", "lf_mkd_version",
+    "lf_mkd_orient_keypoints", "lf_mkd_orient_keypoints_device", "lf_mkd_get_coarse_layer",
 )
 
 
@@ -31,7 +32,8 @@ class Params(ctypes.Structure):
         ("max_image_width", ctypes.c_uint32), ("max_image_height", ctypes.c_uint32),
         ("max_features", ctypes.c_uint32), ("patch_scale_factor", ctypes.c_float),
         ("device", ctypes.c_int32), ("angle_mode", ctypes.c_int32), ("pool_mode", ctypes.c_int32),
-        ("flags", ctypes.c_uint32), ("max_frames", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 3),
+        ("flags", ctypes.c_uint32), ("max_frames", ctypes.c_uint32), ("n_scales", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32 * 2),
     ]
 
 
@@ -83,6 +85,10 @@ def load_library():
     L.lf_mkd_sample_patches_device.argtypes = [vp, vp, u64, vp, vp]
     L.lf_mkd_get_pyramid_level.argtypes = [vp, u32, vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.lf_mkd_synchronize.argtypes = [vp]
+    L.lf_mkd_orient_keypoints.argtypes = [vp, vp, u64, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    L.lf_mkd_orient_keypoints_device.argtypes = [vp, vp, vp, u64, vp, vp, u64, ctypes.POINTER(u64),
+                                                 ctypes.POINTER(u64), vp]
+    L.lf_mkd_get_coarse_layer.argtypes = [vp, u32, vp]
     L.lf_mkd_build_constants.argtypes = [vp] * 7
     L.lf_mkd_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(u64)]
@@ -96,13 +102,14 @@ class MkdHandle:
 
     def __init__(self, pca="liberty", max_features=2000, max_image_width=0, max_image_height=0,
                  patch_scale_factor=24.0, device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_F32, flags=0,
-                 max_frames=1):
+                 max_frames=1, n_scales=4):
         self._h = None
+        self.n_scales = n_scales
         self.L = load_library()
         p = Params(max_image_width=max_image_width, max_image_height=max_image_height,
                    max_features=max_features, patch_scale_factor=patch_scale_factor,
                    device=device, angle_mode=angle_mode, pool_mode=pool_mode, flags=flags,
-                   max_frames=max_frames)
+                   max_frames=max_frames, n_scales=n_scales)
         h = ctypes.c_void_p()
         rc = self.L.lf_mkd_create_from_file(ctypes.byref(p), model_path(pca).encode(), ctypes.byref(h))
         if rc != 0:
@@ -145,6 +152,23 @@ class MkdHandle:
                     "lf_mkd_describe_keypoints")
         return out
 
+    def orient_keypoints(self, extrema, max_out=None):
+        """extrema [n,4] (x, y, size, response) -> (keypoints [m,5] (x, y, size, angle_deg, response), dropped).
+        Ordered by extremum, then histogram bin."""
+        e = np.ascontiguousarray(extrema, np.float32).reshape(-1, 4)
+        n = e.shape[0]
+        cap = 18 * n if max_out is None else int(max_out)
+        out = np.empty((max(cap, 1), 5), np.float32)
+        m, dropped = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.L.lf_mkd_orient_keypoints(self._h, e.ctypes.data, n, out.ctypes.data, cap, ctypes.byref(m),
+                                                   ctypes.byref(dropped)), "lf_mkd_orient_keypoints")
+        return out[:m.value].copy(), dropped.value
+
+    def coarse_layer(self, layer, width, height):
+        out = np.empty((height, width), np.float32)
+        self._check(self.L.lf_mkd_get_coarse_layer(self._h, layer, out.ctypes.data), "lf_mkd_get_coarse_layer")
+        return out
+
     def pyramid_level(self, level):
         w, h = ctypes.c_uint32(), ctypes.c_uint32()
         self._check(self.L.lf_mkd_get_pyramid_level(self._h, level, None, ctypes.byref(w), ctypes.byref(h)),
@@ -178,6 +202,15 @@ class MkdHandle:
     def describe_keypoints_device(self, d_kps, n, d_out, stream=None):
         self._check(self.L.lf_mkd_describe_keypoints_device(self._h, d_kps, n, d_out, stream),
                     "lf_mkd_describe_keypoints_device")
+
+    def orient_keypoints_device(self, d_extrema, d_frame_of_extremum, n, d_out, d_frame_of_kp, max_out, stream=None):
+        """Returns (written, dropped); waits for the stream (the count comes back to the host)."""
+        m, dropped = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.L.lf_mkd_orient_keypoints_device(self._h, d_extrema, d_frame_of_extremum, n, d_out,
+                                                          d_frame_of_kp, max_out, ctypes.byref(m),
+                                                          ctypes.byref(dropped), stream),
+                    "lf_mkd_orient_keypoints_device")
+        return m.value, dropped.value
 
     def sample_patches_device(self, d_kps, n, d_patches, stream=None):
         self._check(self.L.lf_mkd_sample_patches_device(self._h, d_kps, n, d_patches, stream),

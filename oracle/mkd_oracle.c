@@ -38,6 +38,11 @@
 
 #define ATAN_SHADER 0   /* polynomial atan2 incl. its quirks (parity gate)  */
 #define ATAN_LIBM 1     /* exact atan2f, as the CPU twin mkd_ref.rs:140     */
+/* OR-ed into atan_mode: evaluate the blur's `sum += k[i] * p` (patch_gradients.glsl:72-92) as fma(k[i], p, sum).
+ * The shader carries no `precise` qualifier, so a GLSL compiler may contract or not; both are the reference.
+ * It matters only through atan2.glsl's discontinuity at x == 0 (a pixel whose gx rounds to exactly 0 gets angle 0
+ * instead of +-pi/2): see mkd_oracle_quirk_pixels. */
+#define BLUR_CONTRACT 2
 
 /* mkd_ref.rs:7-9 */
 static const float VM_N3_K8[4] = {0.37872374f, 0.51796234f, 0.46882015f, 0.39798096f};
@@ -240,16 +245,16 @@ float mkd_oracle_atan2_shader(float x, float y)
 /* ------------------------------------------------------------------------- */
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-void mkd_oracle_patch_gradients(const float *patch, float *mag, float *angle, int atan_mode)
+static void blur_patch(const float *patch, float *blur, int contract)
 {
     static const float k[5] = {0.0096f, 0.2054f, 0.5699f, 0.2054f, 0.0096f};
-    float tmp[NPX], blur[NPX];
+    float tmp[NPX];
     for (int y = 0; y < PS; y++) /* vertical pass, lines 72-81 */
         for (int x = 0; x < PS; x++) {
             float sum = 0.f;
             for (int i = 0; i < 5; i++) {
                 const int yy = clampi(y + i - 2, 0, PS - 1);
-                sum += k[i] * patch[yy * PS + x];
+                sum = contract ? fmaf(k[i], patch[yy * PS + x], sum) : sum + k[i] * patch[yy * PS + x];
             }
             tmp[y * PS + x] = sum;
         }
@@ -258,10 +263,41 @@ void mkd_oracle_patch_gradients(const float *patch, float *mag, float *angle, in
             float sum = 0.f;
             for (int i = 0; i < 5; i++) {
                 const int xx = clampi(x + i - 2, 0, PS - 1);
-                sum += k[i] * tmp[y * PS + xx];
+                sum = contract ? fmaf(k[i], tmp[y * PS + xx], sum) : sum + k[i] * tmp[y * PS + xx];
             }
             blur[y * PS + x] = sum;
         }
+}
+
+/* Number of pixels of a patch that sit on atan2.glsl's discontinuity: gy != 0 and |gx| <= tol (a few ulps of the
+ * blurred values), evaluated both ways the blur may round.  A descriptor of such a patch is decided by last-bit
+ * rounding the reference leaves to its GLSL compiler; parity tests hold those patches to the contracted variant
+ * when the input bits are shared and set them aside when they are not. */
+int mkd_oracle_quirk_pixels(const float *patch, float tol)
+{
+    float blur[2][NPX];
+    blur_patch(patch, blur[0], 0);
+    blur_patch(patch, blur[1], 1);
+    int n = 0;
+    for (int y = 0; y < PS; y++)
+        for (int x = 0; x < PS; x++) {
+            int hit = 0;
+            for (int v = 0; v < 2; v++) {
+                const float *b = blur[v];
+                const float gx = b[y * PS + clampi(x, 1, PS - 1) - 1] - b[y * PS + clampi(x, 0, PS - 2) + 1];
+                const float gy = b[(clampi(y, 0, PS - 2) + 1) * PS + x] - b[(clampi(y, 1, PS - 1) - 1) * PS + x];
+                hit |= gy != 0.f && fabsf(gx) <= tol;
+            }
+            n += hit;
+        }
+    return n;
+}
+
+void mkd_oracle_patch_gradients(const float *patch, float *mag, float *angle, int atan_mode)
+{
+    float blur[NPX];
+    blur_patch(patch, blur, atan_mode & BLUR_CONTRACT);
+    atan_mode &= ~BLUR_CONTRACT;
     for (int y = 0; y < PS; y++)
         for (int x = 0; x < PS; x++) {
             /* lines 94-96: gx = left - right, gy = down - up, replicate border */

@@ -14,6 +14,7 @@ _LIB = os.path.join(_HERE, "libmkd_oracle.so")
 
 ATAN_SHADER = 0
 ATAN_LIBM = 1
+BLUR_CONTRACT = 2   # OR into atan_mode: the blur's mul+add contracted to fma (both readings are the reference)
 
 _fp = ctypes.POINTER(ctypes.c_float)
 
@@ -50,6 +51,7 @@ class MkdOracle:
             _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_long, ctypes.c_float, _fp]
         L.mkd_oracle_build_pyramid.argtypes = [_fp, ctypes.c_int, ctypes.c_int, _fp]
         L.mkd_oracle_patch_gradients.argtypes = [_fp, _fp, _fp, ctypes.c_int]
+        L.mkd_oracle_quirk_pixels.argtypes = [_fp, ctypes.c_float]
         L.mkd_oracle_build_coarse_stack.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]
         L.mkd_oracle_orient.restype = ctypes.c_long
         L.mkd_oracle_orient.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_long, _fp,
@@ -108,6 +110,11 @@ class MkdOracle:
             self._consts.ctypes.data_as(ctypes.c_void_p), _ptr(p), n, _ptr(desc),
             _ptr(raw) if want_raw else None, atan_mode, nthreads)
         return (desc, raw) if want_raw else desc
+
+    def quirk_pixels(self, patches, tol=2e-7):
+        """Per patch: pixels with gy != 0 and |gx| <= tol, i.e. on the x == 0 discontinuity of atan2.glsl."""
+        p = _f32(patches).reshape(-1, 32, 32)
+        return np.array([self.L.mkd_oracle_quirk_pixels(_ptr(p[i]), tol) for i in range(len(p))], np.int32)
 
     def pyramid_levels(self, w, h):
         return self.L.mkd_oracle_pyramid_levels(w, h)

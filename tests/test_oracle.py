@@ -150,3 +150,24 @@ def test_orientation_properties(oracle):
     assert len(oracle.orient(np.full((7, h, w), 0.3, np.float32), ex)) == 0
     # empty input
     assert oracle.orient(st, np.zeros((0, 4), np.float32)).shape == (0, 5)
+
+
+def test_quirk_pixel_detector_and_contracted_blur(oracle):
+    """atan2.glsl's x == 0 discontinuity: a patch mirrored about column 15 has gx == 0 (or +-1 ulp, depending on how
+    the blur rounds) down that column; the detector flags it, and the two blur roundings the shader allows give
+    different descriptors there while agreeing to 1e-5 on ordinary patches."""
+    from oracle import BLUR_CONTRACT
+    rng = np.random.default_rng(5)
+    p = rng.random((200, 32, 32)).astype(np.float32)
+    q = oracle.quirk_pixels(p)
+    assert (q > 0).sum() <= 3
+    a = oracle.describe_patches(p)
+    b = oracle.describe_patches(p, atan_mode=ATAN_SHADER | BLUR_CONTRACT)
+    assert rel_l2(a, b)[q == 0].max() < 2e-5
+    half = rng.random((32, 16)).astype(np.float32)
+    sym = np.concatenate([half[:, :15], half[:, 15:16], half[:, 14::-1], half[:, :1]], axis=1)   # cols 0..30 mirrored
+    assert sym.shape == (32, 32) and np.array_equal(sym[:, 14], sym[:, 16])
+    assert oracle.quirk_pixels(sym)[0] >= 20
+    mag, ang = oracle.patch_gradients(sym)
+    col = np.abs(ang[:, 15])
+    assert ((col == 0) | (np.abs(col - np.pi / 2) < 1e-3)).all() and (col == 0).any()
