@@ -8,6 +8,11 @@ import numpy as np, torch
 import local_features_python as lfp
 from gen_golden import random_keypoints
 
+# The library treats a NULL stream argument as "the handle's own stream", and torch's default stream IS the NULL
+# stream: run everything on a side stream so that torch's events and the library's launches share one queue.
+_side = torch.cuda.Stream()
+torch.cuda.set_stream(_side)
+
 
 def frame(h, w, seed):
     g = torch.Generator(device="cuda").manual_seed(seed)
@@ -68,6 +73,36 @@ def run_batched(w, h, nk, frames, tag):
     print(f"{tag}: {frames} frames {w}x{h} x {nk} kpts in ONE batch: {dt*1e3:.3f} ms  {n/dt/1e6:.1f} M desc/s", flush=True)
 
 
+def run_orient(w, h, ne, frames, tag):
+    """extract graph from the detector's extrema: pyramid + a-trous stack + orientation + sample + describe"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_orientation import random_extrema
+    cap = 2 * ne
+    hnd = lfp.MkdHandle(max_features=cap, max_image_width=w, max_image_height=h, pool_mode=lfp.POOL_F16X3)
+    s = torch.cuda.current_stream().cuda_stream
+    imgs = [frame(h, w, 100 + f) for f in range(4)]
+    exs = [torch.from_numpy(random_extrema(ne, w, h, 300 + f, border=8.0)).cuda() for f in range(4)]
+    kps = torch.empty((cap, 5), device="cuda")
+    out = torch.empty((cap, 128), device="cuda")
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    acc = np.zeros(3); nk = 0
+    for f in range(frames + 3):
+        e[0].record(); hnd.set_image_device(imgs[f % 4].data_ptr(), w, h, s)
+        e[1].record(); m, dropped = hnd.orient_keypoints_device(exs[f % 4].data_ptr(), None, ne, kps.data_ptr(), None, cap, s)
+        e[2].record(); hnd.describe_keypoints_device(kps.data_ptr(), m, out.data_ptr(), s)
+        e[3].record(); torch.cuda.synchronize()
+        if f >= 3:
+            acc += [e[i].elapsed_time(e[i + 1]) for i in range(3)]; nk += m
+    acc /= frames
+    print(f"{tag}: {w}x{h}, {ne} extrema -> {nk // frames} keypoints/frame: pyramid {acc[0]:.3f} ms, a-trous stack + orientation "
+          f"{acc[1]:.3f} ms (incl. host sync for the count), sample+describe {acc[2]:.3f} ms", flush=True)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "orient":
+    run_orient(1920, 1080, 7000, 20, "configs[1] from extrema")
+    run_orient(640, 480, 1400, 20, "configs[2] frame from extrema")
+    run_orient(3840, 2160, 5600, 20, "configs[4] from extrema")
+    sys.exit(0)
 run(1920, 1080, 10000, 50, "configs[1]")
 run_batched(640, 480, 2000, 256, "configs[2] batched")
 run(640, 480, 2000, 256, "configs[2]")
