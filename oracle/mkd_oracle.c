@@ -771,3 +771,148 @@ long mkd_oracle_orient(const float *stack, int w, int h, int n_layers, const flo
     }
     return m;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Detector: DoG + 3-D extremum scan + refinement + edge test    */
+/* shaders/swt_sub.glsl:17-30, shaders/scan_extrema.glsl:36-241,               */
+/* dispatch vulkan/tasks_detect.rs:264-316, constants vulkan/mod.rs:76,395-407 */
+/* ------------------------------------------------------------------------- */
+
+/* fine[l] = coarse[l] - coarse[l+1], l = 0 .. n_layers-2 (swt_sub.glsl:24-29; texel-centre fetches) */
+void mkd_oracle_dog(const float *stack, int w, int h, int n_layers, float *fine)
+{
+    const long px = (long)w * h;
+    for (int l = 0; l + 1 < n_layers; l++)
+        for (long i = 0; i < px; i++) fine[l * px + i] = stack[l * px + i] - stack[(l + 1) * px + i];
+}
+
+/* Extremum scan over the DoG volume fine[n_fine][h][w].  The shader works in 4x4x4 cubes (one workgroup each,
+ * origin (border, border, 1 + skip_layers)), keeps at most 8 candidates per cube (max_wg_extrema, line 28; WHICH
+ * 8 is left to the atomics) and appends survivors with a global atomic, i.e. in no order.  Order defined here:
+ * cubes in raster order (z, y, x), candidates of a cube by local index x + 4 y + 16 z; a cube with more than
+ * 8 candidates keeps the first 8 in that order.
+ * extrema [max_out][4] = (x + offset_x, y + offset_y, size, contrast).  Returns the number written; *n_total
+ * (may be NULL) receives the number found (reference: n_scanned_extrema, mod.rs:625). */
+long mkd_oracle_scan_extrema(const float *fine, int w, int h, int n_fine, int border, int skip_layers,
+                             float contrast_threshold, float *extrema, long max_out, long *n_total)
+{
+    const long px = (long)w * h;
+    const int b1 = border > 1 ? border : 1;
+    const int gx = (w - 2 * border + 3) / 4, gy = (h - 2 * border + 3) / 4;
+    const int gz = (n_fine - 2 - skip_layers + 3) / 4;
+    long found = 0;
+    if (w - 2 * border <= 0 || h - 2 * border <= 0 || n_fine - 2 - skip_layers <= 0) {
+        if (n_total) *n_total = 0;
+        return 0;
+    }
+#define AT(z, y, x) fine[(long)(z) * px + (long)(y) * w + (x)]
+    for (int cz = 0; cz < gz; cz++)
+        for (int cy = 0; cy < gy; cy++)
+            for (int cx = 0; cx < gx; cx++) {
+                int cand = 0;
+                for (int li = 0; li < 64 && cand < 8; li++) {
+                    const int x = cx * 4 + (li & 3) + border, y = cy * 4 + ((li >> 2) & 3) + border;
+                    const int z = cz * 4 + (li >> 4) + 1 + skip_layers;
+                    /* is_extremum, lines 86-126 */
+                    if (x < b1 || x >= w - b1 || y < b1 || y >= h - b1 || z <= 0 || z >= n_fine - 1) continue;
+                    const float val = AT(z, y, x);
+                    if (fabsf(val) <= contrast_threshold) continue;
+                    const float sgn = glsl_sign(val);
+                    int ok = 1;
+                    for (int dz = -1; dz <= 1 && ok; dz++)
+                        for (int dy = -1; dy <= 1 && ok; dy++)
+                            for (int dx = -1; dx <= 1; dx++)
+                                if ((dz || dy || dx) && !(sgn * val >= sgn * AT(z + dz, y + dy, x + dx))) {
+                                    ok = 0;
+                                    break;
+                                }
+                    if (!ok) continue;
+                    cand++; /* occupies one of the cube's 8 slots whether or not it survives refinement */
+                    /* lines 165-236 */
+                    const float dds = (AT(z + 1, y, x) - AT(z - 1, y, x)) / 2.0f;
+                    const float ddy = (AT(z, y + 1, x) - AT(z, y - 1, x)) / 2.0f;
+                    const float ddx = (AT(z, y, x + 1) - AT(z, y, x - 1)) / 2.0f;
+                    const float value2x = AT(z, y, x) * 2.0f;
+                    const float h11 = AT(z + 1, y, x) + AT(z - 1, y, x) - value2x;
+                    const float h22 = AT(z, y + 1, x) + AT(z, y - 1, x) - value2x;
+                    const float h33 = AT(z, y, x + 1) + AT(z, y, x - 1) - value2x;
+                    const float h12 = (AT(z + 1, y + 1, x) - AT(z - 1, y + 1, x) - AT(z + 1, y - 1, x) +
+                                       AT(z - 1, y - 1, x)) / 4.0f;
+                    const float h13 = (AT(z + 1, y, x + 1) - AT(z - 1, y, x + 1) - AT(z + 1, y, x - 1) +
+                                       AT(z - 1, y, x - 1)) / 4.0f;
+                    const float h23 = (AT(z, y + 1, x + 1) - AT(z, y + 1, x - 1) - AT(z, y - 1, x + 1) +
+                                       AT(z, y - 1, x - 1)) / 4.0f;
+                    const float det = h11 * h22 * h33 - h11 * h23 * h23 - h12 * h12 * h33 +
+                                      2.f * h12 * h13 * h23 - h13 * h13 * h22;
+                    const float hinv11 = (h22 * h33 - h23 * h23) / det;
+                    const float hinv12 = (h13 * h23 - h12 * h33) / det;
+                    const float hinv13 = (h12 * h23 - h13 * h22) / det;
+                    const float hinv22 = (h11 * h33 - h13 * h13) / det;
+                    const float hinv23 = (h12 * h13 - h11 * h23) / det;
+                    const float hinv33 = (h11 * h22 - h12 * h12) / det;
+                    const float os = -(hinv11 * dds + hinv12 * ddy + hinv13 * ddx);
+                    const float oy = -(hinv12 * dds + hinv22 * ddy + hinv23 * ddx);
+                    const float ox = -(hinv13 * dds + hinv23 * ddy + hinv33 * ddx);
+                    /* an offset beyond half a cell moves x, y, z and emits nothing (lines 200-203); NaN offsets
+                     * (det == 0) compare false and fall through to the else branch like in the shader */
+                    if (fabsf(ox) > 0.5f || fabsf(oy) > 0.5f || fabsf(os) > 0.5f) continue;
+                    if (x < border || w - border <= x || y < border || h - border <= y || z < 1 || n_fine - 1 <= z)
+                        continue;
+                    const float interp = os * dds + oy * ddy + ox * ddx;
+                    const float contrast = fabsf(AT(z, y, x) + interp / 2.0f);
+                    const float denom = (h22 + h33) * (h22 + h33);
+                    if (denom == 0.f) continue;
+                    const float cm = 1.f - 4.f * (h22 * h33 - h23 * h23) / denom;
+                    if (0.7f <= cm && cm <= 1.5f) continue; /* edge-like: anisotropic hessian */
+                    const float size = 0.82f * sqrtf(2.0f) * exp2f((float)z + os);
+                    if (found < max_out) {
+                        extrema[4 * found + 0] = (float)x + ox;
+                        extrema[4 * found + 1] = (float)y + oy;
+                        extrema[4 * found + 2] = size;
+                        extrema[4 * found + 3] = contrast;
+                    }
+                    found++;
+                }
+            }
+#undef AT
+    if (n_total) *n_total = found;
+    return found < max_out ? found : max_out;
+}
+
+/* TopKContrastFilter::filter, vulkan/mod.rs:1753-1786: blobs with size >= min_size; if more than n remain, those
+ * whose contrast reaches the (n+1)-th largest, in index order, until n are taken.  (The reference indexes its
+ * copy of the contrasts by the ORIGINAL index while that copy holds only the blobs that passed min_size; the
+ * two coincide when min_size filters nothing, which is how its callers use it.  This restatement indexes by
+ * position, the evident intent.)  Returns the number of indices written. */
+static int cmp_desc(const void *a, const void *b)
+{
+    const float x = *(const float *)a, y = *(const float *)b;
+    return x < y ? 1 : (x > y ? -1 : 0);
+}
+
+long mkd_oracle_topk_filter(const float *extrema, long n_in, long n_keep, float min_size, unsigned *indices)
+{
+    long m = 0;
+    float *c = (float *)malloc(sizeof(float) * (n_in > 0 ? n_in : 1));
+    unsigned *idx = (unsigned *)malloc(sizeof(unsigned) * (n_in > 0 ? n_in : 1));
+    for (long i = 0; i < n_in; i++)
+        if (extrema[4 * i + 2] >= min_size) {
+            idx[m] = (unsigned)i;
+            c[m++] = fabsf(extrema[4 * i + 3]);
+        }
+    long out = 0;
+    if (m <= n_keep) {
+        for (long i = 0; i < m; i++) indices[out++] = idx[i];
+    } else {
+        float *sorted = (float *)malloc(sizeof(float) * m);
+        memcpy(sorted, c, sizeof(float) * m);
+        qsort(sorted, m, sizeof(float), cmp_desc);
+        const float cutoff = sorted[n_keep]; /* order_stat::kth(.., n): element n of the ascending -|c| */
+        for (long i = 0; i < m && out < n_keep; i++)
+            if (c[i] >= cutoff) indices[out++] = idx[i];
+        free(sorted);
+    }
+    free(c);
+    free(idx);
+    return out;
+}

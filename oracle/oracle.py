@@ -51,6 +51,13 @@ class MkdOracle:
             _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_long, ctypes.c_float, _fp]
         L.mkd_oracle_build_pyramid.argtypes = [_fp, ctypes.c_int, ctypes.c_int, _fp]
         L.mkd_oracle_patch_gradients.argtypes = [_fp, _fp, _fp, ctypes.c_int]
+        L.mkd_oracle_dog.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]
+        L.mkd_oracle_scan_extrema.restype = ctypes.c_long
+        L.mkd_oracle_scan_extrema.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_float, _fp, ctypes.c_long, ctypes.POINTER(ctypes.c_long)]
+        L.mkd_oracle_topk_filter.restype = ctypes.c_long
+        L.mkd_oracle_topk_filter.argtypes = [_fp, ctypes.c_long, ctypes.c_long, ctypes.c_float,
+                                             ctypes.POINTER(ctypes.c_uint)]
         L.mkd_oracle_quirk_pixels.argtypes = [_fp, ctypes.c_float]
         L.mkd_oracle_build_coarse_stack.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]
         L.mkd_oracle_orient.restype = ctypes.c_long
@@ -158,6 +165,45 @@ class MkdOracle:
         out = np.zeros((36 * max(len(e), 1), 5), np.float32)
         m = self.L.mkd_oracle_orient(_ptr(stack), w, h, nl, _ptr(e), len(e), _ptr(out), len(out))
         return out[:m].copy()
+
+    def dog(self, stack):
+        """fine[l] = coarse[l] - coarse[l+1] (swt_sub.glsl)."""
+        st = _f32(stack)
+        nl, h, w = st.shape
+        fine = np.zeros((nl - 1, h, w), np.float32)
+        self.L.mkd_oracle_dog(_ptr(st), w, h, nl, _ptr(fine))
+        return fine
+
+    def scan_extrema(self, fine, border=5, skip_layers=0, contrast_threshold=0.035, max_out=None):
+        """DoG volume -> (extrema [m,4] (x, y, size, contrast) in cube-raster order, total found)."""
+        f = _f32(fine)
+        nf, h, w = f.shape
+        cap = int(max_out) if max_out is not None else 1 << 20
+        out = np.zeros((max(cap, 1), 4), np.float32)
+        total = ctypes.c_long()
+        m = self.L.mkd_oracle_scan_extrema(_ptr(f), w, h, nf, border, skip_layers, contrast_threshold, _ptr(out), cap,
+                                           ctypes.byref(total))
+        return out[:m].copy(), total.value
+
+    def topk_filter(self, extrema, n, min_size=0.0):
+        """TopKContrastFilter (mod.rs:1753-1786): indices of the blobs kept, in index order."""
+        e = _f32(extrema).reshape(-1, 4)
+        idx = np.zeros(max(len(e), 1), np.uint32)
+        m = self.L.mkd_oracle_topk_filter(_ptr(e), len(e), n, min_size, idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint)))
+        return idx[:m].copy()
+
+    def detect(self, img, n_scales=4, top_n=None, min_size=0.0, max_blobs=8000, max_features=None, **kw):
+        """LocalFeaturesVulkan::detect (mod.rs:363-593) end to end: (keypoints [m,5], descriptors [m,128])."""
+        img = _f32(img)
+        st = self.build_coarse_stack(img, n_scales)
+        max_extrema = 256 * ((max_blobs + 255) // 256)            # mod.rs:279-286
+        ex, _ = self.scan_extrema(self.dog(st), max_out=max_extrema)
+        if top_n is not None:
+            ex = ex[self.topk_filter(ex, top_n, min_size)]
+        kps = self.orient(st, ex)
+        if max_features is not None:
+            kps = kps[:max_features]
+        return kps, self.describe_keypoints(img, kps[:, :4], **kw)
 
     def describe_keypoints(self, img, kps, patch_scale_factor=24.0, **kw):
         img = _f32(img)

@@ -171,3 +171,50 @@ def test_quirk_pixel_detector_and_contracted_blur(oracle):
     mag, ang = oracle.patch_gradients(sym)
     col = np.abs(ang[:, 15])
     assert ((col == 0) | (np.abs(col - np.pi / 2) < 1e-3)).all() and (col == 0).any()
+
+
+def test_detector_matches_float64_goldens(oracle):
+    """DoG + extremum scan + refinement + edge test (swt_sub.glsl, scan_extrema.glsl) and the top-K blob filter
+    (mod.rs:1753-1786) against the float64 restatement of tools/gen_golden.py."""
+    g = golden("detector.npz")
+    fine = oracle.dog(oracle.build_coarse_stack(g["image"]))
+    assert fine.shape == (6,) + g["image"].shape
+    assert np.abs(fine[2] - g["dog2"]).max() < 1e-6 and np.abs(fine[4] - g["dog4"]).max() < 1e-6
+    ex, total = oracle.scan_extrema(fine)
+    assert total == len(ex) == len(g["extrema"])
+    assert np.abs(ex[:, :2] - g["extrema"][:, :2]).max() < 1e-3            # pixels
+    assert np.abs(ex[:, 2] / g["extrema"][:, 2] - 1).max() < 1e-4          # size
+    assert np.abs(ex[:, 3] - g["extrema"][:, 3]).max() < 1e-6              # contrast
+    assert np.array_equal(oracle.topk_filter(ex, 25), g["top25"])
+
+
+def test_detector_properties(oracle):
+    # one Gaussian blob of sigma s: one extremum at its centre, size ~ 2 sigma... of the blob; sign does not matter
+    h, w = 96, 128
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    for sign in (1, -1):
+        for s, (cx, cy) in ((2.0, (40.3, 50.6)), (4.0, (70.8, 41.2))):
+            img = (0.5 + sign * 0.4 * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))).astype(np.float32)
+            ex, total = oracle.scan_extrema(oracle.dog(oracle.build_coarse_stack(img)))
+            assert total == 1, (sign, s, ex)
+            assert abs(ex[0, 0] - cx) < 0.25 and abs(ex[0, 1] - cy) < 0.25
+            assert 1.2 * s < ex[0, 2] < 2.2 * s and ex[0, 3] > 0.035
+    # a straight edge has an anisotropic hessian everywhere: rejected by the cm test; flat image: nothing
+    edge = np.where(xx > 60.5, 0.9, 0.1).astype(np.float32)
+    assert oracle.scan_extrema(oracle.dog(oracle.build_coarse_stack(edge)))[1] == 0
+    assert oracle.scan_extrema(oracle.dog(oracle.build_coarse_stack(np.full((h, w), 0.4, np.float32))))[1] == 0
+    # nothing closer than `border` to the frame, truncation at max_out keeps the head of the ordered list
+    g = golden("detector.npz")
+    fine = oracle.dog(oracle.build_coarse_stack(g["image"]))
+    ex, total = oracle.scan_extrema(fine)
+    assert ex[:, 0].min() >= 4.5 and ex[:, 1].min() >= 4.5
+    assert ex[:, 0].max() <= g["image"].shape[1] - 4.5 and ex[:, 1].max() <= g["image"].shape[0] - 4.5
+    cut, total2 = oracle.scan_extrema(fine, max_out=10)
+    assert total2 == total and np.array_equal(cut, ex[:10])
+    # top-K: fewer than n -> all; min_size filters first; kept in index order
+    assert np.array_equal(oracle.topk_filter(ex, 1000), np.arange(len(ex)))
+    big = oracle.topk_filter(ex, 1000, min_size=6.0)
+    assert (ex[big, 2] >= 6.0).all() and len(big) == (ex[:, 2] >= 6.0).sum()
+    k = oracle.topk_filter(ex, 10)
+    assert len(k) == 10 and (np.diff(k) > 0).all()
+    assert np.sort(ex[k, 3]).min() >= np.sort(ex[:, 3])[::-1][10]

@@ -237,6 +237,92 @@ def orient(stack, extrema):
     return np.array(out, np.float64).reshape(-1, 5)
 
 
+def scan_extrema(fine, border=5, skip=0, thr=float(np.float32(0.035))):
+    """shaders/scan_extrema.glsl in float64 on a given DoG volume; order: 4x4x4 cubes raster, then local index;
+    at most 8 candidates per cube.  Returns [m,4] (x, y, size, contrast)."""
+    fine = np.asarray(fine, np.float64)
+    nf, h, w = fine.shape
+    b1 = max(border, 1)
+    out = []
+    gx, gy, gz = -(-(w - 2 * border) // 4), -(-(h - 2 * border) // 4), -(-(nf - 2 - skip) // 4)
+    # candidates, vectorised: |v| > thr and sign*v >= sign*neighbour for all 26 neighbours
+    core = fine[1:-1, 1:-1, 1:-1]
+    sg = np.sign(core)
+    ok = np.abs(core) > thr
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if dz or dy or dx:
+                    nb = fine[1 + dz:nf - 1 + dz, 1 + dy:h - 1 + dy, 1 + dx:w - 1 + dx]
+                    ok &= sg * core >= sg * nb
+    cand = np.zeros(fine.shape, bool)
+    cand[1:-1, 1:-1, 1:-1] = ok
+    cand[:1 + skip] = False
+    cand[:, :b1] = False; cand[:, h - b1:] = False; cand[:, :, :b1] = False; cand[:, :, w - b1:] = False
+    zs, ys, xs = np.nonzero(cand)
+    cube = (((zs - 1 - skip) // 4) * gy + (ys - border) // 4) * gx + (xs - border) // 4
+    local = (xs - border) % 4 + 4 * ((ys - border) % 4) + 16 * ((zs - 1 - skip) % 4)
+    order = np.lexsort((local, cube))
+    seen = {}
+    A = lambda z, y, x: fine[z, y, x]
+    for i in order:
+        z, y, x = int(zs[i]), int(ys[i]), int(xs[i])
+        seen[cube[i]] = seen.get(cube[i], 0) + 1
+        if seen[cube[i]] > 8:
+            continue
+        g = np.array([(A(z + 1, y, x) - A(z - 1, y, x)) / 2, (A(z, y + 1, x) - A(z, y - 1, x)) / 2,
+                      (A(z, y, x + 1) - A(z, y, x - 1)) / 2])
+        v2 = 2 * A(z, y, x)
+        h11 = A(z + 1, y, x) + A(z - 1, y, x) - v2
+        h22 = A(z, y + 1, x) + A(z, y - 1, x) - v2
+        h33 = A(z, y, x + 1) + A(z, y, x - 1) - v2
+        h12 = (A(z + 1, y + 1, x) - A(z - 1, y + 1, x) - A(z + 1, y - 1, x) + A(z - 1, y - 1, x)) / 4
+        h13 = (A(z + 1, y, x + 1) - A(z - 1, y, x + 1) - A(z + 1, y, x - 1) + A(z - 1, y, x - 1)) / 4
+        h23 = (A(z, y + 1, x + 1) - A(z, y + 1, x - 1) - A(z, y - 1, x + 1) + A(z, y - 1, x - 1)) / 4
+        H = np.array([[h11, h12, h13], [h12, h22, h23], [h13, h23, h33]])
+        if np.linalg.det(H) == 0:
+            off = np.full(3, np.nan)
+        else:
+            off = -np.linalg.solve(H, g)          # the shader spells out the adjugate; same thing
+        if (np.abs(off) > 0.5).any():
+            continue
+        contrast = abs(A(z, y, x) + off @ g / 2)
+        denom = (h22 + h33) ** 2
+        if denom == 0:
+            continue
+        cm = 1 - 4 * (h22 * h33 - h23 * h23) / denom
+        if 0.7 <= cm <= 1.5:
+            continue
+        size = float(np.float32(0.82)) * np.sqrt(2.0) * 2.0 ** (z + off[0])
+        out.append((x + off[2], y + off[1], size, contrast))
+    return np.array(out, np.float64).reshape(-1, 4)
+
+
+def topk_filter(extrema, n, min_size=0.0):
+    """TopKContrastFilter (vulkan/mod.rs:1753-1786), indexing by position (see the C oracle's note)."""
+    idx = np.flatnonzero(extrema[:, 2] >= min_size)
+    c = np.abs(extrema[idx, 3])
+    if len(idx) <= n:
+        return idx
+    cutoff = np.sort(c)[::-1][n]
+    return idx[c >= cutoff][:n]
+
+
+def blob_image(w, h, seed, n_blobs=60):
+    """Gaussian blobs of both signs and several sizes on a mid-grey ground: DoG extrema well above threshold."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.full((h, w), 0.5)
+    for _ in range(n_blobs):
+        cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+        s = rng.uniform(1.2, 9.0)
+        a = rng.uniform(0.15, 0.45) * rng.choice([-1, 1])
+        e = rng.uniform(0.6, 1.0)                      # some elongated ones for the edge test
+        img += a * np.exp(-((xx - cx) ** 2 + ((yy - cy) / e) ** 2) / (2 * s * s))
+    img += rng.normal(0, 0.004, img.shape)
+    return np.clip(img, 0, 1).astype(np.float32)
+
+
 def random_extrema(n, w, h, seed, n_scales=4):
     """sizes as the detector emits them: 0.82 sqrt2 2^(z+delta), z in [1, n_scales] (scan_extrema.glsl:229)."""
     rng = np.random.default_rng(seed)
@@ -317,6 +403,16 @@ def main():
                         layer2=st[2].astype(np.float32), layer5=st[5].astype(np.float32),
                         keypoints=ok.astype(np.float32))
     print("orientation goldens:", ex.shape, "->", ok.shape)
+    # detector: blobs frame -> a-trous stack (f64) -> DoG; extremum scan in f64 on the f32-rounded DoG volume, so
+    # that the fixture checks the scan logic and the refinement arithmetic, not ties between roundings
+    bimg = blob_image(224, 160, 17, n_blobs=160)
+    bst = coarse_stack(bimg)
+    fine32 = (bst[:-1] - bst[1:]).astype(np.float32)
+    bex = scan_extrema(fine32)
+    keep = topk_filter(bex, 25)
+    np.savez_compressed(os.path.join(GOLDEN, "detector.npz"), image=bimg, dog2=fine32[2], dog4=fine32[4],
+                        extrema=bex.astype(np.float32), top25=keep.astype(np.uint32))
+    print("detector goldens:", bimg.shape, "->", bex.shape, "extrema; top-25 keeps", len(keep))
     phi, ep, ec = luts()
     np.savez_compressed(os.path.join(GOLDEN, "luts.npz"), gradient_angle=phi.astype(np.float32),
                         embedding_polar=ep.astype(np.float32), embedding_cartesian=ec.astype(np.float32))
