@@ -73,7 +73,9 @@ typedef struct {
                                    multi-frame entry points (default 1)                         */
     uint32_t n_scales;          /* BuildTimeParams.n_scales (lib.rs:60, default 4): keypoint orientation
                                    reads an a-trous stack of n_scales + 3 layers                */
-    uint32_t reserved[2];
+    uint32_t max_blobs;         /* BuildTimeParams.max_blobs (lib.rs:58, default 8000): extrema the detector keeps
+                                   per frame, rounded up to a multiple of 256 (mod.rs:279-286)   */
+    uint32_t reserved[1];
 } lf_mkd_params;
 
 /* Keypoint as the path consumes it: struct Keypoint, lib.rs:17-24 (angle in DEGREES,
@@ -169,6 +171,37 @@ int lf_mkd_orient_keypoints_device(lf_mkd *h, const lf_mkd_extremum *d_extrema,
                                    const uint32_t *d_frame_of_extremum, uint64_t n,
                                    lf_mkd_keypoint *d_out, uint32_t *d_frame_of_kp, uint64_t max_out,
                                    uint64_t *n_out, uint64_t *n_dropped, void *stream);
+
+/* Detector: the detect task graph after the a-trous stack (swt_sub.glsl, scan_extrema.glsl; constants
+ * border = 5, contrast threshold 0.035, skip_layers = 0: mod.rs:76,395-407).  Needs lf_mkd_set_image*.
+ * Scans the DoG volume of every loaded frame for 3-D extrema, refines them and applies the edge test;
+ * writes {x + dx, y + dy, size, contrast} in a DEFINED order (the reference appends atomically): by frame,
+ * then 4x4x4 scan cube in raster order (z, y, x), then position x + 4 y + 16 z in the cube.  A cube keeps at
+ * most 8 candidates like the reference, here the first 8 in that order.  At most max_out are written;
+ * *n_out = written, *n_dropped (may be NULL) = found beyond max_out (dropped_blobs, mod.rs:625-633).
+ * d_frame_of (may be NULL) receives each extremum's frame.  n_out / n_dropped are HOST pointers: waits for
+ * `stream`. */
+int lf_mkd_detect_extrema_device(lf_mkd *h, lf_mkd_extremum *d_out, uint32_t *d_frame_of, uint64_t max_out,
+                                 uint64_t *n_out, uint64_t *n_dropped, void *stream);
+int lf_mkd_detect_extrema(lf_mkd *h, lf_mkd_extremum *out, uint64_t max_out, uint64_t *n_out,
+                          uint64_t *n_dropped);
+
+/* The host blob filter of detect_top_n on the device (TopKContrastFilter, mod.rs:1753-1786): of the n
+ * extrema of ONE frame keep those with size >= min_size and, if more than top_n remain, the top_n with the
+ * largest contrast (ties at the cut resolved in index order); index order is preserved.  d_out [top_n]
+ * receives the kept extrema, d_index (may be NULL) their indices into d_extrema.  *n_out on the host. */
+int lf_mkd_filter_extrema_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, uint64_t n, uint32_t top_n,
+                                 float min_size, lf_mkd_extremum *d_out, uint32_t *d_index, uint64_t *n_out,
+                                 void *stream);
+
+/* LocalFeaturesVulkan::detect / detect_top_n (mod.rs:346-593) in one call, host pointers, synchronous:
+ * image -> pyramid + a-trous stack -> extrema (at most max_blobs) -> [top_n filter if top_n > 0] ->
+ * orientation -> sampling -> descriptors.  keypoints [max_out] and descriptors [max_out][128] receive
+ * *n_out <= max_out results; *dropped_blobs and *dropped_features (may be NULL) as FeaturesResult
+ * (lib.rs:77-83). */
+int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height, uint32_t top_n,
+                  float min_size, lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out,
+                  uint64_t *n_out, uint64_t *dropped_blobs, uint64_t *dropped_features);
 
 /* Verification tap: copies layer `layer` (0 .. n_scales + 2) of frame 0's a-trous stack to a host
  * buffer of width x height floats, building the stack first if needed. */

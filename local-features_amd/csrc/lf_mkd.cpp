@@ -41,6 +41,12 @@ struct lf_mkd {
     unsigned *d_counts = nullptr;
     uint64_t kps_out_cap = 0;
     unsigned long long *d_totals = nullptr;
+    // detector scratch (allocated on first use): per-cube slots and counts for max_frames frames of the maximum size
+    uint64_t max_extrema = 8192;
+    float *d_slots = nullptr, *d_det_extrema = nullptr, *d_det_selected = nullptr, *d_det_kps = nullptr,
+          *d_det_desc = nullptr;
+    unsigned *d_cube_counts = nullptr, *d_cube_sums = nullptr, *d_sel_count = nullptr;
+    uint64_t det_out_cap = 0, det_sel_cap = 0;
     int num_cus = 256;
     // LF_MKD_FLAG_KERNEL_TIMING: (start, end) of the describe kernel per batch
     std::vector<hipEvent_t> ev_pending, ev_free;
@@ -108,6 +114,7 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     if (h->params.patch_scale_factor == 0.f) h->params.patch_scale_factor = 24.f;  // lib.rs:46
     const uint64_t mf = params->max_features ? params->max_features : 2000;        // lib.rs:69
     h->n_layers = int(params->n_scales ? params->n_scales : 4) + 3;                // lib.rs:70, mod.rs:1093
+    h->max_extrema = 256 * ((uint64_t(params->max_blobs ? params->max_blobs : 8000) + 255) / 256);  // mod.rs:279-286
     h->batch = (mf + 63) / 64 * 64;
     auto bail = [&](int code) {
         g_create_error = h->err;
@@ -213,9 +220,58 @@ int ensure_orient_scratch(lf_mkd *h, uint64_t n, bool staging, uint64_t max_out)
         if (h->d_kps_out) (void)hipFree(h->d_kps_out);
         h->d_kps_out = nullptr;
         h->kps_out_cap = 0;
+        if (h->d_det_desc) (void)hipFree(h->d_det_desc);
+        h->d_det_desc = nullptr;
         LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_kps_out), max_out * sizeof(lf_mkd_keypoint)));
+        LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_det_desc), max_out * kOut * 4));   // lf_mkd_detect's staging
         h->kps_out_cap = max_out;
     }
+    return LF_MKD_OK;
+}
+
+constexpr int kBorder = 5;                  // mod.rs:405
+constexpr float kContrastThreshold = 0.035f; // mod.rs:76
+constexpr int kSkipLayers = 0;              // mod.rs:398
+
+int ensure_detect_scratch(lf_mkd *h) {
+    if (h->d_slots) return LF_MKD_OK;
+    int gx, gy, gz;
+    scan_grid(int(h->params.max_image_width), int(h->params.max_image_height), h->n_layers - 1, kBorder, kSkipLayers, gx,
+              gy, gz);
+    const size_t cubes = std::max<size_t>(size_t(gx) * gy * gz, 1) * h->max_frames;
+    LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_slots), cubes * 8 * 4 * sizeof(float)));
+    LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_cube_counts), cubes * 4));
+    LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_cube_sums), ((cubes + 1023) / 1024 + 1) * 4));
+    LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_sel_count), 4 * h->max_frames));
+    return LF_MKD_OK;
+}
+
+// ordered extrema of all loaded frames into d_out (device), counts to the host
+int detect_extrema_device(lf_mkd *h, float *d_out, uint32_t *d_frame_of, uint64_t max_out, uint64_t *n_out,
+                          uint64_t *n_dropped, hipStream_t s) {
+    if (int rc = ensure_coarse_stack(h, s)) return rc;
+    if (int rc = ensure_detect_scratch(h)) return rc;
+    launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride,
+                          h->n_layers, h->pd.w[0], h->pd.h[0], int(h->n_frames), kBorder, kSkipLayers, kContrastThreshold,
+                          h->d_slots, h->d_cube_counts, h->d_cube_sums, d_out, d_frame_of, nullptr, max_out, h->d_totals,
+                          s);
+    LF_HIP(h, hipGetLastError());
+    unsigned long long totals[2] = {0, 0};
+    LF_HIP(h, hipMemcpyAsync(totals, h->d_totals, sizeof(totals), hipMemcpyDeviceToHost, s));
+    LF_HIP(h, hipStreamSynchronize(s));
+    *n_out = totals[0];
+    if (n_dropped) *n_dropped = totals[1];
+    return LF_MKD_OK;
+}
+
+template <typename T>
+int grow(lf_mkd *h, T **p, uint64_t *cap, uint64_t want, size_t elem_bytes) {
+    if (want <= *cap && *p) return LF_MKD_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    LF_HIP(h, hipMalloc(reinterpret_cast<void **>(p), std::max<uint64_t>(want, 1) * elem_bytes));
+    *cap = want;
     return LF_MKD_OK;
 }
 
@@ -285,7 +341,9 @@ void lf_mkd_destroy(lf_mkd *h) {
     void *ptrs[] = {h->dc.phi_cs,      h->dc.colmap,     h->dc.pool_b_f32, h->dc.pool_b_f16, h->dc.white_a_f16,
                     h->dc.white_a_f32, h->dc.white_bias, h->d_patches,     h->d_out,         h->d_kps,
                     h->d_image,        h->d_pyr,         h->d_tmp_a,       h->d_tmp_b,       h->d_coarse,
-                    h->d_extrema,      h->d_angles,      h->d_counts,      h->d_kps_out,     h->d_totals};
+                    h->d_extrema,      h->d_angles,      h->d_counts,      h->d_kps_out,     h->d_totals,
+                    h->d_slots,        h->d_det_extrema, h->d_det_selected, h->d_det_kps,    h->d_det_desc,
+                    h->d_cube_counts,  h->d_cube_sums,   h->d_sel_count};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev_pending) (void)hipEventDestroy(e);
@@ -497,6 +555,100 @@ int lf_mkd_orient_keypoints(lf_mkd *h, const lf_mkd_extremum *extrema, uint64_t 
     if (int rc = orient_device(h, h->d_extrema, nullptr, n, h->d_kps_out, nullptr, max_out, n_out, n_dropped, h->stream))
         return rc;
     if (*n_out) LF_HIP(h, hipMemcpy(out, h->d_kps_out, *n_out * sizeof(lf_mkd_keypoint), hipMemcpyDeviceToHost));
+    return LF_MKD_OK;
+}
+
+int lf_mkd_detect_extrema_device(lf_mkd *h, lf_mkd_extremum *d_out, uint32_t *d_frame_of, uint64_t max_out,
+                                 uint64_t *n_out, uint64_t *n_dropped, void *stream) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!n_out) return fail(h, LF_MKD_ERR_BAD_ARG, "detect_extrema_device: n_out is null");
+    *n_out = 0;
+    if (n_dropped) *n_dropped = 0;
+    if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "detect_extrema: call lf_mkd_set_image first");
+    if (!d_out && max_out) return fail(h, LF_MKD_ERR_BAD_ARG, "detect_extrema_device: null pointer");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    return detect_extrema_device(h, reinterpret_cast<float *>(d_out), d_frame_of, max_out, n_out, n_dropped, s);
+}
+
+int lf_mkd_detect_extrema(lf_mkd *h, lf_mkd_extremum *out, uint64_t max_out, uint64_t *n_out, uint64_t *n_dropped) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!n_out) return fail(h, LF_MKD_ERR_BAD_ARG, "detect_extrema: n_out is null");
+    *n_out = 0;
+    if (n_dropped) *n_dropped = 0;
+    if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "detect_extrema: call lf_mkd_set_image first");
+    if (!out && max_out) return fail(h, LF_MKD_ERR_BAD_ARG, "detect_extrema: null pointer");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, max_out, sizeof(lf_mkd_extremum))) return rc;
+    if (int rc = detect_extrema_device(h, h->d_det_extrema, nullptr, max_out, n_out, n_dropped, h->stream)) return rc;
+    if (*n_out) LF_HIP(h, hipMemcpy(out, h->d_det_extrema, *n_out * sizeof(lf_mkd_extremum), hipMemcpyDeviceToHost));
+    return LF_MKD_OK;
+}
+
+int lf_mkd_filter_extrema_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, uint64_t n, uint32_t top_n, float min_size,
+                                 lf_mkd_extremum *d_out, uint32_t *d_index, uint64_t *n_out, void *stream) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!n_out) return fail(h, LF_MKD_ERR_BAD_ARG, "filter_extrema_device: n_out is null");
+    *n_out = 0;
+    if (n == 0 || top_n == 0) return LF_MKD_OK;
+    if (!d_extrema || !d_out) return fail(h, LF_MKD_ERR_BAD_ARG, "filter_extrema_device: null pointer");
+    if (n > 0xFFFFFFFFull) return fail(h, LF_MKD_ERR_BAD_ARG, "filter_extrema_device: more than 2^32 extrema");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    if (!h->d_sel_count) LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_sel_count), 4 * h->max_frames));
+    launch_topk_filter(reinterpret_cast<const float *>(d_extrema), nullptr, nullptr, n, 1, top_n, min_size,
+                       reinterpret_cast<float *>(d_out), d_index, h->d_sel_count, s);
+    LF_HIP(h, hipGetLastError());
+    unsigned cnt = 0;
+    LF_HIP(h, hipMemcpyAsync(&cnt, h->d_sel_count, 4, hipMemcpyDeviceToHost, s));
+    LF_HIP(h, hipStreamSynchronize(s));
+    *n_out = cnt;
+    return LF_MKD_OK;
+}
+
+int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height, uint32_t top_n, float min_size,
+                  lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out, uint64_t *n_out,
+                  uint64_t *dropped_blobs, uint64_t *dropped_features) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!n_out) return fail(h, LF_MKD_ERR_BAD_ARG, "detect: n_out is null");
+    *n_out = 0;
+    if (dropped_blobs) *dropped_blobs = 0;
+    if (dropped_features) *dropped_features = 0;
+    if (max_out && (!keypoints || !descriptors)) return fail(h, LF_MKD_ERR_BAD_ARG, "detect: null output pointer");
+    if (int rc = lf_mkd_set_image(h, image, width, height)) return rc;
+    if (h->n_frames != 1) return fail(h, LF_MKD_ERR_BAD_ARG, "detect: one frame at a time");
+    hipStream_t s = h->stream;
+    // detect graph: extrema, at most max_extrema of them (mod.rs:625-633)
+    if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, h->max_extrema, sizeof(lf_mkd_extremum))) return rc;
+    uint64_t n_ext = 0;
+    if (int rc = detect_extrema_device(h, h->d_det_extrema, nullptr, h->max_extrema, &n_ext, dropped_blobs, s)) return rc;
+    // host blob filter of detect_top_n, on the device
+    const float *d_sel = h->d_det_extrema;
+    if (top_n && n_ext) {
+        if (int rc = grow(h, &h->d_det_selected, &h->det_sel_cap, top_n, sizeof(lf_mkd_extremum))) return rc;
+        uint64_t n_sel = 0;
+        if (int rc = lf_mkd_filter_extrema_device(h, reinterpret_cast<const lf_mkd_extremum *>(h->d_det_extrema), n_ext,
+                                                  top_n, min_size, reinterpret_cast<lf_mkd_extremum *>(h->d_det_selected),
+                                                  nullptr, &n_sel, s))
+            return rc;
+        d_sel = h->d_det_selected;
+        n_ext = n_sel;
+    }
+    if (n_ext == 0 || max_out == 0) return LF_MKD_OK;
+    // extract graph: orientation, sampling, description
+    if (int rc = ensure_orient_scratch(h, n_ext, true, max_out)) return rc;
+    uint64_t n_kp = 0;
+    if (int rc = orient_device(h, d_sel, nullptr, n_ext, h->d_kps_out, nullptr, max_out, &n_kp, dropped_features, s))
+        return rc;
+    if (n_kp == 0) return LF_MKD_OK;
+    static_assert(sizeof(lf_mkd_keypoint) == 20, "keypoint layout");
+    if (int rc = lf_mkd_describe_keypoints_device(h, reinterpret_cast<const lf_mkd_keypoint *>(h->d_kps_out), n_kp,
+                                                  h->d_det_desc, s))
+        return rc;
+    LF_HIP(h, hipMemcpyAsync(keypoints, h->d_kps_out, n_kp * sizeof(lf_mkd_keypoint), hipMemcpyDeviceToHost, s));
+    LF_HIP(h, hipMemcpyAsync(descriptors, h->d_det_desc, n_kp * kOut * 4, hipMemcpyDeviceToHost, s));
+    LF_HIP(h, hipStreamSynchronize(s));
+    *n_out = n_kp;
     return LF_MKD_OK;
 }
 

@@ -50,4 +50,19 @@ void launch_orient(const float *layer0, long layer0_stride, const float *coarse,
                    unsigned *counts, float *kps, unsigned *frame_of_kp, unsigned long long max_out,
                    unsigned long long *totals, hipStream_t stream);
 
+// cubes of the extremum scan for a w x h frame with n_fine DoG layers (tasks_detect.rs:300-310)
+void scan_grid(int w, int h, int n_fine, int border, int skip_layers, int &gx, int &gy, int &gz);
+// a-trous stack -> extrema [<= max_out][4] of all frames, ordered by frame, cube (raster), lane; scratch: slots
+// [frames*cubes][8][4], counts [frames*cubes], sums [ceil(frames*cubes/1024)]; totals[0] = written, [1] = dropped
+void launch_detect_extrema(const float *layer0, long layer0_stride, const float *coarse, long coarse_stride,
+                           long layer_stride, int n_layers, int w, int h, int frames, int border, int skip_layers,
+                           float contrast_threshold, float *slots, unsigned *counts, unsigned *sums, float *extrema,
+                           unsigned *frame_of, unsigned *frame_start, unsigned long long max_out,
+                           unsigned long long *totals, hipStream_t stream);
+// per frame: blobs with size >= min_size, the n_keep best by contrast, index order; out [n_frames][n_keep][4]
+// (the number of extrema is read from n_in on the device, or taken from n_host when n_in is null)
+void launch_topk_filter(const float *extrema, const unsigned *seg_start, const unsigned long long *n_in,
+                        unsigned long long n_host, unsigned n_frames, unsigned n_keep, float min_size, float *out,
+                        unsigned *out_index, unsigned *out_count, hipStream_t stream);
+
 }  // namespace lfmkd

@@ -958,6 +958,291 @@ __global__ __launch_bounds__(1024) void orient_compact(const float *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Detector: DoG + 3-D extremum scan + quadratic refinement + edge test (swt_sub.glsl:17-30,
+// scan_extrema.glsl:36-241).  The reference works in 4x4x4 cubes with at most 8 candidates each; a cube is
+// exactly one wavefront here (lane = x + 4 y + 16 z), so "which 8" and the order of the survivors are settled
+// by ballots in lane order instead of atomics.  The DoG is never written to HBM: each wave differences the
+// a-trous layers into its 6x6x6 LDS cube (the subtraction is the same single f32 operation either way).
+// Output per cube: count + up to 8 slots {x, y, size, contrast}; cubes_compact_* turn that into the ordered list.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ layer0, long layer0_stride,
+                                                    const float *__restrict__ coarse, long coarse_stride,
+                                                    long layer_stride, int n_fine, int w, int h, int border,
+                                                    int skip_layers, float contrast_threshold, int gx, int gy, int gz,
+                                                    float *__restrict__ slots /*[frames*cubes][8][4]*/,
+                                                    unsigned *__restrict__ counts /*[frames*cubes]*/) {
+#pragma clang fp contract(off)
+    __shared__ float s_cube[4][216];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ncubes = gx * gy * gz;
+    const int cube_raw = blockIdx.x * 4 + wave;
+    const bool live = cube_raw < ncubes;
+    const int cube = live ? cube_raw : ncubes - 1;
+    const unsigned f = blockIdx.y;
+    const int cx = cube % gx, cy = (cube / gx) % gy, cz = cube / (gx * gy);
+    const int x0 = cx * 4 + border, y0 = cy * 4 + border, z0 = cz * 4 + 1 + skip_layers;
+    const float *l0 = layer0 + f * layer0_stride, *cs = coarse + f * coarse_stride;
+    float *cb = s_cube[wave];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        if (i < 216) {
+            const int zz = i / 36, r = i - zz * 36, yy = r / 6, xx = r - yy * 6;
+            const int x = x0 - 1 + xx, y = y0 - 1 + yy, z = z0 - 1 + zz;
+            float v = 0.f;
+            if (x >= 0 && x < w && y >= 0 && y < h && z >= 0 && z < n_fine) {
+                const size_t o = (size_t)y * w + x;
+                const float a = z == 0 ? l0[o] : cs[(size_t)(z - 1) * layer_stride + o];
+                v = a - cs[(size_t)z * layer_stride + o];   // fine[z] = coarse[z] - coarse[z+1]
+            }
+            cb[i] = v;
+        }
+    }
+    __syncthreads();
+    const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
+    const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
+    const int c = (lz + 1) * 36 + (ly + 1) * 6 + (lx + 1);
+    auto at = [&](int dz, int dy, int dx) { return cb[c + dz * 36 + dy * 6 + dx]; };
+    const int b1 = border > 1 ? border : 1;
+    const float val = cb[c];
+    bool cand = !(x < b1 || x >= w - b1 || y < b1 || y >= h - b1 || z <= 0 || z >= n_fine - 1) &&
+                fabsf(val) > contrast_threshold;
+    if (cand) {
+        const float sgn = glsl_sign(val), sv = sgn * val;
+#pragma unroll
+        for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx)
+                    if (dz || dy || dx) cand = cand && sv >= sgn * at(dz, dy, dx);
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long cm = __ballot(cand);
+    bool emit = false;
+    float ox = 0.f, oy = 0.f, size = 0.f, contrast = 0.f;
+    if (cand && __popcll(cm & below) < 8) {   // max_wg_extrema = 8 (scan_extrema.glsl:28)
+        const float dds = (at(1, 0, 0) - at(-1, 0, 0)) / 2.0f;
+        const float ddy = (at(0, 1, 0) - at(0, -1, 0)) / 2.0f;
+        const float ddx = (at(0, 0, 1) - at(0, 0, -1)) / 2.0f;
+        const float value2x = val * 2.0f;
+        const float h11 = at(1, 0, 0) + at(-1, 0, 0) - value2x;
+        const float h22 = at(0, 1, 0) + at(0, -1, 0) - value2x;
+        const float h33 = at(0, 0, 1) + at(0, 0, -1) - value2x;
+        const float h12 = (at(1, 1, 0) - at(-1, 1, 0) - at(1, -1, 0) + at(-1, -1, 0)) / 4.0f;
+        const float h13 = (at(1, 0, 1) - at(-1, 0, 1) - at(1, 0, -1) + at(-1, 0, -1)) / 4.0f;
+        const float h23 = (at(0, 1, 1) - at(0, 1, -1) - at(0, -1, 1) + at(0, -1, -1)) / 4.0f;
+        const float det = h11 * h22 * h33 - h11 * h23 * h23 - h12 * h12 * h33 + 2.f * h12 * h13 * h23 - h13 * h13 * h22;
+        const float hinv11 = (h22 * h33 - h23 * h23) / det;
+        const float hinv12 = (h13 * h23 - h12 * h33) / det;
+        const float hinv13 = (h12 * h23 - h13 * h22) / det;
+        const float hinv22 = (h11 * h33 - h13 * h13) / det;
+        const float hinv23 = (h12 * h13 - h11 * h23) / det;
+        const float hinv33 = (h11 * h22 - h12 * h12) / det;
+        const float os = -(hinv11 * dds + hinv12 * ddy + hinv13 * ddx);
+        oy = -(hinv12 * dds + hinv22 * ddy + hinv23 * ddx);
+        ox = -(hinv13 * dds + hinv23 * ddy + hinv33 * ddx);
+        // |offset| > 0.5 in any direction: the shader moves x, y, z and emits nothing (lines 200-203).
+        // A singular hessian gives NaN offsets; the shader would emit NaN coordinates, here it is dropped.
+        const bool inside = fabsf(ox) <= 0.5f && fabsf(oy) <= 0.5f && fabsf(os) <= 0.5f;
+        const float interp = os * dds + oy * ddy + ox * ddx;
+        contrast = fabsf(val + interp / 2.0f);
+        const float denom = (h22 + h33) * (h22 + h33);
+        const float cmv = 1.f - 4.f * (h22 * h33 - h23 * h23) / denom;
+        emit = inside && denom != 0.f && !(0.7f <= cmv && cmv <= 1.5f);
+        size = 0.82f * 1.41421356237f * exp2f((float)z + os);
+    }
+    const unsigned long long em = __ballot(emit);
+    if (live) {
+        const size_t g = (size_t)f * ncubes + cube;
+        if (emit) {
+            float *o = slots + (g * 8 + __popcll(em & below)) * 4;
+            o[0] = (float)x + ox;
+            o[1] = (float)y + oy;
+            o[2] = size;
+            o[3] = contrast;
+        }
+        if (lane == 0) counts[g] = (unsigned)__popcll(em);
+    }
+}
+
+// Ordered compaction of per-cube slots, three small launches: (1) sums of 1024 counts, (2) one workgroup scans the
+// sums, (3) every workgroup rescans its 1024 counts from its base and copies the slots.  Item i belongs to frame
+// i / items_per_frame; frame_start[f] (optional) receives the offset of the frame's first extremum.
+__global__ __launch_bounds__(1024) void cubes_block_sums(const unsigned *__restrict__ counts, long n,
+                                                         unsigned *__restrict__ sums) {
+    __shared__ unsigned ws[16];
+    const long i = (long)blockIdx.x * 1024 + threadIdx.x;
+    unsigned v = i < n ? counts[i] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int k = 0; k < 16; ++k) t += ws[k];
+        sums[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void cubes_scan_sums(unsigned *__restrict__ sums, long nb, unsigned long long max_out,
+                                                        unsigned long long *__restrict__ totals) {
+    __shared__ unsigned ws[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long base = 0;
+    for (long chunk = 0; chunk < nb; chunk += 1024) {
+        const long i = chunk + threadIdx.x;
+        const unsigned c = i < nb ? sums[i] : 0u;
+        unsigned incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        unsigned before = 0, all = 0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const unsigned t = ws[v];
+            before += v < wave ? t : 0u;
+            all += t;
+        }
+        if (i < nb) sums[i] = (unsigned)(base + before + incl - c);   // exclusive offset of the block
+        base += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[0] = base < max_out ? base : max_out;
+        totals[1] = base < max_out ? 0ull : base - max_out;
+    }
+}
+
+__global__ __launch_bounds__(1024) void cubes_scatter(const unsigned *__restrict__ counts,
+                                                      const float *__restrict__ slots,
+                                                      const unsigned *__restrict__ block_offsets, long n,
+                                                      long items_per_frame, float *__restrict__ out /*[max_out][4]*/,
+                                                      unsigned *__restrict__ frame_of, unsigned *__restrict__ frame_start,
+                                                      unsigned long long max_out) {
+    __shared__ unsigned ws[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 1024 + threadIdx.x;
+    const unsigned c = i < n ? counts[i] : 0u;
+    unsigned incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    unsigned before = 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) before += v < wave ? ws[v] : 0u;
+    const unsigned long long first = (unsigned long long)block_offsets[blockIdx.x] + before + incl - c;
+    if (i >= n) return;
+    const unsigned f = (unsigned)(i / items_per_frame);
+    if (frame_start && i == (long)f * items_per_frame) frame_start[f] = (unsigned)(first < max_out ? first : max_out);
+    for (unsigned j = 0; j < c; ++j) {
+        const unsigned long long o = first + j;
+        if (o < max_out) {
+            *reinterpret_cast<f32x4 *>(out + o * 4) = *reinterpret_cast<const f32x4 *>(slots + ((size_t)i * 8 + j) * 4);
+            if (frame_of) frame_of[o] = f;
+        }
+    }
+}
+
+// TopKContrastFilter::filter (vulkan/mod.rs:1753-1786) for one frame's extrema [n][4], one workgroup per frame:
+// keep blobs with size >= min_size; if more than n_keep remain, find the (n_keep+1)-th largest contrast (radix
+// select on the float bits, contrast >= 0) and keep, in index order, the first n_keep blobs that reach it.
+// seg_start[f], seg_start[f+1] delimit frame f (seg_start == nullptr: one segment [0, *n_in)).
+// out: gathered extrema from out_base(f) = f * n_keep; out_count[f].
+__global__ __launch_bounds__(1024) void topk_filter(const float *__restrict__ extrema, const unsigned *__restrict__ seg_start,
+                                                    const unsigned long long *__restrict__ n_in,
+                                                    unsigned long long n_host, unsigned n_frames,
+                                                    unsigned n_keep, float min_size, float *__restrict__ out,
+                                                    unsigned *__restrict__ out_index, unsigned *__restrict__ out_count) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned ws[16];
+    __shared__ unsigned sh_prefix, sh_rank, sh_m;
+    const unsigned f = blockIdx.x;
+    const unsigned total = (unsigned)(n_in ? n_in[0] : n_host);   // count on the device, or given by the host
+    unsigned lo = seg_start ? seg_start[f] : 0u;
+    unsigned hi = seg_start ? (f + 1 < n_frames ? seg_start[f + 1] : total) : total;
+    lo = lo < total ? lo : total;
+    hi = hi < total ? hi : total;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto key_of = [&](unsigned i) { return __float_as_uint(fabsf(extrema[(size_t)i * 4 + 3])); };
+    auto passes = [&](unsigned i) { return extrema[(size_t)i * 4 + 2] >= min_size; };
+    // how many pass min_size
+    if (threadIdx.x == 0) sh_m = 0;
+    __syncthreads();
+    unsigned mine = 0;
+    for (unsigned i = lo + threadIdx.x; i < hi; i += 1024) mine += passes(i) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0) atomicAdd(&sh_m, mine);
+    __syncthreads();
+    const unsigned m = sh_m;
+    unsigned cutoff = 0;   // key threshold; 0 keeps everything that passes
+    if (m > n_keep) {
+        // radix select, most significant byte first: rank n_keep (0-based) in descending key order
+        unsigned prefix = 0, rank = n_keep;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int b = threadIdx.x; b < 256; b += 1024) hist[b] = 0;
+            __syncthreads();
+            const unsigned mask = shift == 24 ? 0u : 0xFFFFFFFFu << (shift + 8);
+            for (unsigned i = lo + threadIdx.x; i < hi; i += 1024)
+                if (passes(i)) {
+                    const unsigned k = key_of(i);
+                    if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+                }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned r = rank, b = 255;
+                for (;; --b) {   // walk down from the largest byte value
+                    if (r < hist[b]) break;
+                    r -= hist[b];
+                    if (b == 0) break;
+                }
+                sh_prefix = prefix | (b << shift);
+                sh_rank = r;
+            }
+            __syncthreads();
+            prefix = sh_prefix;
+            rank = sh_rank;
+            __syncthreads();
+        }
+        cutoff = prefix;
+    }
+    // ordered compaction of {passes && key >= cutoff}, first n_keep
+    unsigned base = 0;
+    for (unsigned chunk = lo; chunk < hi && base < n_keep; chunk += 1024) {
+        const unsigned i = chunk + threadIdx.x;
+        const bool take = i < hi && passes(i) && key_of(i) >= cutoff;
+        const unsigned long long bm = __ballot(take);
+        if (lane == 0) ws[wave] = (unsigned)__popcll(bm);
+        __syncthreads();
+        unsigned before = 0, all = 0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const unsigned t = ws[v];
+            before += v < wave ? t : 0u;
+            all += t;
+        }
+        const unsigned o = base + before + (unsigned)__popcll(bm & ((1ull << lane) - 1ull));
+        if (take && o < n_keep) {
+            const size_t dst = (size_t)f * n_keep + o;
+            *reinterpret_cast<f32x4 *>(out + dst * 4) = *reinterpret_cast<const f32x4 *>(extrema + (size_t)i * 4);
+            if (out_index) out_index[dst] = i - lo;
+        }
+        base += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_count[f] = base < n_keep ? base : n_keep;
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 void launch_describe(const float *patches, long n, const DeviceConsts &dc, int angle_mode, int pool_mode, float *out,
@@ -1045,6 +1330,42 @@ void launch_orient(const float *layer0, long layer0_stride, const float *coarse,
                            coarse, coarse_stride, layer_stride, n_layers, w, h, extrema, frame_of, n, angles, counts);
     hipLaunchKernelGGL(orient_compact, dim3(1), dim3(1024), 0, stream, extrema, frame_of, (const float *)angles,
                        (const unsigned *)counts, n, kps, frame_of_kp, max_out, totals);
+}
+
+void scan_grid(int w, int h, int n_fine, int border, int skip_layers, int &gx, int &gy, int &gz) {
+    gx = w - 2 * border > 0 ? (w - 2 * border + 3) / 4 : 0;
+    gy = h - 2 * border > 0 ? (h - 2 * border + 3) / 4 : 0;
+    gz = n_fine - 2 - skip_layers > 0 ? (n_fine - 2 - skip_layers + 3) / 4 : 0;
+}
+
+// a-trous stack -> ordered extrema of `frames` frames.  slots/counts/sums are scratch sized for frames x cubes.
+void launch_detect_extrema(const float *layer0, long layer0_stride, const float *coarse, long coarse_stride,
+                           long layer_stride, int n_layers, int w, int h, int frames, int border, int skip_layers,
+                           float contrast_threshold, float *slots, unsigned *counts, unsigned *sums, float *extrema,
+                           unsigned *frame_of, unsigned *frame_start, unsigned long long max_out,
+                           unsigned long long *totals, hipStream_t stream) {
+    int gx, gy, gz;
+    scan_grid(w, h, n_layers - 1, border, skip_layers, gx, gy, gz);
+    const long ncubes = (long)gx * gy * gz, n = ncubes * frames;
+    const long nb = (n + 1023) / 1024;
+    if (ncubes > 0) {
+        hipLaunchKernelGGL(scan_extrema, dim3((unsigned)((ncubes + 3) / 4), frames), dim3(256), 0, stream, layer0,
+                           layer0_stride, coarse, coarse_stride, layer_stride, n_layers - 1, w, h, border, skip_layers,
+                           contrast_threshold, gx, gy, gz, slots, counts);
+        hipLaunchKernelGGL(cubes_block_sums, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts, n, sums);
+    }
+    hipLaunchKernelGGL(cubes_scan_sums, dim3(1), dim3(1024), 0, stream, sums, nb, max_out, totals);
+    if (ncubes > 0)
+        hipLaunchKernelGGL(cubes_scatter, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts,
+                           (const float *)slots, (const unsigned *)sums, n, ncubes, extrema, frame_of, frame_start,
+                           max_out);
+}
+
+void launch_topk_filter(const float *extrema, const unsigned *seg_start, const unsigned long long *n_in,
+                        unsigned long long n_host, unsigned n_frames, unsigned n_keep, float min_size, float *out,
+                        unsigned *out_index, unsigned *out_count, hipStream_t stream) {
+    hipLaunchKernelGGL(topk_filter, dim3(n_frames), dim3(1024), 0, stream, extrema, seg_start, n_in, n_host, n_frames,
+                       n_keep, min_size, out, out_index, out_count);
 }
 
 }  // namespace lfmkd

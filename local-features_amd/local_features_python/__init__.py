@@ -2,13 +2,12 @@
 `local_features_python` (python/src/lib.rs:11-160) for the part of it this build covers.
 
 The reference class exposes `detect` / `detect_top_n` (detector + describe in one call,
-python/src/lib.rs:86-149); there is no public describe-only call.  This build accelerates the
-describe half, so the class keeps the constructor signature, the Keypoint
-type and the `(list[Keypoint], ndarray[n,128] f32)` result shape, and adds `describe`, which takes
-the keypoint list the detector would have produced, and `orient` / `describe_extrema`, which take the
-detector's refined extrema and run keypoint orientation first (the whole extract graph, mod.rs:1277-1572).
-`detect*` raise: the scale-space detector is a "next" row, and nothing here falls back
-to a CPU path.
+python/src/lib.rs:86-149), both provided here with the same signatures and the
+`(list[Keypoint], ndarray[n,128] f32)` result.  The hot path of this build is the describe half
+(SURVEY.md section 8), so the class also offers it on its own: `describe` takes the keypoint list the
+detector would have produced, `orient` / `describe_extrema` take the detector's refined extrema and run
+keypoint orientation first (the whole extract graph, mod.rs:1277-1572), `describe_patches` takes patches.
+Nothing here falls back to a CPU path.
 """
 import threading
 
@@ -51,8 +50,8 @@ def _keypoints_to_array(keypoints):
 
 class LocalFeatures:
     """LocalFeatures(max_image_width, max_image_height, max_features, max_blobs, n_scales, pca)
-    -- python/src/lib.rs:43-84.  n_scales sizes the a-trous stack keypoint orientation reads; max_blobs
-    belongs to the detector and is kept only for signature compatibility."""
+    -- python/src/lib.rs:43-84.  The last detect call's FeaturesResult counters (lib.rs:77-83) are kept in
+    `dropped_blobs` / `dropped_features`."""
 
     def __init__(self, max_image_width, max_image_height, max_features, max_blobs=8000, n_scales=4,
                  pca="liberty", device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_F32):
@@ -61,11 +60,13 @@ class LocalFeatures:
         try:
             self._inner = MkdHandle(pca=pca, max_features=max_features, max_image_width=max_image_width,
                                     max_image_height=max_image_height, device=device,
-                                    angle_mode=angle_mode, pool_mode=pool_mode, n_scales=n_scales)
+                                    angle_mode=angle_mode, pool_mode=pool_mode, n_scales=n_scales,
+                                    max_blobs=max_blobs)
         except RuntimeError as e:   # python/src/lib.rs:77-82
             raise RuntimeError("Failed to initialize local features", str(e)) from e
         self._lock = threading.Lock()   # Mutex<LocalFeaturesVulkan>, python/src/lib.rs:38
         self.max_blobs, self.n_scales = max_blobs, n_scales
+        self.dropped_blobs = self.dropped_features = 0
 
     def describe(self, img, keypoints):
         """img: 2-D float32 array in [0,1]; keypoints: list[Keypoint] or [n,4|5] array.
@@ -112,10 +113,21 @@ class LocalFeatures:
         with self._lock:
             return self._inner.describe_patches(patches)
 
+    def _detect(self, img, n, min_size):
+        arr = np.asarray(img)
+        if arr.ndim != 2:
+            raise RuntimeError("Failed to extract features", "image must be 2-dimensional")
+        with self._lock:
+            try:
+                kps, desc, self.dropped_blobs, self.dropped_features = self._inner.detect(arr, n, min_size)
+            except RuntimeError as e:   # python/src/lib.rs:97-102
+                raise RuntimeError("Failed to extract features", str(e)) from e
+        return [Keypoint(*row) for row in kps], desc
+
     def detect(self, img):
-        raise NotImplementedError("the scale-space detector (scan/refine extrema) is outside this build's hot path; "
-                                  "use describe(img, keypoints) or describe_extrema(img, extrema) -- SURVEY.md 8(f)")
+        """python/src/lib.rs:86-113 (detect_extract_all): every extremum the detector finds, at most max_blobs."""
+        return self._detect(img, 0, 0.0)
 
     def detect_top_n(self, img, n, min_size):
-        raise NotImplementedError("the scale-space detector (scan/refine extrema) is outside this build's hot path; "
-                                  "use describe(img, keypoints) or describe_extrema(img, extrema) -- SURVEY.md 8(f)")
+        """python/src/lib.rs:115-149: the n extrema of largest contrast among those of size >= min_size."""
+        return self._detect(img, int(n), float(min_size))

@@ -24,6 +24,7 @@ SYMBOLS = (
     "lf_mkd_describe_keypoints_device", "lf_mkd_sample_patches_device", "lf_mkd_get_pyramid_level",
     "lf_mkd_build_constants", "lf_mkd_kernel_times", "lf_mkd_synchronize", "lf_mkd_version",
     "lf_mkd_orient_keypoints", "lf_mkd_orient_keypoints_device", "lf_mkd_get_coarse_layer",
+    "lf_mkd_detect_extrema", "lf_mkd_detect_extrema_device", "lf_mkd_filter_extrema_device", "lf_mkd_detect",
 )
 
 
@@ -33,7 +34,7 @@ class Params(ctypes.Structure):
         ("max_features", ctypes.c_uint32), ("patch_scale_factor", ctypes.c_float),
         ("device", ctypes.c_int32), ("angle_mode", ctypes.c_int32), ("pool_mode", ctypes.c_int32),
         ("flags", ctypes.c_uint32), ("max_frames", ctypes.c_uint32), ("n_scales", ctypes.c_uint32),
-        ("reserved", ctypes.c_uint32 * 2),
+        ("max_blobs", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 1),
     ]
 
 
@@ -89,6 +90,11 @@ def load_library():
     L.lf_mkd_orient_keypoints_device.argtypes = [vp, vp, vp, u64, vp, vp, u64, ctypes.POINTER(u64),
                                                  ctypes.POINTER(u64), vp]
     L.lf_mkd_get_coarse_layer.argtypes = [vp, u32, vp]
+    pu64 = ctypes.POINTER(u64)
+    L.lf_mkd_detect_extrema.argtypes = [vp, vp, u64, pu64, pu64]
+    L.lf_mkd_detect_extrema_device.argtypes = [vp, vp, vp, u64, pu64, pu64, vp]
+    L.lf_mkd_filter_extrema_device.argtypes = [vp, vp, u64, u32, ctypes.c_float, vp, vp, pu64, vp]
+    L.lf_mkd_detect.argtypes = [vp, vp, u32, u32, u32, ctypes.c_float, vp, vp, u64, pu64, pu64, pu64]
     L.lf_mkd_build_constants.argtypes = [vp] * 7
     L.lf_mkd_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(u64)]
@@ -102,14 +108,15 @@ class MkdHandle:
 
     def __init__(self, pca="liberty", max_features=2000, max_image_width=0, max_image_height=0,
                  patch_scale_factor=24.0, device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_F32, flags=0,
-                 max_frames=1, n_scales=4):
+                 max_frames=1, n_scales=4, max_blobs=8000):
         self._h = None
         self.n_scales = n_scales
+        self.max_features = max_features
         self.L = load_library()
         p = Params(max_image_width=max_image_width, max_image_height=max_image_height,
                    max_features=max_features, patch_scale_factor=patch_scale_factor,
                    device=device, angle_mode=angle_mode, pool_mode=pool_mode, flags=flags,
-                   max_frames=max_frames, n_scales=n_scales)
+                   max_frames=max_frames, n_scales=n_scales, max_blobs=max_blobs)
         h = ctypes.c_void_p()
         rc = self.L.lf_mkd_create_from_file(ctypes.byref(p), model_path(pca).encode(), ctypes.byref(h))
         if rc != 0:
@@ -164,6 +171,28 @@ class MkdHandle:
                                                    ctypes.byref(dropped)), "lf_mkd_orient_keypoints")
         return out[:m.value].copy(), dropped.value
 
+    def detect_extrema(self, max_out=1 << 16):
+        """Extrema of the loaded frame(s): ([m,4] (x, y, size, contrast), dropped).  Ordered by frame, scan cube, lane."""
+        out = np.empty((max(max_out, 1), 4), np.float32)
+        m, dropped = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.L.lf_mkd_detect_extrema(self._h, out.ctypes.data, max_out, ctypes.byref(m),
+                                                 ctypes.byref(dropped)), "lf_mkd_detect_extrema")
+        return out[:m.value].copy(), dropped.value
+
+    def detect(self, img, top_n=0, min_size=0.0, max_out=None):
+        """lf_mkd_detect: (keypoints [m,5], descriptors [m,128], dropped_blobs, dropped_features)."""
+        if img.ndim != 2:
+            raise RuntimeError("image must be 2-D")
+        a = np.ascontiguousarray(img, np.float32)
+        cap = int(max_out if max_out is not None else self.max_features)
+        kps = np.empty((max(cap, 1), 5), np.float32)
+        desc = np.empty((max(cap, 1), 128), np.float32)
+        m, db, df = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.L.lf_mkd_detect(self._h, a.ctypes.data, a.shape[1], a.shape[0], top_n, min_size,
+                                         kps.ctypes.data, desc.ctypes.data, cap, ctypes.byref(m), ctypes.byref(db),
+                                         ctypes.byref(df)), "lf_mkd_detect")
+        return kps[:m.value].copy(), desc[:m.value].copy(), db.value, df.value
+
     def coarse_layer(self, layer, width, height):
         out = np.empty((height, width), np.float32)
         self._check(self.L.lf_mkd_get_coarse_layer(self._h, layer, out.ctypes.data), "lf_mkd_get_coarse_layer")
@@ -211,6 +240,18 @@ class MkdHandle:
                                                           ctypes.byref(dropped), stream),
                     "lf_mkd_orient_keypoints_device")
         return m.value, dropped.value
+
+    def detect_extrema_device(self, d_out, d_frame_of, max_out, stream=None):
+        m, dropped = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.L.lf_mkd_detect_extrema_device(self._h, d_out, d_frame_of, max_out, ctypes.byref(m),
+                                                        ctypes.byref(dropped), stream), "lf_mkd_detect_extrema_device")
+        return m.value, dropped.value
+
+    def filter_extrema_device(self, d_extrema, n, top_n, min_size, d_out, d_index=None, stream=None):
+        m = ctypes.c_uint64()
+        self._check(self.L.lf_mkd_filter_extrema_device(self._h, d_extrema, n, top_n, min_size, d_out, d_index,
+                                                        ctypes.byref(m), stream), "lf_mkd_filter_extrema_device")
+        return m.value
 
     def sample_patches_device(self, d_kps, n, d_patches, stream=None):
         self._check(self.L.lf_mkd_sample_patches_device(self._h, d_kps, n, d_patches, stream),

@@ -1,0 +1,172 @@
+"""GPU parity tests of the detector row (swt_sub.glsl + scan_extrema.glsl + the top-K blob filter) and of the whole
+detect() pipeline through the C ABI.  The extremum list is discrete (which voxels survive) plus refined values: the
+tests demand the same list in the same order as the oracle, sub-pixel positions within 1e-3 px, size within 1e-4
+relative, contrast within 1e-6."""
+import numpy as np
+import pytest
+
+from conftest import assert_keypoint_parity, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lfp():
+    import local_features_python as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "these tests need the MI355X"
+    return t
+
+
+def blob_image(w, h, seed, n_blobs=150):
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_golden import blob_image as b
+    return b(w, h, seed, n_blobs)
+
+
+def assert_same_extrema(got, want, what=""):
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    if len(want) == 0:
+        return
+    assert np.abs(got[:, :2] - want[:, :2]).max() < 1e-3, (what, np.abs(got[:, :2] - want[:, :2]).max())
+    assert np.abs(got[:, 2] / want[:, 2] - 1).max() < 1e-4, what
+    assert np.abs(got[:, 3] - want[:, 3]).max() < 1e-6, what
+
+
+def test_detector_goldens(lfp):
+    g = golden("detector.npz")
+    img = g["image"]
+    hgt, w = img.shape
+    h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt)
+    h.set_image(img)
+    ex, dropped = h.detect_extrema()
+    assert dropped == 0
+    assert_same_extrema(ex, g["extrema"], "golden")
+
+
+@pytest.mark.parametrize("w,hgt,n_scales,blobs", [(640, 480, 4, 900), (333, 257, 5, 300), (97, 64, 3, 60),
+                                                  (22, 19, 4, 6)])
+def test_extrema_vs_oracle(lfp, oracle, w, hgt, n_scales, blobs):
+    img = blob_image(w, hgt, w + 1, blobs)
+    h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt, n_scales=n_scales)
+    h.set_image(img)
+    want, total = oracle.scan_extrema(oracle.dog(oracle.build_coarse_stack(img, n_scales)))
+    got, dropped = h.detect_extrema()
+    assert dropped == 0 and total == len(want)
+    if w > 50:
+        assert len(want) > blobs // 8
+    assert_same_extrema(got, want, (w, hgt))
+    if len(want) > 10:                        # truncation keeps the head of the ordered list and counts the rest
+        cut, dropped = h.detect_extrema(max_out=10)
+        assert dropped == len(want) - 10 and np.array_equal(cut, got[:10])
+
+
+def test_extrema_edge_cases(lfp, oracle):
+    w, hgt = 128, 96
+    h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt)
+    with pytest.raises(RuntimeError, match="set_image"):
+        h.detect_extrema()
+    yy, xx = np.mgrid[0:hgt, 0:w].astype(np.float64)
+    flat = np.full((hgt, w), 0.4, np.float32)
+    edge = np.where(xx > 60.5, 0.9, 0.1).astype(np.float32)              # anisotropic hessian: edge test rejects
+    one = (0.5 - 0.4 * np.exp(-((xx - 40.3) ** 2 + (yy - 50.6) ** 2) / 8.0)).astype(np.float32)
+    checker = (0.5 + 0.45 * (((xx // 3) + (yy // 3)) % 2 - 0.5)).astype(np.float32)   # many candidates per cube
+    for name, img in (("flat", flat), ("edge", edge), ("one", one), ("checker", checker)):
+        h.set_image(img)
+        got, _ = h.detect_extrema()
+        want, _ = oracle.scan_extrema(oracle.dog(oracle.build_coarse_stack(img)))
+        assert_same_extrema(got, want, name)
+        if name == "one":
+            assert len(got) == 1 and abs(got[0, 0] - 40.3) < 0.25 and abs(got[0, 1] - 50.6) < 0.25
+        if name in ("flat", "edge"):
+            assert len(got) == 0
+
+
+def test_topk_filter_vs_oracle(lfp, torch, oracle):
+    rng = np.random.default_rng(3)
+    n = 5000
+    ex = np.stack([rng.uniform(5, 600, n), rng.uniform(5, 400, n), 0.82 * np.sqrt(2) * 2 ** rng.uniform(1, 4.4, n),
+                   rng.uniform(0.035, 0.5, n)], axis=1).astype(np.float32)
+    ex[rng.integers(0, n, 400), 3] = np.float32(0.2)          # ties, some of them exactly at a cut
+    h = lfp.MkdHandle(max_features=64)
+    d_ex = torch.from_numpy(ex).cuda()
+    for top_n, min_size in ((1, 0.0), (100, 0.0), (2000, 0.0), (4999, 0.0), (5000, 0.0), (9000, 0.0), (700, 6.0),
+                            (3000, 20.0), (10, 1e9)):
+        d_out = torch.zeros((top_n, 4), device="cuda")
+        d_idx = torch.zeros((top_n,), dtype=torch.int32, device="cuda")
+        m = h.filter_extrema_device(d_ex.data_ptr(), n, top_n, min_size, d_out.data_ptr(), d_idx.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
+        want = oracle.topk_filter(ex, top_n, min_size)
+        assert m == len(want), (top_n, min_size, m, len(want))
+        assert np.array_equal(d_idx[:m].cpu().numpy().view(np.uint32), want), (top_n, min_size)
+        assert np.array_equal(d_out[:m].cpu().numpy(), ex[want])
+    # the cut among equal contrasts: with every contrast equal, the first top_n in index order are kept
+    ex[:, 3] = 0.1
+    d_ex = torch.from_numpy(ex).cuda()
+    d_out = torch.zeros((50, 4), device="cuda")
+    d_idx = torch.zeros((50,), dtype=torch.int32, device="cuda")
+    assert h.filter_extrema_device(d_ex.data_ptr(), n, 50, 0.0, d_out.data_ptr(), d_idx.data_ptr()) == 50
+    h.synchronize()
+    assert np.array_equal(d_idx.cpu().numpy(), np.arange(50))
+
+
+def test_multi_frame_extrema(lfp, torch, oracle):
+    w, hgt, frames = 160, 120, 3
+    imgs = np.stack([blob_image(w, hgt, 50 + f, 80) for f in range(frames)])
+    h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt, max_frames=frames)
+    d_img = torch.from_numpy(imgs).cuda().contiguous()
+    s = torch.cuda.current_stream().cuda_stream
+    h.set_images_device(d_img.data_ptr(), frames, w, hgt, s)
+    d_ex = torch.zeros((4096, 4), device="cuda")
+    d_fo = torch.zeros((4096,), dtype=torch.int32, device="cuda")
+    m, dropped = h.detect_extrema_device(d_ex.data_ptr(), d_fo.data_ptr(), 4096, s)
+    per = [oracle.scan_extrema(oracle.dog(oracle.build_coarse_stack(imgs[f])))[0] for f in range(frames)]
+    assert dropped == 0 and m == sum(len(p) for p in per)
+    assert_same_extrema(d_ex[:m].cpu().numpy(), np.concatenate(per), "frames")
+    assert np.array_equal(d_fo[:m].cpu().numpy(), np.concatenate([np.full(len(p), f) for f, p in enumerate(per)]))
+
+
+@pytest.mark.parametrize("top_n", [0, 120])
+def test_detect_end_to_end(lfp, oracle, top_n):
+    """LocalFeatures.detect / detect_top_n against the oracle's restatement of LocalFeaturesVulkan::detect."""
+    w, hgt = 400, 300
+    img = blob_image(w, hgt, 7, 400)
+    lf = lfp.LocalFeatures(w, hgt, 2000, max_blobs=1000, n_scales=4, pool_mode=lfp.POOL_F16X3)
+    kps, desc = lf.detect_top_n(img, top_n, 0.0) if top_n else lf.detect(img)
+    want_k, _ = oracle.detect(img, top_n=top_n or None, max_blobs=1000)
+    got = np.array([(k.x, k.y, k.size, k.angle, k.response) for k in kps], np.float32).reshape(-1, 5)
+    assert got.shape == want_k.shape and len(got) > (100 if top_n else 200)
+    assert_same_extrema(got[:, [0, 1, 2, 4]], want_k[:, [0, 1, 2, 4]], "detect")
+    d = np.abs(got[:, 3] - want_k[:, 3])
+    # orientation windows are read at int(x), int(y): an x within 1e-4 of an integer may land in the other texel
+    close = np.minimum(d, 360 - d) < 1e-3
+    assert close.mean() > 0.99, close.mean()
+    assert desc.shape == (len(got), 128)
+    assert lf.dropped_blobs == 0 and lf.dropped_features == 0
+    lf._inner.set_image(img)
+    assert_keypoint_parity(oracle, lf._inner, img, got, desc, what="detect")
+
+
+def test_detect_counts_what_does_not_fit(lfp, oracle):
+    w, hgt = 400, 300
+    img = blob_image(w, hgt, 7, 400)
+    want_all, _ = oracle.detect(img, max_blobs=1000)
+    lf = lfp.LocalFeatures(w, hgt, 50, max_blobs=1000)
+    kps, desc = lf.detect(img)
+    assert len(kps) == 50 and desc.shape == (50, 128) and lf.dropped_features == len(want_all) - 50
+    w, hgt = 640, 480
+    img = blob_image(w, hgt, 641, 900)
+    ex, total = oracle.scan_extrema(oracle.dog(oracle.build_coarse_stack(img)))
+    lf = lfp.LocalFeatures(w, hgt, 2000, max_blobs=256)
+    kps, _ = lf.detect(img)
+    assert total > 256 and lf.dropped_blobs == total - 256
+    # the 256 blobs kept are the head of the ordered list
+    xy = np.array([(k.x, k.y) for k in kps])
+    dist = np.abs(xy[:, None, :] - ex[None, :256, :2]).max(axis=2).min(axis=1)
+    assert dist.max() < 1e-3
