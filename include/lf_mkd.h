@@ -203,6 +203,23 @@ int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height
                   float min_size, lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out,
                   uint64_t *n_out, uint64_t *dropped_blobs, uint64_t *dropped_features);
 
+/* Brute-force matcher: match_features of examples/match_images/src/main.rs:8-27.  For every row of a [na][128]:
+ * similarity = dot product with every row of b [nb][128]; best = the largest (the HIGHEST index among equal maxima,
+ * as the reference's stable sort leaves it), second = the next one down; match[i] = index of the best if
+ * best * ratio > second (the reference uses ratio = 0.8), else -1.  d_best / d_second (may be NULL) receive the
+ * two similarities.  d_exclude_lo / d_exclude_hi (may both be NULL): b rows [lo[i], hi[i]) are not candidates for
+ * a row i -- the cross-image form of BASELINE configs[3], where b is the all-gathered descriptor set and a row
+ * must not match its own image.  nb must be at least 2 (the reference indexes the second-to-last candidate).
+ * The similarities are computed on the matrix cores from f16 hi+lo splits of both sides (f32 accumulate,
+ * ~2^-21 relative): decisions can differ from an f32 dot product only where two similarities, or best*ratio and
+ * second, agree to ~1e-7.  Device pointers, asynchronous on `stream`. */
+int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d_b, uint64_t nb,
+                        const uint32_t *d_exclude_lo, const uint32_t *d_exclude_hi, float ratio,
+                        int32_t *d_match, float *d_best, float *d_second, void *stream);
+/* Host pointers, synchronous. */
+int lf_mkd_match(lf_mkd *h, const float *a, uint64_t na, const float *b, uint64_t nb, float ratio,
+                 int32_t *match);
+
 /* Verification tap: copies layer `layer` (0 .. n_scales + 2) of frame 0's a-trous stack to a host
  * buffer of width x height floats, building the stack first if needed. */
 int lf_mkd_get_coarse_layer(lf_mkd *h, uint32_t layer, float *out);

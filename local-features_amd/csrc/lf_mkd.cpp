@@ -47,6 +47,11 @@ struct lf_mkd {
           *d_det_desc = nullptr;
     unsigned *d_cube_counts = nullptr, *d_cube_sums = nullptr, *d_sel_count = nullptr;
     uint64_t det_out_cap = 0, det_sel_cap = 0;
+    // matcher scratch
+    unsigned char *d_match_a = nullptr, *d_match_b = nullptr;
+    float *d_match_part = nullptr, *d_match_in = nullptr;
+    int *d_match_out = nullptr;
+    uint64_t match_a_cap = 0, match_b_cap = 0, match_part_cap = 0, match_in_cap = 0, match_out_cap = 0;
     int num_cus = 256;
     // LF_MKD_FLAG_KERNEL_TIMING: (start, end) of the describe kernel per batch
     std::vector<hipEvent_t> ev_pending, ev_free;
@@ -343,7 +348,8 @@ void lf_mkd_destroy(lf_mkd *h) {
                     h->d_image,        h->d_pyr,         h->d_tmp_a,       h->d_tmp_b,       h->d_coarse,
                     h->d_extrema,      h->d_angles,      h->d_counts,      h->d_kps_out,     h->d_totals,
                     h->d_slots,        h->d_det_extrema, h->d_det_selected, h->d_det_kps,    h->d_det_desc,
-                    h->d_cube_counts,  h->d_cube_sums,   h->d_sel_count};
+                    h->d_cube_counts,  h->d_cube_sums,   h->d_sel_count,   h->d_match_a,     h->d_match_b,
+                    h->d_match_part,   h->d_match_in,    h->d_match_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev_pending) (void)hipEventDestroy(e);
@@ -649,6 +655,50 @@ int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height
     LF_HIP(h, hipMemcpyAsync(descriptors, h->d_det_desc, n_kp * kOut * 4, hipMemcpyDeviceToHost, s));
     LF_HIP(h, hipStreamSynchronize(s));
     *n_out = n_kp;
+    return LF_MKD_OK;
+}
+
+int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d_b, uint64_t nb,
+                        const uint32_t *d_exclude_lo, const uint32_t *d_exclude_hi, float ratio, int32_t *d_match,
+                        float *d_best, float *d_second, void *stream) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (na == 0) return LF_MKD_OK;
+    if (!d_a || !d_b || !d_match) return fail(h, LF_MKD_ERR_BAD_ARG, "match_device: null pointer");
+    if (nb < 2) return fail(h, LF_MKD_ERR_BAD_ARG, "match: needs at least two candidates in b (main.rs:20)");
+    if ((d_exclude_lo == nullptr) != (d_exclude_hi == nullptr))
+        return fail(h, LF_MKD_ERR_BAD_ARG, "match_device: exclude_lo and exclude_hi go together");
+    if (na > 0x7FFFFFFFull || nb > 0x7FFFFFFFull) return fail(h, LF_MKD_ERR_BAD_ARG, "match: more than 2^31 rows");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    const int splits = match_splits(long(na), long(nb), h->num_cus);
+    if (int rc = grow(h, &h->d_match_a, &h->match_a_cap, match_tiles_bytes(long(na)), 1)) return rc;
+    if (int rc = grow(h, &h->d_match_b, &h->match_b_cap, match_tiles_bytes(long(nb)), 1)) return rc;
+    if (int rc = grow(h, &h->d_match_part, &h->match_part_cap, uint64_t(splits) * na * 3, sizeof(float))) return rc;
+    launch_match_split(d_a, long(na), h->d_match_a, s);
+    launch_match_split(d_b, long(nb), h->d_match_b, s);
+    float *p_best = h->d_match_part, *p_second = p_best + uint64_t(splits) * na;
+    int *p_index = reinterpret_cast<int *>(p_second + uint64_t(splits) * na);
+    launch_match(h->d_match_a, long(na), h->d_match_b, long(nb), d_exclude_lo, d_exclude_hi, ratio, splits, p_best,
+                 p_index, p_second, d_match, d_best, d_second, s);
+    LF_HIP(h, hipGetLastError());
+    return LF_MKD_OK;
+}
+
+int lf_mkd_match(lf_mkd *h, const float *a, uint64_t na, const float *b, uint64_t nb, float ratio, int32_t *match) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (na == 0) return LF_MKD_OK;
+    if (!a || !b || !match) return fail(h, LF_MKD_ERR_BAD_ARG, "match: null pointer");
+    if (nb < 2) return fail(h, LF_MKD_ERR_BAD_ARG, "match: needs at least two candidates in b (main.rs:20)");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    if (int rc = grow(h, &h->d_match_in, &h->match_in_cap, (na + nb) * kOut, sizeof(float))) return rc;
+    if (int rc = grow(h, &h->d_match_out, &h->match_out_cap, na, sizeof(int))) return rc;
+    LF_HIP(h, hipMemcpyAsync(h->d_match_in, a, na * kOut * 4, hipMemcpyHostToDevice, h->stream));
+    LF_HIP(h, hipMemcpyAsync(h->d_match_in + na * kOut, b, nb * kOut * 4, hipMemcpyHostToDevice, h->stream));
+    if (int rc = lf_mkd_match_device(h, h->d_match_in, na, h->d_match_in + na * kOut, nb, nullptr, nullptr, ratio,
+                                     h->d_match_out, nullptr, nullptr, h->stream))
+        return rc;
+    LF_HIP(h, hipMemcpyAsync(match, h->d_match_out, na * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    LF_HIP(h, hipStreamSynchronize(h->stream));
     return LF_MKD_OK;
 }
 

@@ -65,4 +65,14 @@ void launch_topk_filter(const float *extrema, const unsigned *seg_start, const u
                         unsigned long long n_host, unsigned n_frames, unsigned n_keep, float min_size, float *out,
                         unsigned *out_index, unsigned *out_count, hipStream_t stream);
 
+// brute-force matcher (csrc/mkd_match.hip): x [n][128] f32 -> f16 hi/lo operand tiles (match_tiles_bytes(n) bytes);
+// a tiles against b tiles -> match [na] (index into b or -1) and optionally the best / second-best similarity.
+// p_* hold splits x na partial results; excl_lo/hi (nullable): b rows [lo[i], hi[i]) are skipped for a row i.
+size_t match_tiles_bytes(long n);
+int match_splits(long na, long nb, int num_cus);
+void launch_match_split(const float *x, long n, unsigned char *tiles, hipStream_t stream);
+void launch_match(const unsigned char *a_tiles, long na, const unsigned char *b_tiles, long nb, const unsigned *excl_lo,
+                  const unsigned *excl_hi, float ratio, int splits, float *p_best, int *p_index, float *p_second,
+                  int *match, float *best, float *second, hipStream_t stream);
+
 }  // namespace lfmkd

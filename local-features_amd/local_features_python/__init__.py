@@ -108,6 +108,13 @@ class LocalFeatures:
                 raise RuntimeError("Failed to extract features", str(e)) from e
         return [Keypoint(*row) for row in kps], desc
 
+    def match(self, desc_a, desc_b, ratio=0.8):
+        """match_features of the reference's match_images example (examples/match_images/src/main.rs:8-27):
+        list of (i, j) with j the best match of desc_a[i] in desc_b that passes Lowe's ratio test."""
+        with self._lock:
+            m = self._inner.match(desc_a, desc_b, ratio)
+        return [(int(i), int(j)) for i, j in enumerate(m) if j >= 0]
+
     def describe_patches(self, patches):
         """patches: [n,32,32] float32 -> ndarray[n,128] (the CPU twin's Mkd::patch, mkd_ref.rs:57-77)."""
         with self._lock:

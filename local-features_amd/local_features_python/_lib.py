@@ -25,6 +25,7 @@ SYMBOLS = (
     "lf_mkd_build_constants", "lf_mkd_kernel_times", "lf_mkd_synchronize", "lf_mkd_version",
     "lf_mkd_orient_keypoints", "lf_mkd_orient_keypoints_device", "lf_mkd_get_coarse_layer",
     "lf_mkd_detect_extrema", "lf_mkd_detect_extrema_device", "lf_mkd_filter_extrema_device", "lf_mkd_detect",
+    "lf_mkd_match", "lf_mkd_match_device",
 )
 
 
@@ -95,6 +96,8 @@ def load_library():
     L.lf_mkd_detect_extrema_device.argtypes = [vp, vp, vp, u64, pu64, pu64, vp]
     L.lf_mkd_filter_extrema_device.argtypes = [vp, vp, u64, u32, ctypes.c_float, vp, vp, pu64, vp]
     L.lf_mkd_detect.argtypes = [vp, vp, u32, u32, u32, ctypes.c_float, vp, vp, u64, pu64, pu64, pu64]
+    L.lf_mkd_match_device.argtypes = [vp, vp, u64, vp, u64, vp, vp, ctypes.c_float, vp, vp, vp, vp]
+    L.lf_mkd_match.argtypes = [vp, vp, u64, vp, u64, ctypes.c_float, vp]
     L.lf_mkd_build_constants.argtypes = [vp] * 7
     L.lf_mkd_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(u64)]
@@ -193,6 +196,15 @@ class MkdHandle:
                                          ctypes.byref(df)), "lf_mkd_detect")
         return kps[:m.value].copy(), desc[:m.value].copy(), db.value, df.value
 
+    def match(self, a, b, ratio=0.8):
+        """match_features (examples/match_images/src/main.rs:8-27): int32 [na], index into b or -1."""
+        a = np.ascontiguousarray(a, np.float32).reshape(-1, 128)
+        b = np.ascontiguousarray(b, np.float32).reshape(-1, 128)
+        out = np.empty(len(a), np.int32)
+        self._check(self.L.lf_mkd_match(self._h, a.ctypes.data, len(a), b.ctypes.data, len(b), ratio, out.ctypes.data),
+                    "lf_mkd_match")
+        return out
+
     def coarse_layer(self, layer, width, height):
         out = np.empty((height, width), np.float32)
         self._check(self.L.lf_mkd_get_coarse_layer(self._h, layer, out.ctypes.data), "lf_mkd_get_coarse_layer")
@@ -252,6 +264,11 @@ class MkdHandle:
         self._check(self.L.lf_mkd_filter_extrema_device(self._h, d_extrema, n, top_n, min_size, d_out, d_index,
                                                         ctypes.byref(m), stream), "lf_mkd_filter_extrema_device")
         return m.value
+
+    def match_device(self, d_a, na, d_b, nb, d_match, ratio=0.8, d_exclude_lo=None, d_exclude_hi=None, d_best=None,
+                     d_second=None, stream=None):
+        self._check(self.L.lf_mkd_match_device(self._h, d_a, na, d_b, nb, d_exclude_lo, d_exclude_hi, ratio, d_match,
+                                               d_best, d_second, stream), "lf_mkd_match_device")
 
     def sample_patches_device(self, d_kps, n, d_patches, stream=None):
         self._check(self.L.lf_mkd_sample_patches_device(self._h, d_kps, n, d_patches, stream),

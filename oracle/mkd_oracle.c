@@ -916,3 +916,78 @@ long mkd_oracle_topk_filter(const float *extrema, long n_in, long n_keep, float 
     free(idx);
     return out;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Brute-force matcher: examples/match_images/src/main.rs:8-27   */
+/* ------------------------------------------------------------------------- */
+
+/* `(&vb * &va).sum()`: ndarray (0.16, a dependency, not in the tree) sums a contiguous f32 array with eight
+ * running partial sums combined as ((p0+p4)+(p1+p5))+((p2+p6)+(p3+p7)), then the tail; 128 = 16 x 8, no tail. */
+static float dot128(const float *a, const float *b)
+{
+    float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 128; i += 8)
+        for (int j = 0; j < 8; j++) p[j] += a[i + j] * b[i + j];
+    float acc = 0.f;
+    acc += p[0] + p[4];
+    acc += p[1] + p[5];
+    acc += p[2] + p[6];
+    acc += p[3] + p[7];
+    return acc;
+}
+
+typedef struct {
+    const float *a, *b;
+    long nb, begin, end;
+    const unsigned *excl_lo, *excl_hi;
+    float ratio;
+    int *match;
+    float *best, *second;
+} match_job_t;
+
+static void *match_worker(void *arg)
+{
+    match_job_t *j = (match_job_t *)arg;
+    for (long i = j->begin; i < j->end; i++) {
+        /* stable ascending sort by similarity, take the last two (lines 15-21): the best is the HIGHEST index among
+         * equal maxima, the second the next one down, possibly an equal value */
+        float s1 = -INFINITY, s2 = -INFINITY;
+        long i1 = -1;
+        for (long k = 0; k < j->nb; k++) {
+            if (j->excl_lo && (unsigned long)k >= j->excl_lo[i] && (unsigned long)k < j->excl_hi[i]) continue;
+            const float s = dot128(j->a + i * 128, j->b + k * 128);
+            if (s >= s1) {
+                s2 = s1;
+                s1 = s;
+                i1 = k;
+            } else if (s > s2) {
+                s2 = s;
+            }
+        }
+        j->match[i] = (i1 >= 0 && s1 * j->ratio > s2) ? (int)i1 : -1; /* line 22: sim[first] * 0.8 > sim[second] */
+        if (j->best) j->best[i] = s1;
+        if (j->second) j->second[i] = s2;
+    }
+    return NULL;
+}
+
+/* a [na][128] against b [nb][128]: match[i] = index of a_i's best b if it passes Lowe's ratio test, else -1.
+ * excl_lo/excl_hi (may be NULL): b indices [excl_lo[i], excl_hi[i]) are skipped for a_i -- the "cross-image" form
+ * of BASELINE configs[3], where a descriptor is not matched against its own image; the reference has two images
+ * and no such notion.  The reference needs nb >= 2 (it indexes idxs[len - 2]); fewer candidates give -1 here. */
+void mkd_oracle_match(const float *a, long na, const float *b, long nb, float ratio, const unsigned *excl_lo,
+                      const unsigned *excl_hi, int *match, float *best, float *second, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    match_job_t jobs[256];
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t] = (match_job_t){a, b, nb, na * t / nthreads, na * (t + 1) / nthreads, excl_lo, excl_hi, ratio,
+                                match, best, second};
+        if (nthreads == 1) match_worker(&jobs[t]);
+        else pthread_create(&th[t], NULL, match_worker, &jobs[t]);
+    }
+    if (nthreads > 1)
+        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+}

@@ -58,6 +58,8 @@ class MkdOracle:
         L.mkd_oracle_topk_filter.restype = ctypes.c_long
         L.mkd_oracle_topk_filter.argtypes = [_fp, ctypes.c_long, ctypes.c_long, ctypes.c_float,
                                              ctypes.POINTER(ctypes.c_uint)]
+        L.mkd_oracle_match.argtypes = [_fp, ctypes.c_long, _fp, ctypes.c_long, ctypes.c_float, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p, _fp, _fp, ctypes.c_int]
         L.mkd_oracle_quirk_pixels.argtypes = [_fp, ctypes.c_float]
         L.mkd_oracle_build_coarse_stack.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]
         L.mkd_oracle_orient.restype = ctypes.c_long
@@ -204,6 +206,19 @@ class MkdOracle:
         if max_features is not None:
             kps = kps[:max_features]
         return kps, self.describe_keypoints(img, kps[:, :4], **kw)
+
+    def match(self, a, b, ratio=0.8, exclude=None, nthreads=8):
+        """match_features (examples/match_images/src/main.rs:8-27): (match [na] int32 (-1 = none), best, second).
+        exclude = (lo, hi) uint32 arrays: b[lo[i]:hi[i]] is skipped for a[i]."""
+        a, b = _f32(a).reshape(-1, 128), _f32(b).reshape(-1, 128)
+        m = np.zeros(len(a), np.int32)
+        s1, s2 = np.zeros(len(a), np.float32), np.zeros(len(a), np.float32)
+        lo = hi = None
+        if exclude is not None:
+            lo, hi = (np.ascontiguousarray(x, np.uint32) for x in exclude)
+        self.L.mkd_oracle_match(_ptr(a), len(a), _ptr(b), len(b), ratio, lo.ctypes.data if lo is not None else None,
+                                hi.ctypes.data if hi is not None else None, m.ctypes.data, _ptr(s1), _ptr(s2), nthreads)
+        return m, s1, s2
 
     def describe_keypoints(self, img, kps, patch_scale_factor=24.0, **kw):
         img = _f32(img)

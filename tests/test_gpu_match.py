@@ -1,0 +1,127 @@
+"""GPU parity tests of the brute-force matcher (examples/match_images/src/main.rs:8-27) through the C ABI.
+The result is discrete (an index or -1 per query).  The kernel's similarities carry ~1e-7 of rounding relative to the
+oracle's f32 dot product, so a decision may differ only where two similarities, or best*ratio and second, agree to
+that level: the tests demand identical results everywhere else and bound the number of such near-ties."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lfp():
+    import local_features_python as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "these tests need the MI355X"
+    return t
+
+
+def unit(x):
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+def descriptor_sets(na, nb, seed, noise=0.25):
+    """b random unit vectors; a = noisy copies of some b rows plus unrelated ones: a mix of accepted and rejected."""
+    rng = np.random.default_rng(seed)
+    b = unit(rng.normal(size=(nb, 128)))
+    src = rng.integers(0, nb, na)
+    a = b[src] + noise * rng.normal(size=(na, 128)) / np.sqrt(128) * rng.uniform(0, 4, (na, 1))
+    a[rng.random(na) < 0.2] = rng.normal(size=(128,))
+    return unit(a), b
+
+
+def compare(got, got_s1, got_s2, want, s1, s2, ratio, what):
+    assert np.abs(got_s1 - s1).max() < 2e-6 and np.abs(got_s2 - s2).max() < 2e-6, what
+    diff = np.flatnonzero(got != want)
+    # a differing decision must be a near-tie: best vs second (index choice) or best*ratio vs second (acceptance)
+    for i in diff:
+        near_accept = abs(s1[i] * ratio - s2[i]) < 2e-6
+        near_index = abs(s1[i] - s2[i]) < 2e-6
+        assert near_accept or near_index, (what, i, got[i], want[i], s1[i], s2[i])
+    assert len(diff) <= max(2, len(want) // 500), (what, len(diff))
+
+
+@pytest.mark.parametrize("na,nb", [(2000, 2000), (1, 2), (31, 33), (513, 1025), (3000, 700), (64, 40000)])
+def test_match_vs_oracle(lfp, torch, oracle, na, nb):
+    a, b = descriptor_sets(na, nb, na + nb)
+    h = lfp.MkdHandle(max_features=64)
+    want, s1, s2 = oracle.match(a, b)
+    if na >= 500:
+        assert 0.1 < (want >= 0).mean() < 0.95               # both outcomes occur
+    d_a, d_b = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    d_m = torch.empty(na, dtype=torch.int32, device="cuda")
+    d_1, d_2 = torch.empty(na, device="cuda"), torch.empty(na, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    h.match_device(d_a.data_ptr(), na, d_b.data_ptr(), nb, d_m.data_ptr(), 0.8, None, None, d_1.data_ptr(),
+                   d_2.data_ptr(), s)
+    torch.cuda.synchronize()
+    compare(d_m.cpu().numpy(), d_1.cpu().numpy(), d_2.cpu().numpy(), want, s1, s2, np.float32(0.8), (na, nb))
+    assert np.array_equal(h.match(a, b), d_m.cpu().numpy())   # host entry point = device entry point
+
+
+def test_match_ties_and_errors(lfp, oracle):
+    h = lfp.MkdHandle(max_features=64)
+    rng = np.random.default_rng(1)
+    b = unit(rng.normal(size=(300, 128)))
+    b[250] = b[17]                      # two identical candidates: best = the higher index, second equal -> rejected
+    b[299] = b[40]
+    a = np.concatenate([b[17:18], b[40:41], b[5:6], unit(rng.normal(size=(5, 128)))])
+    want, s1, s2 = oracle.match(a, b)
+    got = h.match(a, b)
+    assert np.array_equal(got, want) and got[0] == -1 and got[1] == -1 and got[2] == 5
+    # ratio 1.0 accepts every strict best; a duplicated best is still rejected (best * 1 > second is false)
+    got1 = h.match(a, b, ratio=1.0)
+    assert np.array_equal(got1, oracle.match(a, b, ratio=1.0)[0]) and got1[0] == -1 and (got1[2:] >= 0).all()
+    with pytest.raises(RuntimeError, match="two candidates"):
+        h.match(a, b[:1])
+    assert len(h.match(np.zeros((0, 128), np.float32), b)) == 0
+
+
+def test_cross_image_exclusion(lfp, torch, oracle):
+    """BASELINE configs[3] form: b = the descriptors of all images, a row is not matched against its own image."""
+    rng = np.random.default_rng(2)
+    sizes = [300, 17, 450, 233, 64, 1]
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    nb = int(starts[-1])
+    base = unit(rng.normal(size=(500, 128)))
+    b = unit(base[rng.integers(0, 500, nb)] + 0.08 * rng.normal(size=(nb, 128)))   # the same things seen in many images
+    img = np.repeat(np.arange(len(sizes)), sizes)
+    lo, hi = starts[img].astype(np.uint32), starts[img + 1].astype(np.uint32)
+    h = lfp.MkdHandle(max_features=64)
+    want, s1, s2 = oracle.match(b, b, exclude=(lo, hi))
+    assert (img[want[want >= 0]] != img[want >= 0]).all()
+    plain = oracle.match(b, b)[0]
+    assert (plain == np.arange(nb)).sum() > nb // 2           # without the exclusion a row finds itself
+    d_b = torch.from_numpy(b).cuda()
+    d_lo, d_hi = torch.from_numpy(lo.view(np.int32)).cuda(), torch.from_numpy(hi.view(np.int32)).cuda()
+    d_m = torch.empty(nb, dtype=torch.int32, device="cuda")
+    d_1, d_2 = torch.empty(nb, device="cuda"), torch.empty(nb, device="cuda")
+    h.match_device(d_b.data_ptr(), nb, d_b.data_ptr(), nb, d_m.data_ptr(), 0.8, d_lo.data_ptr(), d_hi.data_ptr(),
+                   d_1.data_ptr(), d_2.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    compare(d_m.cpu().numpy(), d_1.cpu().numpy(), d_2.cpu().numpy(), want, s1, s2, np.float32(0.8), "cross-image")
+
+
+def test_match_real_descriptors(lfp, oracle):
+    """Two views of one scene through the whole pipeline: detect both, match, as the reference's example does."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_golden import blob_image
+    img1 = blob_image(400, 300, 7, 400)
+    img2 = np.ascontiguousarray(np.roll(img1, (9, -14), axis=(0, 1)))
+    lf = lfp.LocalFeatures(400, 300, 2000, max_blobs=2000)
+    k1, d1 = lf.detect(img1)
+    k2, d2 = lf.detect(img2)
+    pairs = lf.match(d1, d2)
+    want = oracle.match(d1, d2)[0]
+    assert pairs == [(i, int(j)) for i, j in enumerate(want) if j >= 0]
+    assert len(pairs) > 30
+    # a matched pair is the same blob, displaced by the shift
+    dx = np.array([k2[j].x - k1[i].x for i, j in pairs]); dy = np.array([k2[j].y - k1[i].y for i, j in pairs])
+    ok = (np.abs(dx + 14) < 1.0) & (np.abs(dy - 9) < 1.0)
+    assert ok.mean() > 0.9

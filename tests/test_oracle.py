@@ -218,3 +218,29 @@ def test_detector_properties(oracle):
     k = oracle.topk_filter(ex, 10)
     assert len(k) == 10 and (np.diff(k) > 0).all()
     assert np.sort(ex[k, 3]).min() >= np.sort(ex[:, 3])[::-1][10]
+
+
+def test_matcher_restates_match_features(oracle):
+    """examples/match_images/src/main.rs:8-27 against a NumPy stable argsort of the similarity matrix."""
+    rng = np.random.default_rng(11)
+    b = rng.normal(size=(700, 128)).astype(np.float32)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    a = b[rng.integers(0, 700, 400)] + 0.06 * rng.normal(size=(400, 128)).astype(np.float32)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b[650] = b[3]                                           # equal maxima: the higher index is the best, and is rejected
+    a[0] = b[3]
+    m, s1, s2 = oracle.match(a, b)
+    S = a.astype(np.float64) @ b.astype(np.float64).T
+    order = np.argsort(S, axis=1, kind="stable")
+    first, second = order[:, -1], order[:, -2]
+    rows = np.arange(len(a))
+    want = np.where(S[rows, first] * 0.8 > S[rows, second], first, -1)
+    assert np.array_equal(m[1:], want[1:]) and m[0] == -1
+    assert np.abs(s1 - S[rows, first]).max() < 1e-6 and np.abs(s2 - S[rows, second]).max() < 1e-6
+    assert 0.2 < (m >= 0).mean() < 0.98
+    # exclusion ranges drop candidates; thread count does not matter
+    lo = np.zeros(len(a), np.uint32)
+    hi = np.full(len(a), 350, np.uint32)
+    mx = oracle.match(a, b, exclude=(lo, hi), nthreads=3)[0]
+    assert (mx[mx >= 0] >= 350).all()
+    assert np.array_equal(oracle.match(a, b, nthreads=1)[0], m)
