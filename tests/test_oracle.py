@@ -226,6 +226,7 @@ def test_matcher_restates_match_features(oracle):
     b = rng.normal(size=(700, 128)).astype(np.float32)
     b /= np.linalg.norm(b, axis=1, keepdims=True)
     a = b[rng.integers(0, 700, 400)] + 0.06 * rng.normal(size=(400, 128)).astype(np.float32)
+    a[200:] = rng.normal(size=(200, 128))                   # unrelated queries: best and second close, rejected
     a /= np.linalg.norm(a, axis=1, keepdims=True)
     b[650] = b[3]                                           # equal maxima: the higher index is the best, and is rejected
     a[0] = b[3]
