@@ -106,9 +106,11 @@ __global__ __launch_bounds__(512) void match_scan(const unsigned char *__restric
     if (t_begin < t_end) issue(t_begin, 0);
     for (long t = t_begin; t < t_end; ++t) {
         const int buf = (int)((t - t_begin) & 1);
+#ifndef LF_MATCH_ABLATE_SYNC
         __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of tile t have landed
         __syncthreads();                      // ... and everybody's; everybody is also done with the other buffer
         if (t + 1 < t_end) issue(t + 1, buf ^ 1);
+#endif
         const unsigned char *bb = &s_b[buf][0] + (h * 32 + r) * 16;
         f32x16 acc[kATiles];
 #pragma unroll
@@ -116,7 +118,8 @@ __global__ __launch_bounds__(512) void match_scan(const unsigned char *__restric
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < 8; ++s) {   // (requesting the fragments one k-step ahead was measured: no gain, the
+                                        // partner wave on the SIMD already covers the LDS latency)
             const h8 bh = *reinterpret_cast<const h8 *>(bb + s * 1024);
             const h8 bl = *reinterpret_cast<const h8 *>(bb + s * 1024 + kTileBytes / 2);
 #pragma unroll
@@ -126,7 +129,11 @@ __global__ __launch_bounds__(512) void match_scan(const unsigned char *__restric
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah[q][s], acc[q], 0, 0, 0);
             }
         }
-        // acc[q][i] = <b row, a col r>, b row = 32 t + (i & 3) + 8 (i >> 2) + 4 h: ascending in i
+#ifdef LF_MATCH_ABLATE_EPILOGUE
+#pragma unroll
+        for (int q = 0; q < kATiles; ++q) best[q] += acc[q][0] + acc[q][7] + acc[q][15];
+        continue;
+#endif
         const int row0 = (int)(t * kTileRows) + 4 * h;
         const bool tail = (t + 1) * kTileRows > nb;
 #pragma unroll

@@ -35,6 +35,47 @@ def all_gather_descriptors(desc_local, group=None):
     return torch.cat(parts, dim=0), counts
 
 
+def cross_image_match(desc_local, image_sizes_local, match_fn, ratio=0.8, group=None):
+    """The match stage of BASELINE configs[3]: every rank holds the descriptors of its own images
+    (desc_local [n_i,128], image_sizes_local = descriptors per image, in storage order); descriptor shards are
+    all-gathered (the path's one collective), and each rank matches ITS descriptors against ALL descriptors
+    except those of the same image -- no second exchange, results stay sharded like the queries.
+
+    match_fn(a, b, exclude_lo, exclude_hi, ratio) -> int32 [len(a)] is the engine: the product passes
+    `gpu_match_fn(handle)` (lf_mkd_match_device); the CPU rehearsal in tests/ injects the oracle.
+
+    Returns (match [n_i] int64 GLOBAL row indices into the gathered set or -1, gathered descriptors,
+    global offset of this rank's first row)."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    sizes = torch.as_tensor(list(image_sizes_local), dtype=torch.int64)
+    if int(sizes.sum()) != desc_local.shape[0]:
+        raise ValueError("image_sizes_local must add up to the number of local descriptors")
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        gathered, counts = all_gather_descriptors(desc_local, group)
+    else:
+        gathered, counts = desc_local, [desc_local.shape[0]]
+    base = sum(counts[:rank])
+    starts = base + torch.cumsum(sizes, 0) - sizes                       # global row of each local image's first row
+    lo = torch.repeat_interleave(starts, sizes).to(torch.int32)
+    hi = torch.repeat_interleave(starts + sizes, sizes).to(torch.int32)
+    match = match_fn(desc_local, gathered, lo.to(desc_local.device), hi.to(desc_local.device), ratio)
+    return match.to(torch.int64), gathered, base
+
+
+def gpu_match_fn(handle):
+    """Engine for cross_image_match backed by lf_mkd_match_device (tensors on the handle's GPU)."""
+    def fn(a, b, lo, hi, ratio):
+        a, b = a.contiguous(), b.contiguous()
+        lo, hi = lo.contiguous(), hi.contiguous()
+        out = torch.empty((a.shape[0],), dtype=torch.int32, device=a.device)
+        if a.shape[0]:
+            handle.match_device(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], out.data_ptr(), ratio,
+                                lo.data_ptr(), hi.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.current_stream().synchronize()
+        return out
+    return fn
+
+
 def max_over_ranks(seconds, device):
     """bench.py's timing rule: the slowest rank defines the step time."""
     t = torch.tensor([seconds], device=device, dtype=torch.float64)

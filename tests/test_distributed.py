@@ -38,6 +38,37 @@ def _worker(rank, world, port, q):
     ok = ok and counts == [sum(kp_per_frame[f] for f in sharding.frames_of_rank(7, r, world)) for r in range(world)]
     tmax = sharding.max_over_ranks(1.0 + rank, "cpu")
     ok = ok and tmax == float(world)
+    # match stage of configs[3]: local queries against the gathered set, own image excluded; the engine is injected
+    # (the oracle here, lf_mkd_match_device on the GPUs), the sharding logic is what is rehearsed
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import MkdOracle
+    orc = MkdOracle(os.path.join(ROOT, "local-features_amd", "models", "mkd", "concat-pca-liberty.safetensors"))
+
+    def engine(a, b, lo, hi, ratio):
+        m = orc.match(a.numpy(), b.numpy(), ratio, exclude=(lo.numpy().view(np.uint32), hi.numpy().view(np.uint32)))[0]
+        return torch.from_numpy(m)
+    things = rng.normal(size=(7, 3, 128)).astype(np.float32)
+    def image(f):   # image f shows 3 things of its own, the 3 things of image f-1 (slightly perturbed), and clutter
+        g = np.random.default_rng(100 + f)
+        d = np.concatenate([things[f], things[(f - 1) % 7] + 0.02 * g.normal(size=(3, 128)),
+                            g.normal(size=(kp_per_frame[f], 128))])
+        return (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    imgs = [image(f) for f in range(7)]
+    local = torch.from_numpy(np.concatenate([imgs[f] for f in mine]))
+    match, gathered2, base = sharding.cross_image_match(local, [len(imgs[f]) for f in mine], engine)
+    # single-process answer over the same global order
+    order = [f for r in range(world) for f in sharding.frames_of_rank(7, r, world)]
+    glob = np.concatenate([imgs[f] for f in order])
+    sizes = np.array([len(imgs[f]) for f in order])
+    starts = np.cumsum(sizes) - sizes
+    img_of = np.repeat(np.arange(7), sizes)
+    want = orc.match(glob, glob, 0.8, exclude=(starts[img_of].astype(np.uint32),
+                                               (starts + sizes)[img_of].astype(np.uint32)))[0]
+    ok = ok and np.array_equal(gathered2.numpy(), glob)
+    ok = ok and np.array_equal(match.numpy(), want[base:base + len(local)])
+    ok = ok and (match.numpy() >= 0).sum() >= 6 * len(mine)                 # every shared thing finds its partner
+    sel = match.numpy() >= 0
+    ok = ok and (img_of[match.numpy()[sel]] != img_of[base:base + len(local)][sel]).all()
     a, b = sharding.patch_slice_of_rank(1001, rank, world)
     q.put((rank, ok, a, b))
     dist.destroy_process_group()
