@@ -203,6 +203,21 @@ int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height
                   float min_size, lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out,
                   uint64_t *n_out, uint64_t *dropped_blobs, uint64_t *dropped_features);
 
+/* Per-frame pipeline as one hipGraph (BASELINE configs[4]: 4K stream, detect + describe per frame).
+ * lf_mkd_stream_create records the launch sequence of lf_mkd_detect for frames of width x height -- pyramid,
+ * a-trous stack, extremum scan, [top_n filter if top_n > 0], orientation, sampling, description -- with every
+ * count handed from stage to stage in device memory, so a frame needs no host round trip.  The buffers are
+ * fixed at creation, all DEVICE memory owned by the caller: d_image [height][width] f32 (write the next frame
+ * there before each launch), d_keypoints [max_out], d_descriptors [max_out][128], d_counts [8] uint64:
+ * [0] extrema found (capped at max_blobs), [1] dropped_blobs, [2] extrema after the top_n filter,
+ * [3] keypoints written (valid rows of the two outputs), [4] dropped_features.
+ * lf_mkd_stream_frame launches the graph on `stream` (NULL: the handle's stream), asynchronously.
+ * One stream pipeline per handle; creating another replaces it. */
+int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t top_n, float min_size,
+                         uint64_t max_out, const float *d_image, lf_mkd_keypoint *d_keypoints,
+                         float *d_descriptors, uint64_t *d_counts);
+int lf_mkd_stream_frame(lf_mkd *h, void *stream);
+
 /* Brute-force matcher: match_features of examples/match_images/src/main.rs:8-27.  For every row of a [na][128]:
  * similarity = dot product with every row of b [nb][128]; best = the largest (the HIGHEST index among equal maxima,
  * as the reference's stable sort leaves it), second = the next one down; match[i] = index of the best if

@@ -35,7 +35,7 @@ struct lf_mkd {
     int n_layers = 7;
     float *d_coarse = nullptr;
     long layer_stride = 0, coarse_stride = 0;  // floats between layers / between frames
-    bool coarse_valid = false;
+    bool coarse_valid = false, coarse_l1_valid = false;
     uint64_t orient_cap = 0;                   // extrema the scratch arrays below hold
     float *d_extrema = nullptr, *d_angles = nullptr, *d_kps_out = nullptr;
     unsigned *d_counts = nullptr;
@@ -47,6 +47,11 @@ struct lf_mkd {
           *d_det_desc = nullptr;
     unsigned *d_cube_counts = nullptr, *d_cube_sums = nullptr, *d_sel_count = nullptr;
     uint64_t det_out_cap = 0, det_sel_cap = 0;
+    // graph-captured per-frame pipeline (lf_mkd_stream_*)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    float *d_stream_patches = nullptr;
+    uint64_t stream_patch_cap = 0;
     // matcher scratch
     unsigned char *d_match_a = nullptr, *d_match_b = nullptr;
     float *d_match_part = nullptr, *d_match_in = nullptr;
@@ -185,7 +190,7 @@ int mark(lf_mkd *h, hipStream_t s) {
 
 int run_batch(lf_mkd *h, const float *d_patches, uint64_t n, float *d_out, float *d_raw, hipStream_t s) {
     if (int rc = mark(h, s)) return rc;
-    launch_describe(d_patches, long(n), h->dc, h->params.angle_mode, h->params.pool_mode, d_out ? d_out : h->d_out,
+    launch_describe(d_patches, long(n), nullptr, h->dc, h->params.angle_mode, h->params.pool_mode, d_out ? d_out : h->d_out,
                     d_raw, h->num_cus, s);
     LF_HIP(h, hipGetLastError());
     if (int rc = mark(h, s)) return rc;
@@ -201,7 +206,8 @@ int ensure_coarse_stack(lf_mkd *h, hipStream_t s) {
         LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_coarse), size_t(h->coarse_stride) * h->max_frames * 4));
     }
     launch_build_coarse_stack(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride,
-                              h->d_tmp_a, h->n_layers, h->pd.w[0], h->pd.h[0], int(h->n_frames), s);
+                              h->d_tmp_a, h->n_layers, h->coarse_l1_valid ? 1 : 0, h->pd.w[0], h->pd.h[0],
+                              int(h->n_frames), s);
     LF_HIP(h, hipGetLastError());
     h->coarse_valid = true;
     return LF_MKD_OK;
@@ -284,8 +290,8 @@ int orient_device(lf_mkd *h, const float *d_extrema, const uint32_t *d_frame_of,
                   uint32_t *d_frame_of_kp, uint64_t max_out, uint64_t *n_out, uint64_t *n_dropped, hipStream_t s) {
     if (int rc = ensure_coarse_stack(h, s)) return rc;
     launch_orient(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride, h->n_layers,
-                  h->pd.w[0], h->pd.h[0], d_extrema, d_frame_of, long(n), h->d_angles, h->d_counts, d_out, d_frame_of_kp,
-                  max_out, h->d_totals, s);
+                  h->pd.w[0], h->pd.h[0], d_extrema, d_frame_of, long(n), nullptr, h->d_angles, h->d_counts, d_out,
+                  d_frame_of_kp, max_out, h->d_totals, s);
     LF_HIP(h, hipGetLastError());
     unsigned long long totals[2] = {0, 0};
     LF_HIP(h, hipMemcpyAsync(totals, h->d_totals, sizeof(totals), hipMemcpyDeviceToHost, s));
@@ -352,6 +358,9 @@ void lf_mkd_destroy(lf_mkd *h) {
                     h->d_match_part,   h->d_match_in,    h->d_match_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    if (h->d_stream_patches) (void)hipFree(h->d_stream_patches);
     for (hipEvent_t e : h->ev_pending) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -444,8 +453,12 @@ int lf_mkd_set_images_device(lf_mkd *h, const float *d_images, uint32_t n_frames
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     describe_pyramid(width, height, h->pd);
+    // once the a-trous stack exists (orientation or the detector have been used on this handle) the pyramid's
+    // a-trous layer 1 goes straight into it
+    const bool share = h->d_coarse != nullptr && h->pd.levels >= 2;
     launch_build_pyramid(d_images, long(width) * height, h->d_pyr, h->pyr_stride, h->d_tmp_a, h->d_tmp_b, h->pd,
-                         int(n_frames), s);
+                         int(n_frames), share ? h->d_coarse : nullptr, h->coarse_stride, s);
+    h->coarse_l1_valid = share;
     LF_HIP(h, hipGetLastError());
     h->have_image = true;
     h->coarse_valid = false;
@@ -479,7 +492,7 @@ int lf_mkd_sample_patches_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_kps), nullptr, long(n),
-                          h->params.patch_scale_factor, d_patches, s);
+                          nullptr, h->params.patch_scale_factor, d_patches, s);
     LF_HIP(h, hipGetLastError());
     return LF_MKD_OK;
 }
@@ -495,8 +508,8 @@ int lf_mkd_describe_keypoints_frames_device(lf_mkd *h, const lf_mkd_keypoint *d_
     for (uint64_t off = 0; off < n; off += h->batch) {
         const uint64_t m = std::min<uint64_t>(h->batch, n - off);
         launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_kps + off),
-                              d_frame_of_kp ? d_frame_of_kp + off : nullptr, long(m), h->params.patch_scale_factor,
-                              h->d_patches, s);
+                              d_frame_of_kp ? d_frame_of_kp + off : nullptr, long(m), nullptr,
+                              h->params.patch_scale_factor, h->d_patches, s);
         LF_HIP(h, hipGetLastError());
         const int rc = run_batch(h, h->d_patches, m, d_out + off * kOut, nullptr, s);
         if (rc) return rc;
@@ -518,8 +531,8 @@ int lf_mkd_describe_keypoints(lf_mkd *h, const lf_mkd_keypoint *kps, uint64_t n,
     for (uint64_t off = 0; off < n; off += h->batch) {
         const uint64_t m = std::min<uint64_t>(h->batch, n - off);
         LF_HIP(h, hipMemcpyAsync(h->d_kps, kps + off, m * sizeof(lf_mkd_keypoint), hipMemcpyHostToDevice, h->stream));
-        launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, h->d_kps, nullptr, long(m), h->params.patch_scale_factor,
-                              h->d_patches, h->stream);
+        launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, h->d_kps, nullptr, long(m), nullptr,
+                              h->params.patch_scale_factor, h->d_patches, h->stream);
         LF_HIP(h, hipGetLastError());
         const int rc = run_batch(h, h->d_patches, m, h->d_out, nullptr, h->stream);
         if (rc) return rc;
@@ -603,7 +616,7 @@ int lf_mkd_filter_extrema_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, ui
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     if (!h->d_sel_count) LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_sel_count), 4 * h->max_frames));
     launch_topk_filter(reinterpret_cast<const float *>(d_extrema), nullptr, nullptr, n, 1, top_n, min_size,
-                       reinterpret_cast<float *>(d_out), d_index, h->d_sel_count, s);
+                       reinterpret_cast<float *>(d_out), d_index, h->d_sel_count, nullptr, s);
     LF_HIP(h, hipGetLastError());
     unsigned cnt = 0;
     LF_HIP(h, hipMemcpyAsync(&cnt, h->d_sel_count, 4, hipMemcpyDeviceToHost, s));
@@ -655,6 +668,80 @@ int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height
     LF_HIP(h, hipMemcpyAsync(descriptors, h->d_det_desc, n_kp * kOut * 4, hipMemcpyDeviceToHost, s));
     LF_HIP(h, hipStreamSynchronize(s));
     *n_out = n_kp;
+    return LF_MKD_OK;
+}
+
+int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t top_n, float min_size, uint64_t max_out,
+                         const float *d_image, lf_mkd_keypoint *d_keypoints, float *d_descriptors, uint64_t *d_counts) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!d_image || !d_keypoints || !d_descriptors || !d_counts || max_out == 0 || width < 2 || height < 2)
+        return fail(h, LF_MKD_ERR_BAD_ARG, "stream_create: bad argument");
+    if (!h->d_pyr || width > h->params.max_image_width || height > h->params.max_image_height)
+        return fail(h, LF_MKD_ERR_BAD_ARG, "stream_create: frame exceeds max_image_width/height given at creation");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    // every allocation happens before the capture starts
+    describe_pyramid(width, height, h->pd);
+    h->n_frames = 1;
+    h->have_image = true;
+    if (!h->d_coarse) {
+        h->layer_stride = long(h->params.max_image_width) * h->params.max_image_height;
+        h->coarse_stride = h->layer_stride * (h->n_layers - 1);
+        LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_coarse), size_t(h->coarse_stride) * h->max_frames * 4));
+    }
+    if (int rc = ensure_detect_scratch(h)) return rc;
+    if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, h->max_extrema, sizeof(lf_mkd_extremum))) return rc;
+    const uint64_t cap = top_n ? top_n : h->max_extrema;   // extrema that can reach orientation
+    if (top_n)
+        if (int rc = grow(h, &h->d_det_selected, &h->det_sel_cap, top_n, sizeof(lf_mkd_extremum))) return rc;
+    if (int rc = ensure_orient_scratch(h, cap, false, 0)) return rc;
+    if (int rc = grow(h, &h->d_stream_patches, &h->stream_patch_cap, max_out * kPx, sizeof(float))) return rc;
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(d_counts);
+    LF_HIP(h, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), h->stream));
+    LF_HIP(h, hipStreamSynchronize(h->stream));
+
+    hipStream_t s = h->stream;
+    LF_HIP(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    launch_build_pyramid(d_image, long(width) * height, h->d_pyr, h->pyr_stride, h->d_tmp_a, h->d_tmp_b, h->pd, 1,
+                         h->pd.levels >= 2 ? h->d_coarse : nullptr, h->coarse_stride, s);
+    launch_build_coarse_stack(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride,
+                              h->d_tmp_a, h->n_layers, h->pd.levels >= 2 ? 1 : 0, int(width), int(height), 1, s);
+    launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride,
+                          h->n_layers, int(width), int(height), 1, kBorder, kSkipLayers, kContrastThreshold, h->d_slots,
+                          h->d_cube_counts, h->d_cube_sums, h->d_det_extrema, nullptr, nullptr, h->max_extrema, cnt + 0, s);
+    const float *d_sel = h->d_det_extrema;
+    const unsigned long long *n_sel = cnt + 0;
+    if (top_n) {
+        launch_topk_filter(h->d_det_extrema, nullptr, cnt + 0, 0, 1, top_n, min_size, h->d_det_selected, nullptr,
+                           h->d_sel_count, cnt + 2, s);
+        d_sel = h->d_det_selected;
+        n_sel = cnt + 2;
+    }
+    launch_orient(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride, h->n_layers,
+                  int(width), int(height), d_sel, nullptr, long(cap), n_sel, h->d_angles, h->d_counts,
+                  reinterpret_cast<float *>(d_keypoints), nullptr, max_out, cnt + 3, s);
+    launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr,
+                          long(max_out), cnt + 3, h->params.patch_scale_factor, h->d_stream_patches, s);
+    launch_describe(h->d_stream_patches, long(max_out), cnt + 3, h->dc, h->params.angle_mode, h->params.pool_mode,
+                    d_descriptors, nullptr, h->num_cus, s);
+    hipError_t e_end = hipStreamEndCapture(s, &h->graph);
+    if (e_end != hipSuccess || !h->graph) {
+        h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e_end);
+        return LF_MKD_ERR_HIP;
+    }
+    LF_HIP(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+    h->coarse_valid = true;      // every launch rebuilds the stack of the frame in d_image
+    h->coarse_l1_valid = true;
+    return LF_MKD_OK;
+}
+
+int lf_mkd_stream_frame(lf_mkd *h, void *stream) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!h->graph_exec) return fail(h, LF_MKD_ERR_BAD_ARG, "stream_frame: call lf_mkd_stream_create first");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_HIP(h, hipGraphLaunch(h->graph_exec, stream ? static_cast<hipStream_t>(stream) : h->stream));
     return LF_MKD_OK;
 }
 

@@ -31,24 +31,27 @@ struct DeviceConsts {
 };
 
 // patches [n][32][32] -> out [n][128] (and, when raw_out != nullptr, the un-whitened [n][238])
-void launch_describe(const float *patches, long n, const DeviceConsts &dc, int angle_mode, int pool_mode, float *out,
-                     float *raw_out, int num_cus, hipStream_t stream);
+// (n_dev != nullptr: the count is read on the device, n only sizes the grid; same for the launchers below)
+void launch_describe(const float *patches, long n, const unsigned long long *n_dev, const DeviceConsts &dc,
+                     int angle_mode, int pool_mode, float *out, float *raw_out, int num_cus, hipStream_t stream);
 // frame_of_kp == nullptr: every keypoint belongs to frame 0
 void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
-                           const unsigned *frame_of_kp, long n, float psf, float *patches, hipStream_t stream);
+                           const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
+                           float *patches, hipStream_t stream);
 void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,
-                          float *tmp_b, const PyramidDesc &pd, int frames, hipStream_t stream);
+                          float *tmp_b, const PyramidDesc &pd, int frames, float *layer1, long layer1_stride,
+                          hipStream_t stream);
 
 // a-trous layers 1 .. n_layers-1 over layer0 (= pyramid level 0); tmp holds frames x w x h floats
 void launch_build_coarse_stack(const float *layer0, long layer0_stride, float *coarse, long coarse_stride,
-                               long layer_stride, float *tmp, int n_layers, int w, int h, int frames,
+                               long layer_stride, float *tmp, int n_layers, int first_layer, int w, int h, int frames,
                                hipStream_t stream);
 // extrema [n][4] -> kps [<= max_out][5] ordered by extremum then bin; angles [n][18], counts [n] are scratch;
 // totals[0] = written, totals[1] = dropped
 void launch_orient(const float *layer0, long layer0_stride, const float *coarse, long coarse_stride, long layer_stride,
-                   int n_layers, int w, int h, const float *extrema, const unsigned *frame_of, long n, float *angles,
-                   unsigned *counts, float *kps, unsigned *frame_of_kp, unsigned long long max_out,
-                   unsigned long long *totals, hipStream_t stream);
+                   int n_layers, int w, int h, const float *extrema, const unsigned *frame_of, long n,
+                   const unsigned long long *n_dev, float *angles, unsigned *counts, float *kps, unsigned *frame_of_kp,
+                   unsigned long long max_out, unsigned long long *totals, hipStream_t stream);
 
 // cubes of the extremum scan for a w x h frame with n_fine DoG layers (tasks_detect.rs:300-310)
 void scan_grid(int w, int h, int n_fine, int border, int skip_layers, int &gx, int &gy, int &gz);
@@ -63,7 +66,7 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, const float 
 // (the number of extrema is read from n_in on the device, or taken from n_host when n_in is null)
 void launch_topk_filter(const float *extrema, const unsigned *seg_start, const unsigned long long *n_in,
                         unsigned long long n_host, unsigned n_frames, unsigned n_keep, float min_size, float *out,
-                        unsigned *out_index, unsigned *out_count, hipStream_t stream);
+                        unsigned *out_index, unsigned *out_count, unsigned long long *out_count64, hipStream_t stream);
 
 // brute-force matcher (csrc/mkd_match.hip): x [n][128] f32 -> f16 hi/lo operand tiles (match_tiles_bytes(n) bytes);
 // a tiles against b tiles -> match [na] (index into b or -1) and optionally the best / second-best similarity.

@@ -472,7 +472,8 @@ __device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lan
 // the three blurred rows of the gradient stencil.
 // Algorithmic HBM bytes per patch: 4096 read + 512 written; the kernel moves nothing else.
 template <int ANGLE, int POOL>
-__global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patches, long n,
+__global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patches, long n_host,
+                                                const unsigned long long *__restrict__ n_dev,
                                                 const unsigned char *__restrict__ lut_rows,
                                                 const float *__restrict__ phi_cs,
                                                 const short *__restrict__ colmap,
@@ -480,6 +481,8 @@ __global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patche
                                                 const float *__restrict__ bias,
                                                 float *__restrict__ out, float *__restrict__ raw_out) {
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kPoolLds];
+    // number of patches: given by the host, or (graph-captured pipelines) left on the device by the previous stage
+    const long n = n_dev ? (long)*n_dev : n_host;
     float *s_phi = reinterpret_cast<float *>(s_mem + kPhiOff);
     for (int i = threadIdx.x; i < 2048; i += 512) s_phi[i] = phi_cs[i];
 
@@ -738,8 +741,10 @@ __global__ void pyr_down_v(const float *__restrict__ in, float *__restrict__ out
 // frames of the batch (pyr_stride floats apart).
 __global__ __launch_bounds__(256) void sample_patches(const float *__restrict__ pyr, long pyr_stride, PyramidDesc pd,
                                                       const float *__restrict__ kps /*[n][5]*/,
-                                                      const unsigned *__restrict__ frame_of_kp, long n, float psf,
+                                                      const unsigned *__restrict__ frame_of_kp, long n_host,
+                                                      const unsigned long long *__restrict__ n_dev, float psf,
                                                       float *__restrict__ patches) {
+    const long n = n_dev ? (long)*n_dev : n_host;
     const long k = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= n) return;
     const int lane = threadIdx.x & 63;
@@ -803,10 +808,13 @@ __global__ __launch_bounds__(256) void orient_peaks(const float *__restrict__ la
                                                     const float *__restrict__ coarse, long coarse_stride,
                                                     long layer_stride, int n_layers, int w, int h,
                                                     const float *__restrict__ extrema /*[n][4]*/,
-                                                    const unsigned *__restrict__ frame_of, long n,
+                                                    const unsigned *__restrict__ frame_of, long n_host,
+                                                    const unsigned long long *__restrict__ n_dev,
                                                     float *__restrict__ angles /*[n][18]*/,
                                                     unsigned *__restrict__ counts /*[n]*/) {
 #pragma clang fp contract(off)
+    const long n = n_dev ? (long)*n_dev : n_host;
+    if (n <= 0) return;   // uniform: no barrier is skipped by part of a block
     __shared__ float s_patch[4][kOriPx];
     __shared__ float s_weight[4][kOriPx];
     __shared__ int s_bin[4][kOriPx];
@@ -911,11 +919,13 @@ __global__ __launch_bounds__(256) void orient_peaks(const float *__restrict__ la
 __global__ __launch_bounds__(1024) void orient_compact(const float *__restrict__ extrema,
                                                        const unsigned *__restrict__ frame_of,
                                                        const float *__restrict__ angles,
-                                                       const unsigned *__restrict__ counts, long n,
+                                                       const unsigned *__restrict__ counts, long n_host,
+                                                       const unsigned long long *__restrict__ n_dev,
                                                        float *__restrict__ kps /*[max_out][5]*/,
                                                        unsigned *__restrict__ frame_of_kp, unsigned long long max_out,
                                                        unsigned long long *__restrict__ totals) {
     __shared__ unsigned wave_sum[16];
+    const long n = n_dev ? (long)*n_dev : n_host;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long base = 0;
     for (long chunk = 0; chunk < n; chunk += 1024) {
@@ -1161,7 +1171,8 @@ __global__ __launch_bounds__(1024) void topk_filter(const float *__restrict__ ex
                                                     const unsigned long long *__restrict__ n_in,
                                                     unsigned long long n_host, unsigned n_frames,
                                                     unsigned n_keep, float min_size, float *__restrict__ out,
-                                                    unsigned *__restrict__ out_index, unsigned *__restrict__ out_count) {
+                                                    unsigned *__restrict__ out_index, unsigned *__restrict__ out_count,
+                                                    unsigned long long *__restrict__ out_count64) {
     __shared__ unsigned hist[256];
     __shared__ unsigned ws[16];
     __shared__ unsigned sh_prefix, sh_rank, sh_m;
@@ -1239,14 +1250,18 @@ __global__ __launch_bounds__(1024) void topk_filter(const float *__restrict__ ex
         base += all;
         __syncthreads();
     }
-    if (threadIdx.x == 0) out_count[f] = base < n_keep ? base : n_keep;
+    if (threadIdx.x == 0) {
+        out_count[f] = base < n_keep ? base : n_keep;
+        if (out_count64 && f == 0) out_count64[0] = base < n_keep ? base : n_keep;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-void launch_describe(const float *patches, long n, const DeviceConsts &dc, int angle_mode, int pool_mode, float *out,
-                     float *raw_out, int num_cus, hipStream_t stream) {
+// n_dev != nullptr: the patch count is read on the device (<= n, which then only sizes the grid)
+void launch_describe(const float *patches, long n, const unsigned long long *n_dev, const DeviceConsts &dc,
+                     int angle_mode, int pool_mode, float *out, float *raw_out, int num_cus, hipStream_t stream) {
     if (n <= 0) return;
     const long nbatch = (n + 127) / 128;
     const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);  // one 152 KiB-LDS workgroup per CU
@@ -1256,7 +1271,7 @@ void launch_describe(const float *patches, long n, const DeviceConsts &dc, int a
     const unsigned char *wf = f16 ? reinterpret_cast<const unsigned char *>(dc.white_a_f16)
                                   : reinterpret_cast<const unsigned char *>(dc.white_a_f32);
 #define LF_LAUNCH(A, P)                                                                                        \
-    hipLaunchKernelGGL((mkd_pool<A, P>), dim3(grid), dim3(512), 0, stream, patches, n, lut, dc.phi_cs, dc.colmap, \
+    hipLaunchKernelGGL((mkd_pool<A, P>), dim3(grid), dim3(512), 0, stream, patches, n, n_dev, lut, dc.phi_cs, dc.colmap, \
                        wf, dc.white_bias, out, raw_out)
     if (f16) {
         if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH(LF_ANGLE_EXACT, LF_POOL_F16X3);
@@ -1269,16 +1284,20 @@ void launch_describe(const float *patches, long n, const DeviceConsts &dc, int a
 }
 
 void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
-                           const unsigned *frame_of_kp, long n, float psf, float *patches, hipStream_t stream) {
+                           const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
+                           float *patches, hipStream_t stream) {
     if (n <= 0) return;
     hipLaunchKernelGGL(sample_patches, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, pyr, pyr_stride, pd, kps,
-                       frame_of_kp, n, psf, patches);
+                       frame_of_kp, n, n_dev, psf, patches);
 }
 
 // Builds the pyramids of `frames` frames (image_stride floats apart) into pyr (pyr_stride apart); tmp_a and tmp_b
 // hold frames x w x h floats each.
+// With layer1 != nullptr the a-trous layer 1 the pyramid needs anyway is written there (frames layer1_stride apart) instead
+// of tmp_b: it is layer 1 of the stack orientation and the detector read, so they need not build it again.
 void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,
-                          float *tmp_b, const PyramidDesc &pd, int frames, hipStream_t stream) {
+                          float *tmp_b, const PyramidDesc &pd, int frames, float *layer1, long layer1_stride,
+                          hipStream_t stream) {
     const int w = pd.w[0], h = pd.h[0];
     const long ts = (long)w * h;
     const dim3 blk(32, 8);
@@ -1292,9 +1311,11 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     // level 1: one a-trous pass over level 0, nearest-decimated
     hipLaunchKernelGGL(pyr_swt, grid(w, h), blk, 0, stream, (const float *)(pyr + pd.offset[0]), tmp_a, pyr_stride, ts,
                        w, h, 0, 1);
-    hipLaunchKernelGGL(pyr_swt, grid(w, h), blk, 0, stream, (const float *)tmp_a, tmp_b, ts, ts, w, h, 1, 1);
-    hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)tmp_b, pyr + pd.offset[1],
-                       ts, pyr_stride, w, h, pd.w[1], pd.h[1]);
+    float *l1 = layer1 ? layer1 : tmp_b;
+    const long l1s = layer1 ? layer1_stride : ts;
+    hipLaunchKernelGGL(pyr_swt, grid(w, h), blk, 0, stream, (const float *)tmp_a, l1, ts, l1s, w, h, 1, 1);
+    hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)l1, pyr + pd.offset[1],
+                       l1s, pyr_stride, w, h, pd.w[1], pd.h[1]);
     // levels >= 2: binomial H at the resolution of level l-1, then V with 2x decimation
     for (int l = 2; l < pd.levels; ++l) {
         const int pw = pd.w[l - 1], ph = pd.h[l - 1];
@@ -1308,11 +1329,11 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
 // Layers 1 .. n_layers-1 of the a-trous stack (mod.rs:1093-1130): layer l+1 = [1 4 6 4 1]/16 H then V over layer l
 // with taps 2^l apart.  Layer 0 is pyramid level 0 (the sigma-0.6 blur), so it is read in place.
 void launch_build_coarse_stack(const float *layer0, long layer0_stride, float *coarse, long coarse_stride,
-                               long layer_stride, float *tmp, int n_layers, int w, int h, int frames,
+                               long layer_stride, float *tmp, int n_layers, int first_layer, int w, int h, int frames,
                                hipStream_t stream) {
     const long ts = (long)w * h;
     const dim3 blk(32, 8), grid((w + 31) / 32, (h + 7) / 8, frames);
-    for (int l = 0; l + 1 < n_layers; ++l) {
+    for (int l = first_layer; l + 1 < n_layers; ++l) {   // first_layer = 1: layer 1 came with the pyramid
         const float *in = l == 0 ? layer0 : coarse + (long)(l - 1) * layer_stride;
         const long in_stride = l == 0 ? layer0_stride : coarse_stride;
         hipLaunchKernelGGL(pyr_swt, grid, blk, 0, stream, in, tmp, in_stride, ts, w, h, 0, 1 << l);
@@ -1322,14 +1343,15 @@ void launch_build_coarse_stack(const float *layer0, long layer0_stride, float *c
 }
 
 void launch_orient(const float *layer0, long layer0_stride, const float *coarse, long coarse_stride, long layer_stride,
-                   int n_layers, int w, int h, const float *extrema, const unsigned *frame_of, long n, float *angles,
-                   unsigned *counts, float *kps, unsigned *frame_of_kp, unsigned long long max_out,
-                   unsigned long long *totals, hipStream_t stream) {
+                   int n_layers, int w, int h, const float *extrema, const unsigned *frame_of, long n,
+                   const unsigned long long *n_dev, float *angles, unsigned *counts, float *kps, unsigned *frame_of_kp,
+                   unsigned long long max_out, unsigned long long *totals, hipStream_t stream) {
     if (n > 0)
         hipLaunchKernelGGL(orient_peaks, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, layer0, layer0_stride,
-                           coarse, coarse_stride, layer_stride, n_layers, w, h, extrema, frame_of, n, angles, counts);
+                           coarse, coarse_stride, layer_stride, n_layers, w, h, extrema, frame_of, n, n_dev, angles,
+                           counts);
     hipLaunchKernelGGL(orient_compact, dim3(1), dim3(1024), 0, stream, extrema, frame_of, (const float *)angles,
-                       (const unsigned *)counts, n, kps, frame_of_kp, max_out, totals);
+                       (const unsigned *)counts, n, n_dev, kps, frame_of_kp, max_out, totals);
 }
 
 void scan_grid(int w, int h, int n_fine, int border, int skip_layers, int &gx, int &gy, int &gz) {
@@ -1363,9 +1385,9 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, const float 
 
 void launch_topk_filter(const float *extrema, const unsigned *seg_start, const unsigned long long *n_in,
                         unsigned long long n_host, unsigned n_frames, unsigned n_keep, float min_size, float *out,
-                        unsigned *out_index, unsigned *out_count, hipStream_t stream) {
+                        unsigned *out_index, unsigned *out_count, unsigned long long *out_count64, hipStream_t stream) {
     hipLaunchKernelGGL(topk_filter, dim3(n_frames), dim3(1024), 0, stream, extrema, seg_start, n_in, n_host, n_frames,
-                       n_keep, min_size, out, out_index, out_count);
+                       n_keep, min_size, out, out_index, out_count, out_count64);
 }
 
 }  // namespace lfmkd

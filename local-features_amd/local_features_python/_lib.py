@@ -25,7 +25,7 @@ SYMBOLS = (
     "lf_mkd_build_constants", "lf_mkd_kernel_times", "lf_mkd_synchronize", "lf_mkd_version",
     "lf_mkd_orient_keypoints", "lf_mkd_orient_keypoints_device", "lf_mkd_get_coarse_layer",
     "lf_mkd_detect_extrema", "lf_mkd_detect_extrema_device", "lf_mkd_filter_extrema_device", "lf_mkd_detect",
-    "lf_mkd_match", "lf_mkd_match_device",
+    "lf_mkd_match", "lf_mkd_match_device", "lf_mkd_stream_create", "lf_mkd_stream_frame",
 )
 
 
@@ -98,6 +98,8 @@ def load_library():
     L.lf_mkd_detect.argtypes = [vp, vp, u32, u32, u32, ctypes.c_float, vp, vp, u64, pu64, pu64, pu64]
     L.lf_mkd_match_device.argtypes = [vp, vp, u64, vp, u64, vp, vp, ctypes.c_float, vp, vp, vp, vp]
     L.lf_mkd_match.argtypes = [vp, vp, u64, vp, u64, ctypes.c_float, vp]
+    L.lf_mkd_stream_create.argtypes = [vp, u32, u32, u32, ctypes.c_float, u64, vp, vp, vp, vp]
+    L.lf_mkd_stream_frame.argtypes = [vp, vp]
     L.lf_mkd_build_constants.argtypes = [vp] * 7
     L.lf_mkd_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(u64)]
@@ -269,6 +271,14 @@ class MkdHandle:
                      d_second=None, stream=None):
         self._check(self.L.lf_mkd_match_device(self._h, d_a, na, d_b, nb, d_exclude_lo, d_exclude_hi, ratio, d_match,
                                                d_best, d_second, stream), "lf_mkd_match_device")
+
+    def stream_create(self, width, height, top_n, min_size, max_out, d_image, d_keypoints, d_descriptors, d_counts):
+        """Records the per-frame detect+describe pipeline as a hipGraph over fixed device buffers."""
+        self._check(self.L.lf_mkd_stream_create(self._h, width, height, top_n, min_size, max_out, d_image, d_keypoints,
+                                                d_descriptors, d_counts), "lf_mkd_stream_create")
+
+    def stream_frame(self, stream=None):
+        self._check(self.L.lf_mkd_stream_frame(self._h, stream), "lf_mkd_stream_frame")
 
     def sample_patches_device(self, d_kps, n, d_patches, stream=None):
         self._check(self.L.lf_mkd_sample_patches_device(self._h, d_kps, n, d_patches, stream),

@@ -170,3 +170,34 @@ def test_detect_counts_what_does_not_fit(lfp, oracle):
     xy = np.array([(k.x, k.y) for k in kps])
     dist = np.abs(xy[:, None, :] - ex[None, :256, :2]).max(axis=2).min(axis=1)
     assert dist.max() < 1e-3
+
+
+@pytest.mark.parametrize("top_n", [0, 150])
+def test_graph_captured_stream_pipeline_equals_detect(lfp, torch, top_n):
+    """lf_mkd_stream_*: the per-frame pipeline recorded as one hipGraph, counts handed over on the device.  Frame after
+    frame it must give exactly what lf_mkd_detect gives (same kernels, same order), with no host round trip."""
+    w, hgt, cap = 320, 240, 1024
+    frames = [blob_image(w, hgt, 60 + f, 120 + 60 * f) for f in range(3)]
+    h = lfp.MkdHandle(max_features=cap, max_image_width=w, max_image_height=hgt, max_blobs=2048, pool_mode=lfp.POOL_F16X3)
+    ref = lfp.MkdHandle(max_features=cap, max_image_width=w, max_image_height=hgt, max_blobs=2048,
+                        pool_mode=lfp.POOL_F16X3)
+    d_img = torch.zeros((hgt, w), device="cuda")
+    d_k = torch.zeros((cap, 5), device="cuda")
+    d_d = torch.zeros((cap, 128), device="cuda")
+    d_c = torch.zeros((8,), dtype=torch.int64, device="cuda")
+    h.stream_create(w, hgt, top_n, 0.0, cap, d_img.data_ptr(), d_k.data_ptr(), d_d.data_ptr(), d_c.data_ptr())
+    side = torch.cuda.Stream()
+    for rep in range(2):                                   # the graph is re-launched, buffers reused
+        for f, img in enumerate(frames):
+            with torch.cuda.stream(side):
+                d_img.copy_(torch.from_numpy(img), non_blocking=False)
+                h.stream_frame(side.cuda_stream)
+            side.synchronize()
+            want_k, want_d, dropped_blobs, dropped_features = ref.detect(img, top_n, 0.0, cap)
+            cnt = d_c.cpu().numpy()
+            assert cnt[3] == len(want_k) > 50, (f, cnt)
+            assert cnt[1] == dropped_blobs and cnt[4] == dropped_features
+            if top_n:
+                assert cnt[2] == min(top_n, cnt[0])
+            assert np.array_equal(d_k[:cnt[3]].cpu().numpy(), want_k)
+            assert np.array_equal(d_d[:cnt[3]].cpu().numpy(), want_d)
