@@ -124,6 +124,11 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     if (h->params.patch_scale_factor == 0.f) h->params.patch_scale_factor = 24.f;  // lib.rs:46
     const uint64_t mf = params->max_features ? params->max_features : 2000;        // lib.rs:69
     h->n_layers = int(params->n_scales ? params->n_scales : 4) + 3;                // lib.rs:70, mod.rs:1093
+    if (h->n_layers - 1 > 8) {   // the extremum scan keeps at most 8 DoG layers of a tile in LDS
+        g_create_error = "n_scales must not exceed 6";
+        delete h;
+        return LF_MKD_ERR_BAD_ARG;
+    }
     h->max_extrema = 256 * ((uint64_t(params->max_blobs ? params->max_blobs : 8000) + 255) / 256);  // mod.rs:279-286
     h->batch = (mf + 63) / 64 * 64;
     auto bail = [&](int code) {

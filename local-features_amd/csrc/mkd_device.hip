@@ -667,45 +667,106 @@ __device__ __forceinline__ float tex_bilinear(const float *__restrict__ img, int
 
 // All pyramid kernels work on a batch of frames of one size: blockIdx.z = frame, consecutive frames are
 // in_stride / out_stride floats apart.
+// Full-resolution passes: a workgroup of (64, 4) threads covers a 256 x 4 strip, each thread four pixels 64 apart,
+// so that every thread has its 20 (a-trous) or 20 (sep3) loads in flight at once.  Strips that cannot touch the
+// frame border skip the mirror arithmetic.
+//
 // blur.glsl:34-65 (sigma 0.6) and blur_pyramid.glsl horizontal pass share this shape:
-// out = w0 * tex(c) + w1 * (tex(c - off) + tex(c + off)) along one axis.
-__global__ void pyr_sep3(const float *__restrict__ in, float *__restrict__ out, long in_stride, long out_stride, int w,
-                         int h, float w0, float w1, float off, int vertical) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= w || y >= h) return;
+// out = w0 * tex(c) + w1 * (tex(c - off) + tex(c + off)) along one axis.  The bilinear fetch is evaluated exactly as
+// tex_bilinear does, minus the terms that are multiplied by a weight of exactly 0: the centre tap sits on a texel
+// centre (both fractions 0), the side taps have fraction 0 across the pass direction.
+__device__ __forceinline__ float sep3_pixel(const float *__restrict__ in, int w, int h, int x, int y, float w0, float w1,
+                                            float off, int vertical) {
+    const float c = (float)(vertical ? y : x) + 0.5f;
+    const int n = vertical ? h : w;
+    const long stride = vertical ? w : 1;
+    const float *line = vertical ? in + x : in + (size_t)y * w;
+    float side[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float u = k == 0 ? c - off : c + off;
+        const float fu = u - 0.5f;
+        const float f0 = floorf(fu);
+        const float a = fu - f0;
+        const int i0 = mirror_idx((int)f0, n), i1 = mirror_idx((int)f0 + 1, n);
+        side[k] = line[i0 * stride] * (1.f - a) + line[i1 * stride] * a;
+    }
+    float s = in[(size_t)y * w + x] * w0;
+    s += (side[0] + side[1]) * w1;
+    return s;
+}
+
+__global__ __launch_bounds__(256) void pyr_sep3(const float *__restrict__ in, float *__restrict__ out, long in_stride,
+                                                long out_stride, int w, int h, float w0, float w1, float off,
+                                                int vertical) {
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (y >= h) return;
     in += blockIdx.z * in_stride;
     out += blockIdx.z * out_stride;
-    const float cx = (float)x + 0.5f, cy = (float)y + 0.5f;
-    const float dx = vertical ? 0.f : off, dy = vertical ? off : 0.f;
-    float s = tex_bilinear(in, w, h, cx, cy) * w0;
-    s += (tex_bilinear(in, w, h, cx - dx, cy - dy) + tex_bilinear(in, w, h, cx + dx, cy + dy)) * w1;
-    out[(size_t)y * w + x] = s;
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = blockIdx.x * 256 + threadIdx.x + 64 * j;
+        r[j] = sep3_pixel(in, w, h, x < w ? x : w - 1, y, w0, w1, off, vertical);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = blockIdx.x * 256 + threadIdx.x + 64 * j;
+        if (x < w) out[(size_t)y * w + x] = r[j];
+    }
 }
 
 // swt.glsl:24-58: [1 4 6 4 1]/16 at texel centres, taps d = 2^in_level apart, mirrored.
-__global__ void pyr_swt(const float *__restrict__ in, float *__restrict__ out, long in_stride, long out_stride, int w,
-                        int h, int vertical, int d) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= w || y >= h) return;
+__global__ __launch_bounds__(256) void pyr_swt(const float *__restrict__ in, float *__restrict__ out, long in_stride,
+                                               long out_stride, int w, int h, int vertical, int d) {
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (y >= h) return;
     in += blockIdx.z * in_stride;
     out += blockIdx.z * out_stride;
     const float k0 = 6.f / 16.f, k1 = 4.f / 16.f, k2 = 1.f / 16.f;
-    float s;
+    const int xs = blockIdx.x * 256;
+    float v[4][5];
     if (!vertical) {
         const float *row = in + (size_t)y * w;
-        s = row[x] * k0;
-        s += row[mirror_idx(x - 2 * d, w)] * k2;
-        s += row[mirror_idx(x - d, w)] * k1;
-        s += row[mirror_idx(x + d, w)] * k1;
-        s += row[mirror_idx(x + 2 * d, w)] * k2;
+        const bool interior = xs - 2 * d >= 0 && xs + 255 + 2 * d < w;   // uniform over the workgroup
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xr = xs + threadIdx.x + 64 * j, x = xr < w ? xr : w - 1;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int i = x + (t - 2) * d;
+                v[j][t] = row[interior ? i : mirror_idx(i, w)];
+            }
+        }
     } else {
-        s = in[(size_t)y * w + x] * k0;
-        s += in[(size_t)mirror_idx(y - d, h) * w + x] * k1;
-        s += in[(size_t)mirror_idx(y - 2 * d, h) * w + x] * k2;
-        s += in[(size_t)mirror_idx(y + 2 * d, h) * w + x] * k2;
-        s += in[(size_t)mirror_idx(y + d, h) * w + x] * k1;
+        const bool interior = y - 2 * d >= 0 && y + 2 * d < h;
+        int yy[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) yy[t] = interior ? y + (t - 2) * d : mirror_idx(y + (t - 2) * d, h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xr = xs + threadIdx.x + 64 * j, x = xr < w ? xr : w - 1;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) v[j][t] = in[(size_t)yy[t] * w + x];
+        }
     }
-    out[(size_t)y * w + x] = s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = xs + threadIdx.x + 64 * j;
+        float s = v[j][2] * k0;
+        if (!vertical) {   // the shader's tap order differs between the passes (swt.glsl:38-56)
+            s += v[j][0] * k2;
+            s += v[j][1] * k1;
+            s += v[j][3] * k1;
+            s += v[j][4] * k2;
+        } else {
+            s += v[j][1] * k1;
+            s += v[j][0] * k2;
+            s += v[j][4] * k2;
+            s += v[j][3] * k1;
+        }
+        if (x < w) out[(size_t)y * w + x] = s;
+    }
 }
 
 // Nearest blit [0,w)x[0,h) -> [0,w/2)x[0,h/2): patch_pyramid.rs:251-285.
@@ -729,9 +790,21 @@ __global__ void pyr_down_v(const float *__restrict__ in, float *__restrict__ out
     if (x >= ow || y >= oh) return;
     in += blockIdx.z * in_stride;
     out += blockIdx.z * out_stride;
-    const float cx = 2.f * (float)x + 0.5f, cy = 2.f * (float)y + 0.5f;
-    float s = tex_bilinear(in, w, h, cx, cy) * 0.375f;
-    s += (tex_bilinear(in, w, h, cx, cy - 1.2f) + tex_bilinear(in, w, h, cx, cy + 1.2f)) * 0.3125f;
+    // taps centred on texel (2x, 2y): same arithmetic as tex_bilinear, zero-weight terms left out (see sep3_pixel)
+    const int sx = mirror_idx(2 * x, w);
+    const float cy = 2.f * (float)y + 0.5f;
+    float side[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float u = k == 0 ? cy - 1.2f : cy + 1.2f;
+        const float fu = u - 0.5f;
+        const float f0 = floorf(fu);
+        const float a = fu - f0;
+        const int i0 = mirror_idx((int)f0, h), i1 = mirror_idx((int)f0 + 1, h);
+        side[k] = in[(size_t)i0 * w + sx] * (1.f - a) + in[(size_t)i1 * w + sx] * a;
+    }
+    float s = in[(size_t)mirror_idx(2 * y, h) * w + sx] * 0.375f;
+    s += (side[0] + side[1]) * 0.3125f;
     out[(size_t)y * ow + x] = s;
 }
 
@@ -971,10 +1044,15 @@ __global__ __launch_bounds__(1024) void orient_compact(const float *__restrict__
 // Detector: DoG + 3-D extremum scan + quadratic refinement + edge test (swt_sub.glsl:17-30,
 // scan_extrema.glsl:36-241).  The reference works in 4x4x4 cubes with at most 8 candidates each; a cube is
 // exactly one wavefront here (lane = x + 4 y + 16 z), so "which 8" and the order of the survivors are settled
-// by ballots in lane order instead of atomics.  The DoG is never written to HBM: each wave differences the
-// a-trous layers into its 6x6x6 LDS cube (the subtraction is the same single f32 operation either way).
+// by ballots in lane order instead of atomics.  The DoG is never written to HBM: a workgroup differences the
+// a-trous layers into an LDS tile (the subtraction is the same single f32 operation either way).
 // Output per cube: count + up to 8 slots {x, y, size, contrast}; cubes_compact_* turn that into the ordered list.
 // ---------------------------------------------------------------------------------------------
+// Workgroup = a 32 x 8 pixel tile (8 x 2 cubes per cube layer): the tile's DoG volume (plus a one-texel rim) is
+// differenced into LDS once with row-contiguous loads, then each of the 4 waves walks its share of the cubes.
+constexpr int kScanTX = 32, kScanTY = 8, kScanMaxFine = 8;
+constexpr int kScanRowLen = kScanTX + 2, kScanPlane = (kScanTY + 2) * kScanRowLen;
+
 __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ layer0, long layer0_stride,
                                                     const float *__restrict__ coarse, long coarse_stride,
                                                     long layer_stride, int n_fine, int w, int h, int border,
@@ -982,89 +1060,87 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
                                                     float *__restrict__ slots /*[frames*cubes][8][4]*/,
                                                     unsigned *__restrict__ counts /*[frames*cubes]*/) {
 #pragma clang fp contract(off)
-    __shared__ float s_cube[4][216];
+    __shared__ float s_dog[kScanMaxFine * kScanPlane];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ncubes = gx * gy * gz;
-    const int cube_raw = blockIdx.x * 4 + wave;
-    const bool live = cube_raw < ncubes;
-    const int cube = live ? cube_raw : ncubes - 1;
-    const unsigned f = blockIdx.y;
-    const int cx = cube % gx, cy = (cube / gx) % gy, cz = cube / (gx * gy);
-    const int x0 = cx * 4 + border, y0 = cy * 4 + border, z0 = cz * 4 + 1 + skip_layers;
+    const unsigned f = blockIdx.z;
+    const int tx0 = blockIdx.x * kScanTX + border, ty0 = blockIdx.y * kScanTY + border;   // first candidate texel
     const float *l0 = layer0 + f * layer0_stride, *cs = coarse + f * coarse_stride;
-    float *cb = s_cube[wave];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = lane + 64 * j;
-        if (i < 216) {
-            const int zz = i / 36, r = i - zz * 36, yy = r / 6, xx = r - yy * 6;
-            const int x = x0 - 1 + xx, y = y0 - 1 + yy, z = z0 - 1 + zz;
-            float v = 0.f;
-            if (x >= 0 && x < w && y >= 0 && y < h && z >= 0 && z < n_fine) {
-                const size_t o = (size_t)y * w + x;
-                const float a = z == 0 ? l0[o] : cs[(size_t)(z - 1) * layer_stride + o];
-                v = a - cs[(size_t)z * layer_stride + o];   // fine[z] = coarse[z] - coarse[z+1]
-            }
-            cb[i] = v;
+    // fine[z] = coarse[z] - coarse[z+1] (swt_sub.glsl:24-29) for the tile and its rim; outside the frame: 0
+    for (int i = threadIdx.x; i < kScanPlane; i += 256) {
+        const int yy = i / kScanRowLen, xx = i - yy * kScanRowLen;
+        const int x = tx0 - 1 + xx, y = ty0 - 1 + yy;
+        const bool in = x >= 0 && x < w && y >= 0 && y < h;
+        const size_t o = in ? (size_t)y * w + x : 0;
+        float prev = in ? l0[o] : 0.f;
+        for (int z = 0; z < n_fine; ++z) {
+            const float next = in ? cs[(size_t)z * layer_stride + o] : 0.f;
+            s_dog[z * kScanPlane + i] = prev - next;
+            prev = next;
         }
     }
     __syncthreads();
     const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
-    const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
-    const int c = (lz + 1) * 36 + (ly + 1) * 6 + (lx + 1);
-    auto at = [&](int dz, int dy, int dx) { return cb[c + dz * 36 + dy * 6 + dx]; };
     const int b1 = border > 1 ? border : 1;
-    const float val = cb[c];
-    bool cand = !(x < b1 || x >= w - b1 || y < b1 || y >= h - b1 || z <= 0 || z >= n_fine - 1) &&
-                fabsf(val) > contrast_threshold;
-    if (cand) {
-        const float sgn = glsl_sign(val), sv = sgn * val;
-#pragma unroll
-        for (int dz = -1; dz <= 1; ++dz)
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx)
-                    if (dz || dy || dx) cand = cand && sv >= sgn * at(dz, dy, dx);
-    }
+    const int ncubes = gx * gy * gz;
     const unsigned long long below = (1ull << lane) - 1ull;
-    const unsigned long long cm = __ballot(cand);
-    bool emit = false;
-    float ox = 0.f, oy = 0.f, size = 0.f, contrast = 0.f;
-    if (cand && __popcll(cm & below) < 8) {   // max_wg_extrema = 8 (scan_extrema.glsl:28)
-        const float dds = (at(1, 0, 0) - at(-1, 0, 0)) / 2.0f;
-        const float ddy = (at(0, 1, 0) - at(0, -1, 0)) / 2.0f;
-        const float ddx = (at(0, 0, 1) - at(0, 0, -1)) / 2.0f;
-        const float value2x = val * 2.0f;
-        const float h11 = at(1, 0, 0) + at(-1, 0, 0) - value2x;
-        const float h22 = at(0, 1, 0) + at(0, -1, 0) - value2x;
-        const float h33 = at(0, 0, 1) + at(0, 0, -1) - value2x;
-        const float h12 = (at(1, 1, 0) - at(-1, 1, 0) - at(1, -1, 0) + at(-1, -1, 0)) / 4.0f;
-        const float h13 = (at(1, 0, 1) - at(-1, 0, 1) - at(1, 0, -1) + at(-1, 0, -1)) / 4.0f;
-        const float h23 = (at(0, 1, 1) - at(0, 1, -1) - at(0, -1, 1) + at(0, -1, -1)) / 4.0f;
-        const float det = h11 * h22 * h33 - h11 * h23 * h23 - h12 * h12 * h33 + 2.f * h12 * h13 * h23 - h13 * h13 * h22;
-        const float hinv11 = (h22 * h33 - h23 * h23) / det;
-        const float hinv12 = (h13 * h23 - h12 * h33) / det;
-        const float hinv13 = (h12 * h23 - h13 * h22) / det;
-        const float hinv22 = (h11 * h33 - h13 * h13) / det;
-        const float hinv23 = (h12 * h13 - h11 * h23) / det;
-        const float hinv33 = (h11 * h22 - h12 * h12) / det;
-        const float os = -(hinv11 * dds + hinv12 * ddy + hinv13 * ddx);
-        oy = -(hinv12 * dds + hinv22 * ddy + hinv23 * ddx);
-        ox = -(hinv13 * dds + hinv23 * ddy + hinv33 * ddx);
-        // |offset| > 0.5 in any direction: the shader moves x, y, z and emits nothing (lines 200-203).
-        // A singular hessian gives NaN offsets; the shader would emit NaN coordinates, here it is dropped.
-        const bool inside = fabsf(ox) <= 0.5f && fabsf(oy) <= 0.5f && fabsf(os) <= 0.5f;
-        const float interp = os * dds + oy * ddy + ox * ddx;
-        contrast = fabsf(val + interp / 2.0f);
-        const float denom = (h22 + h33) * (h22 + h33);
-        const float cmv = 1.f - 4.f * (h22 * h33 - h23 * h23) / denom;
-        emit = inside && denom != 0.f && !(0.7f <= cmv && cmv <= 1.5f);
-        size = 0.82f * 1.41421356237f * exp2f((float)z + os);
-    }
-    const unsigned long long em = __ballot(emit);
-    if (live) {
-        const size_t g = (size_t)f * ncubes + cube;
+    for (int q = wave; q < 16 * gz; q += 4) {   // cube q of this tile: (cube layer, cube row, cube column)
+        const int qz = q >> 4, qy = (q >> 3) & 1, qx = q & 7;
+        const int cx = blockIdx.x * 8 + qx, cy = blockIdx.y * 2 + qy;
+        if (cx >= gx || cy >= gy) continue;      // uniform per wave
+        const int x = tx0 + qx * 4 + lx, y = ty0 + qy * 4 + ly, z = qz * 4 + lz + 1 + skip_layers;
+        const bool inside = !(x < b1 || x >= w - b1 || y < b1 || y >= h - b1 || z <= 0 || z >= n_fine - 1);
+        // LDS index of this voxel; out-of-range lanes are parked on a valid interior voxel and never become candidates
+        const int c = (inside ? z : 1) * kScanPlane + (qy * 4 + ly + 1) * kScanRowLen + (qx * 4 + lx + 1);
+        auto at = [&](int dz, int dy, int dx) { return s_dog[c + dz * kScanPlane + dy * kScanRowLen + dx]; };
+        const float val = s_dog[c];
+        bool cand = inside && fabsf(val) > contrast_threshold;
+        if (cand) {
+            const float sgn = glsl_sign(val), sv = sgn * val;
+#pragma unroll
+            for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx)
+                        if (dz || dy || dx) cand = cand && sv >= sgn * at(dz, dy, dx);
+        }
+        const unsigned long long cm = __ballot(cand);
+        bool emit = false;
+        float ox = 0.f, oy = 0.f, size = 0.f, contrast = 0.f;
+        if (cand && __popcll(cm & below) < 8) {   // max_wg_extrema = 8 (scan_extrema.glsl:28)
+            const float dds = (at(1, 0, 0) - at(-1, 0, 0)) / 2.0f;
+            const float ddy = (at(0, 1, 0) - at(0, -1, 0)) / 2.0f;
+            const float ddx = (at(0, 0, 1) - at(0, 0, -1)) / 2.0f;
+            const float value2x = val * 2.0f;
+            const float h11 = at(1, 0, 0) + at(-1, 0, 0) - value2x;
+            const float h22 = at(0, 1, 0) + at(0, -1, 0) - value2x;
+            const float h33 = at(0, 0, 1) + at(0, 0, -1) - value2x;
+            const float h12 = (at(1, 1, 0) - at(-1, 1, 0) - at(1, -1, 0) + at(-1, -1, 0)) / 4.0f;
+            const float h13 = (at(1, 0, 1) - at(-1, 0, 1) - at(1, 0, -1) + at(-1, 0, -1)) / 4.0f;
+            const float h23 = (at(0, 1, 1) - at(0, 1, -1) - at(0, -1, 1) + at(0, -1, -1)) / 4.0f;
+            const float det =
+                h11 * h22 * h33 - h11 * h23 * h23 - h12 * h12 * h33 + 2.f * h12 * h13 * h23 - h13 * h13 * h22;
+            const float hinv11 = (h22 * h33 - h23 * h23) / det;
+            const float hinv12 = (h13 * h23 - h12 * h33) / det;
+            const float hinv13 = (h12 * h23 - h13 * h22) / det;
+            const float hinv22 = (h11 * h33 - h13 * h13) / det;
+            const float hinv23 = (h12 * h13 - h11 * h23) / det;
+            const float hinv33 = (h11 * h22 - h12 * h12) / det;
+            const float os = -(hinv11 * dds + hinv12 * ddy + hinv13 * ddx);
+            oy = -(hinv12 * dds + hinv22 * ddy + hinv23 * ddx);
+            ox = -(hinv13 * dds + hinv23 * ddy + hinv33 * ddx);
+            // |offset| > 0.5 in any direction: the shader moves x, y, z and emits nothing (lines 200-203).
+            // A singular hessian gives NaN offsets; the shader would emit NaN coordinates, here it is dropped.
+            const bool within = fabsf(ox) <= 0.5f && fabsf(oy) <= 0.5f && fabsf(os) <= 0.5f;
+            const float interp = os * dds + oy * ddy + ox * ddx;
+            contrast = fabsf(val + interp / 2.0f);
+            const float denom = (h22 + h33) * (h22 + h33);
+            const float cmv = 1.f - 4.f * (h22 * h33 - h23 * h23) / denom;
+            emit = within && denom != 0.f && !(0.7f <= cmv && cmv <= 1.5f);
+            size = 0.82f * 1.41421356237f * exp2f((float)z + os);
+        }
+        const unsigned long long em = __ballot(emit);
+        const size_t g = (size_t)f * ncubes + ((size_t)qz * gy + cy) * gx + cx;
         if (emit) {
             float *o = slots + (g * 8 + __popcll(em & below)) * 4;
             o[0] = (float)x + ox;
@@ -1183,13 +1259,31 @@ __global__ __launch_bounds__(1024) void topk_filter(const float *__restrict__ ex
     lo = lo < total ? lo : total;
     hi = hi < total ? hi : total;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    auto key_of = [&](unsigned i) { return __float_as_uint(fabsf(extrema[(size_t)i * 4 + 3])); };
-    auto passes = [&](unsigned i) { return extrema[(size_t)i * 4 + 2] >= min_size; };
+    // One sweep over the segment, four extrema per thread and step so that their loads are in flight together (the
+    // segment is a few thousand to a few ten thousand entries: the sweeps are latency-, not bandwidth-bound).
+    // fn(index, passes min_size, key = float bits of |contrast|)
+    auto sweep = [&](auto fn) {
+        for (unsigned i0 = lo + threadIdx.x; i0 < hi; i0 += 4096) {
+            float sz[4], ct[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned i = i0 + 1024u * j;
+                const bool in = i < hi;
+                sz[j] = in ? extrema[(size_t)i * 4 + 2] : 0.f;
+                ct[j] = in ? extrema[(size_t)i * 4 + 3] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned i = i0 + 1024u * j;
+                if (i < hi) fn(i, sz[j] >= min_size, __float_as_uint(fabsf(ct[j])));
+            }
+        }
+    };
     // how many pass min_size
     if (threadIdx.x == 0) sh_m = 0;
     __syncthreads();
     unsigned mine = 0;
-    for (unsigned i = lo + threadIdx.x; i < hi; i += 1024) mine += passes(i) ? 1u : 0u;
+    sweep([&](unsigned, bool pass, unsigned) { mine += pass ? 1u : 0u; });
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
     if (lane == 0) atomicAdd(&sh_m, mine);
@@ -1203,21 +1297,30 @@ __global__ __launch_bounds__(1024) void topk_filter(const float *__restrict__ ex
             for (int b = threadIdx.x; b < 256; b += 1024) hist[b] = 0;
             __syncthreads();
             const unsigned mask = shift == 24 ? 0u : 0xFFFFFFFFu << (shift + 8);
-            for (unsigned i = lo + threadIdx.x; i < hi; i += 1024)
-                if (passes(i)) {
-                    const unsigned k = key_of(i);
-                    if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
-                }
+            sweep([&](unsigned, bool pass, unsigned k) {
+                if (pass && (k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+            });
             __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned r = rank, b = 255;
-                for (;; --b) {   // walk down from the largest byte value
-                    if (r < hist[b]) break;
-                    r -= hist[b];
-                    if (b == 0) break;
+            // the bin holding the wanted rank, walking down from byte value 255: threads 0..255 take bins 255..0,
+            // prefix sums over them locate it in parallel
+            {
+                const unsigned c = threadIdx.x < 256 ? hist[255 - threadIdx.x] : 0u;   // waves 4..15 carry zeros
+                unsigned incl = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned t = __shfl_up(incl, o);
+                    if (lane >= o) incl += t;
                 }
-                sh_prefix = prefix | (b << shift);
-                sh_rank = r;
+                if (lane == 63) ws[wave] = incl;
+                __syncthreads();
+                unsigned before = 0;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) before += v < wave ? ws[v] : 0u;
+                const unsigned excl = before + incl - c;
+                if (c != 0 && rank >= excl && rank < excl + c) {
+                    sh_prefix = prefix | ((255u - threadIdx.x) << shift);
+                    sh_rank = rank - excl;
+                }
             }
             __syncthreads();
             prefix = sh_prefix;
@@ -1230,7 +1333,8 @@ __global__ __launch_bounds__(1024) void topk_filter(const float *__restrict__ ex
     unsigned base = 0;
     for (unsigned chunk = lo; chunk < hi && base < n_keep; chunk += 1024) {
         const unsigned i = chunk + threadIdx.x;
-        const bool take = i < hi && passes(i) && key_of(i) >= cutoff;
+        const bool take = i < hi && extrema[(size_t)i * 4 + 2] >= min_size &&
+                          __float_as_uint(fabsf(extrema[(size_t)i * 4 + 3])) >= cutoff;
         const unsigned long long bm = __ballot(take);
         if (lane == 0) ws[wave] = (unsigned)__popcll(bm);
         __syncthreads();
@@ -1300,26 +1404,27 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
                           hipStream_t stream) {
     const int w = pd.w[0], h = pd.h[0];
     const long ts = (long)w * h;
-    const dim3 blk(32, 8);
+    const dim3 blk(32, 8), strip(64, 4);   // strip kernels: 256 x 4 pixels per workgroup
     auto grid = [&](int gw, int gh) { return dim3((gw + 31) / 32, (gh + 7) / 8, frames); };
+    auto sgrid = [&](int gw, int gh) { return dim3((gw + 255) / 256, (gh + 3) / 4, frames); };
     // level 0: sigma-0.6 blur, H then V (tasks_detect.rs:150-161, mod.rs:1043-1067)
-    hipLaunchKernelGGL(pyr_sep3, grid(w, h), blk, 0, stream, image, tmp_a, image_stride, ts, w, h, 0.66381836f,
+    hipLaunchKernelGGL(pyr_sep3, sgrid(w, h), strip, 0, stream, image, tmp_a, image_stride, ts, w, h, 0.66381836f,
                        0.16809084f, 1.015267163f, 0);
-    hipLaunchKernelGGL(pyr_sep3, grid(w, h), blk, 0, stream, (const float *)tmp_a, pyr + pd.offset[0], ts, pyr_stride, w,
-                       h, 0.66381836f, 0.16809084f, 1.015267163f, 1);
+    hipLaunchKernelGGL(pyr_sep3, sgrid(w, h), strip, 0, stream, (const float *)tmp_a, pyr + pd.offset[0], ts, pyr_stride,
+                       w, h, 0.66381836f, 0.16809084f, 1.015267163f, 1);
     if (pd.levels < 2) return;
     // level 1: one a-trous pass over level 0, nearest-decimated
-    hipLaunchKernelGGL(pyr_swt, grid(w, h), blk, 0, stream, (const float *)(pyr + pd.offset[0]), tmp_a, pyr_stride, ts,
-                       w, h, 0, 1);
+    hipLaunchKernelGGL(pyr_swt, sgrid(w, h), strip, 0, stream, (const float *)(pyr + pd.offset[0]), tmp_a, pyr_stride,
+                       ts, w, h, 0, 1);
     float *l1 = layer1 ? layer1 : tmp_b;
     const long l1s = layer1 ? layer1_stride : ts;
-    hipLaunchKernelGGL(pyr_swt, grid(w, h), blk, 0, stream, (const float *)tmp_a, l1, ts, l1s, w, h, 1, 1);
+    hipLaunchKernelGGL(pyr_swt, sgrid(w, h), strip, 0, stream, (const float *)tmp_a, l1, ts, l1s, w, h, 1, 1);
     hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)l1, pyr + pd.offset[1],
                        l1s, pyr_stride, w, h, pd.w[1], pd.h[1]);
     // levels >= 2: binomial H at the resolution of level l-1, then V with 2x decimation
     for (int l = 2; l < pd.levels; ++l) {
         const int pw = pd.w[l - 1], ph = pd.h[l - 1];
-        hipLaunchKernelGGL(pyr_sep3, grid(pw, ph), blk, 0, stream, (const float *)(pyr + pd.offset[l - 1]), tmp_a,
+        hipLaunchKernelGGL(pyr_sep3, sgrid(pw, ph), strip, 0, stream, (const float *)(pyr + pd.offset[l - 1]), tmp_a,
                            pyr_stride, ts, pw, ph, 0.375f, 0.3125f, 1.2f, 0);
         hipLaunchKernelGGL(pyr_down_v, grid(pd.w[l], pd.h[l]), blk, 0, stream, (const float *)tmp_a, pyr + pd.offset[l],
                            ts, pyr_stride, pw, ph, pd.w[l], pd.h[l]);
@@ -1332,7 +1437,7 @@ void launch_build_coarse_stack(const float *layer0, long layer0_stride, float *c
                                long layer_stride, float *tmp, int n_layers, int first_layer, int w, int h, int frames,
                                hipStream_t stream) {
     const long ts = (long)w * h;
-    const dim3 blk(32, 8), grid((w + 31) / 32, (h + 7) / 8, frames);
+    const dim3 blk(64, 4), grid((w + 255) / 256, (h + 3) / 4, frames);
     for (int l = first_layer; l + 1 < n_layers; ++l) {   // first_layer = 1: layer 1 came with the pyramid
         const float *in = l == 0 ? layer0 : coarse + (long)(l - 1) * layer_stride;
         const long in_stride = l == 0 ? layer0_stride : coarse_stride;
@@ -1371,7 +1476,7 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, const float 
     const long ncubes = (long)gx * gy * gz, n = ncubes * frames;
     const long nb = (n + 1023) / 1024;
     if (ncubes > 0) {
-        hipLaunchKernelGGL(scan_extrema, dim3((unsigned)((ncubes + 3) / 4), frames), dim3(256), 0, stream, layer0,
+        hipLaunchKernelGGL(scan_extrema, dim3((gx + 7) / 8, (gy + 1) / 2, frames), dim3(256), 0, stream, layer0,
                            layer0_stride, coarse, coarse_stride, layer_stride, n_layers - 1, w, h, border, skip_layers,
                            contrast_threshold, gx, gy, gz, slots, counts);
         hipLaunchKernelGGL(cubes_block_sums, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts, n, sums);

@@ -53,6 +53,43 @@ def run(w, h, top_n, frames, tag, sigma=2.5):
           f"orientation {acc[3]:.3f}, sample+describe {acc[4]:.3f} ms", flush=True)
 
 
+def run_graph(w, h, top_n, frames, tag, sigma=2.5):
+    """the same frames through lf_mkd_stream_*: one hipGraph launch per frame, no host round trip"""
+    cap = 2 * top_n
+    hnd = lfp.MkdHandle(max_features=cap, max_image_width=w, max_image_height=h, pool_mode=lfp.POOL_F16X3,
+                        max_blobs=1 << 17)
+    s = torch.cuda.current_stream().cuda_stream
+    imgs = [frame(h, w, 100 + f, sigma) for f in range(4)]
+    d_img = torch.empty((h, w), device="cuda")
+    kps = torch.empty((cap, 5), device="cuda")
+    out = torch.empty((cap, 128), device="cuda")
+    cnt = torch.zeros((8,), dtype=torch.int64, device="cuda")
+    hnd.stream_create(w, h, top_n, 0.0, cap, d_img.data_ptr(), kps.data_ptr(), out.data_ptr(), cnt.data_ptr())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for f in range(3):
+        d_img.copy_(imgs[f % 4]); hnd.stream_frame(s)
+    torch.cuda.synchronize()
+    # latency: one frame at a time, waited for
+    lat = []
+    for f in range(frames):
+        d_img.copy_(imgs[f % 4])
+        e0.record(); hnd.stream_frame(s); e1.record(); torch.cuda.synchronize()
+        lat.append(e0.elapsed_time(e1))
+    n_kp = int(cnt[3].item())
+    # throughput: frames queued back to back (the copy into d_image is part of the stream)
+    t0 = time.perf_counter()
+    for f in range(frames):
+        d_img.copy_(imgs[f % 4]); hnd.stream_frame(s)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / frames
+    print(f"{tag} hipGraph: {w}x{h}: {int(cnt[0].item())} extrema -> top {int(cnt[2].item())} -> {n_kp} keypoints; "
+          f"latency {np.median(lat):.3f} ms/frame (graph launch to done), queued {dt*1e3:.3f} ms/frame "
+          f"({n_kp/dt/1e6:.1f} M desc/s)", flush=True)
+
+
 run(3840, 2160, 6000, 20, "configs[4]")
+run_graph(3840, 2160, 6000, 20, "configs[4]")
+run_graph(1920, 1080, 7000, 20, "configs[1]-sized")
+run_graph(640, 480, 1400, 20, "configs[2]-sized frame", sigma=1.8)
 run(1920, 1080, 7000, 20, "configs[1]-sized")
 run(640, 480, 1400, 20, "configs[2]-sized frame", sigma=1.8)
