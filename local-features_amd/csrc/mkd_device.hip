@@ -58,12 +58,13 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, void *ldst) {
                                      (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
 }
 
-// one LUT row (24 pieces) into an LDS row buffer, 3 pieces per wave
+// one LUT row (24 pieces) into an LDS row buffer, 24 / W pieces per wave
+template <int W>
 __device__ __forceinline__ void issue_lut_row(const unsigned char *__restrict__ lut_rows, int row,
                                               unsigned char *lds_row, int wave, int lane) {
     const unsigned char *g = lut_rows + (size_t)row * kRowBytes + lane * 16;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) lds_dma16(g + (wave + 8 * j) * 1024, lds_row + (wave + 8 * j) * 1024);
+    for (int j = 0; j < 24 / W; ++j) lds_dma16(g + (wave + W * j) * 1024, lds_row + (wave + W * j) * 1024);
 }
 
 // one raw patch row (16 patches x 128 B) of this wave into ring slot `slot`; rows outside [0,31] replicate
@@ -471,8 +472,10 @@ __device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lan
 // 6-slot ring private to each wave, one row per step, so the main loop holds no patch data in VGPRs beyond
 // the three blurred rows of the gradient stencil.
 // Algorithmic HBM bytes per patch: 4096 read + 512 written; the kernel moves nothing else.
-template <int ANGLE, int POOL>
-__global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patches, long n_host,
+// W = waves per workgroup: 8 (128 patches, two waves per SIMD) for throughput; 4 (64 patches) when the whole request
+// fits one round of workgroups anyway, so that it spreads over twice as many CUs with a SIMD to each wave.
+template <int ANGLE, int POOL, int W>
+__global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ patches, long n_host,
                                                 const unsigned long long *__restrict__ n_dev,
                                                 const unsigned char *__restrict__ lut_rows,
                                                 const float *__restrict__ phi_cs,
@@ -480,25 +483,25 @@ __global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patche
                                                 const unsigned char *__restrict__ wfrag,
                                                 const float *__restrict__ bias,
                                                 float *__restrict__ out, float *__restrict__ raw_out) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kPoolLds];
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kRingOff + W * kRingSlots * 2048];
     // number of patches: given by the host, or (graph-captured pipelines) left on the device by the previous stage
     const long n = n_dev ? (long)*n_dev : n_host;
     float *s_phi = reinterpret_cast<float *>(s_mem + kPhiOff);
-    for (int i = threadIdx.x; i < 2048; i += 512) s_phi[i] = phi_cs[i];
+    for (int i = threadIdx.x; i < 2048; i += 64 * W) s_phi[i] = phi_cs[i];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = lane & 15, q = lane >> 4;
     const int addr_l = ((lane - 16) & 63) * 4, addr_r = ((lane + 16) & 63) * 4;
     const bool has_l = q > 0, has_r = q < 3;
-    const long nbatch = (n + 127) / 128;
+    const long nbatch = (n + 16 * W - 1) / (16 * W);
     unsigned char *ring = s_mem + kRingOff + wave * (kRingSlots * 2048);
     // DMA writes are lane-linear (lane l -> bytes [16l, 16l+16) of a 1 KiB piece): lane (p, q) moves the 16-B
     // chunk q of its patch's half-row; the reader (p, q) needs chunks 2(q&1), 2(q&1)+1 of half q>>1.
     const unsigned char *ring_lane = ring + (q >> 1) * 1024 + ((2 * (q & 1)) * 16 + p) * 16;
 
     auto lane_src = [&](long batch) {
-        const long b0 = batch * 128 + wave * 16;
+        const long b0 = batch * (16 * W) + wave * 16;
         const long pidx = (b0 + p < n) ? b0 + p : n - 1;  // tail lanes recompute the last patch
         return patches + pidx * 1024 + 4 * q;
     };
@@ -509,12 +512,12 @@ __global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patche
         const float *src = lane_src(batch);
 #pragma unroll
         for (int r = -2; r <= 3; ++r) issue_raw_row(src, r, ring, r + 2);
-        issue_lut_row(lut_rows, 0, s_mem, wave, lane);
+        issue_lut_row<W>(lut_rows, 0, s_mem, wave, lane);
     }
     unsigned par = 0;  // LUT row buffer holding the row about to be consumed
 
     for (; batch < nbatch; batch += gridDim.x) {
-        const long base = batch * 128 + wave * 16;
+        const long base = batch * (16 * W) + wave * 16;
         const float *src = lane_src(batch);
         const bool more = batch + gridDim.x < nbatch;
         const float *src_next = more ? lane_src(batch + gridDim.x) : src;
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(512) void mkd_pool(const float *__restrict__ patche
             __syncthreads();
 #endif
             const unsigned char *brow = s_mem + par * kRowBytes + lane * 16;
-            if (g < 31 || more) issue_lut_row(lut_rows, (g + 1) & 31, s_mem + (par ^ 1) * kRowBytes, wave, lane);
+            if (g < 31 || more) issue_lut_row<W>(lut_rows, (g + 1) & 31, s_mem + (par ^ 1) * kRowBytes, wave, lane);
             par ^= 1;
             BFrag bm[3] = {load_b<0>(brow), load_b<1>(brow), load_b<2>(brow)};   // m-stream fragments
 
@@ -1367,16 +1370,23 @@ __global__ __launch_bounds__(1024) void topk_filter(const float *__restrict__ ex
 void launch_describe(const float *patches, long n, const unsigned long long *n_dev, const DeviceConsts &dc,
                      int angle_mode, int pool_mode, float *out, float *raw_out, int num_cus, hipStream_t stream) {
     if (n <= 0) return;
-    const long nbatch = (n + 127) / 128;
-    const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);  // one 152 KiB-LDS workgroup per CU
+    // one 100-152 KiB-LDS workgroup per CU; requests of at most one round of 64-patch workgroups take the 4-wave form
+    const bool small = n <= 64L * num_cus;
+    const long nbatch = small ? (n + 63) / 64 : (n + 127) / 128;
+    const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);
     const bool f16 = pool_mode == LF_POOL_F16X3;
     const unsigned char *lut = f16 ? reinterpret_cast<const unsigned char *>(dc.pool_b_f16)
                                    : reinterpret_cast<const unsigned char *>(dc.pool_b_f32);
     const unsigned char *wf = f16 ? reinterpret_cast<const unsigned char *>(dc.white_a_f16)
                                   : reinterpret_cast<const unsigned char *>(dc.white_a_f32);
-#define LF_LAUNCH(A, P)                                                                                        \
-    hipLaunchKernelGGL((mkd_pool<A, P>), dim3(grid), dim3(512), 0, stream, patches, n, n_dev, lut, dc.phi_cs, dc.colmap, \
-                       wf, dc.white_bias, out, raw_out)
+#define LF_LAUNCH_W(A, P, WV)                                                                                          \
+    hipLaunchKernelGGL((mkd_pool<A, P, WV>), dim3(grid), dim3(64 * WV), 0, stream, patches, n, n_dev, lut, dc.phi_cs, \
+                       dc.colmap, wf, dc.white_bias, out, raw_out)
+#define LF_LAUNCH(A, P)            \
+    do {                           \
+        if (small) LF_LAUNCH_W(A, P, 4); \
+        else LF_LAUNCH_W(A, P, 8); \
+    } while (0)
     if (f16) {
         if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH(LF_ANGLE_EXACT, LF_POOL_F16X3);
         else LF_LAUNCH(LF_ANGLE_SHADER, LF_POOL_F16X3);
@@ -1384,6 +1394,7 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
         if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH(LF_ANGLE_EXACT, LF_POOL_F32);
         else LF_LAUNCH(LF_ANGLE_SHADER, LF_POOL_F32);
     }
+#undef LF_LAUNCH_W
 #undef LF_LAUNCH
 }
 
