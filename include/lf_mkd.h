@@ -203,6 +203,19 @@ int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height
                   float min_size, lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out,
                   uint64_t *n_out, uint64_t *dropped_blobs, uint64_t *dropped_features);
 
+/* detect_top_n over a BATCH of frames (BASELINE configs[2]: hundreds of small frames): n_frames frames of one size,
+ * contiguous in device memory, through the whole pipeline with every stage launched once for all frames --
+ * pyramids, a-trous stacks, extremum scan, per-frame top_n filter (top_n = 0: every extremum, at most max_blobs
+ * per frame), orientation, sampling, description.  Results are ordered by frame, then as lf_mkd_detect orders
+ * them; d_frame_of_kp [max_out] names each keypoint's frame.  *dropped_blobs sums the extrema beyond max_blobs
+ * over the frames; *dropped_features counts keypoints beyond max_out (a budget for the whole batch).
+ * n_frames <= max_frames.  Counts come back to the host (the call waits for `stream`). */
+int lf_mkd_detect_frames_device(lf_mkd *h, const float *d_images, uint32_t n_frames, uint32_t width,
+                                uint32_t height, uint32_t top_n, float min_size, lf_mkd_keypoint *d_keypoints,
+                                uint32_t *d_frame_of_kp, float *d_descriptors, uint64_t max_out,
+                                uint64_t *n_out, uint64_t *dropped_blobs, uint64_t *dropped_features,
+                                void *stream);
+
 /* Per-frame pipeline as one hipGraph (BASELINE configs[4]: 4K stream, detect + describe per frame).
  * lf_mkd_stream_create records the launch sequence of lf_mkd_detect for frames of width x height -- pyramid,
  * a-trous stack, extremum scan, [top_n filter if top_n > 0], orientation, sampling, description -- with every

@@ -47,6 +47,10 @@ struct lf_mkd {
           *d_det_desc = nullptr;
     unsigned *d_cube_counts = nullptr, *d_cube_sums = nullptr, *d_sel_count = nullptr;
     uint64_t det_out_cap = 0, det_sel_cap = 0;
+    // multi-frame detect (lf_mkd_detect_frames_device)
+    float *d_mf_padded = nullptr, *d_mf_list = nullptr;
+    unsigned *d_mf_frame_start = nullptr, *d_mf_offsets = nullptr, *d_mf_frame_of = nullptr;
+    uint64_t mf_padded_cap = 0, mf_list_cap = 0, mf_start_cap = 0, mf_off_cap = 0, mf_fo_cap = 0;
     // graph-captured per-frame pipeline (lf_mkd_stream_*)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -163,7 +167,7 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_patches), h->batch * kPx * 4));
     LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_out), h->batch * kOut * 4));
     LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_kps), h->batch * 5 * 4));
-    LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_totals), 2 * sizeof(unsigned long long)));
+    LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_totals), 8 * sizeof(unsigned long long)));
     if (params->max_image_width && params->max_image_height) {
         h->max_frames = params->max_frames ? params->max_frames : 1;
         const size_t px = size_t(params->max_image_width) * params->max_image_height * h->max_frames;
@@ -360,7 +364,8 @@ void lf_mkd_destroy(lf_mkd *h) {
                     h->d_extrema,      h->d_angles,      h->d_counts,      h->d_kps_out,     h->d_totals,
                     h->d_slots,        h->d_det_extrema, h->d_det_selected, h->d_det_kps,    h->d_det_desc,
                     h->d_cube_counts,  h->d_cube_sums,   h->d_sel_count,   h->d_match_a,     h->d_match_b,
-                    h->d_match_part,   h->d_match_in,    h->d_match_out};
+                    h->d_match_part,   h->d_match_in,    h->d_match_out,   h->d_mf_padded,   h->d_mf_list,
+                    h->d_mf_frame_start, h->d_mf_offsets, h->d_mf_frame_of};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
@@ -620,7 +625,7 @@ int lf_mkd_filter_extrema_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, ui
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     if (!h->d_sel_count) LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_sel_count), 4 * h->max_frames));
-    launch_topk_filter(reinterpret_cast<const float *>(d_extrema), nullptr, nullptr, n, 1, top_n, min_size,
+    launch_topk_filter(reinterpret_cast<const float *>(d_extrema), nullptr, nullptr, n, 1, 0xFFFFFFFFu, top_n, min_size,
                        reinterpret_cast<float *>(d_out), d_index, h->d_sel_count, nullptr, s);
     LF_HIP(h, hipGetLastError());
     unsigned cnt = 0;
@@ -676,6 +681,58 @@ int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height
     return LF_MKD_OK;
 }
 
+int lf_mkd_detect_frames_device(lf_mkd *h, const float *d_images, uint32_t n_frames, uint32_t width, uint32_t height,
+                                uint32_t top_n, float min_size, lf_mkd_keypoint *d_keypoints, uint32_t *d_frame_of_kp,
+                                float *d_descriptors, uint64_t max_out, uint64_t *n_out, uint64_t *dropped_blobs,
+                                uint64_t *dropped_features, void *stream) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!n_out) return fail(h, LF_MKD_ERR_BAD_ARG, "detect_frames: n_out is null");
+    *n_out = 0;
+    if (dropped_blobs) *dropped_blobs = 0;
+    if (dropped_features) *dropped_features = 0;
+    if (max_out && (!d_keypoints || !d_descriptors || !d_frame_of_kp))
+        return fail(h, LF_MKD_ERR_BAD_ARG, "detect_frames: null output pointer");
+    if (int rc = lf_mkd_set_images_device(h, d_images, n_frames, width, height, stream)) return rc;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    const uint64_t cap_f = h->max_extrema;                       // extrema kept per frame (mod.rs:625-633)
+    const uint64_t keep = top_n ? std::min<uint64_t>(top_n, cap_f) : cap_f;
+    const uint64_t all_cap = cap_f * n_frames * 2;               // room for frames that exceed their share
+    if (int rc = ensure_coarse_stack(h, s)) return rc;
+    if (int rc = ensure_detect_scratch(h)) return rc;
+    if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, all_cap, sizeof(lf_mkd_extremum))) return rc;
+    if (int rc = grow(h, &h->d_mf_frame_start, &h->mf_start_cap, n_frames, 4)) return rc;
+    if (int rc = grow(h, &h->d_mf_offsets, &h->mf_off_cap, n_frames, 4)) return rc;
+    if (int rc = grow(h, &h->d_mf_padded, &h->mf_padded_cap, keep * n_frames, sizeof(lf_mkd_extremum))) return rc;
+    if (int rc = grow(h, &h->d_mf_list, &h->mf_list_cap, keep * n_frames, sizeof(lf_mkd_extremum))) return rc;
+    if (int rc = grow(h, &h->d_mf_frame_of, &h->mf_fo_cap, keep * n_frames, 4)) return rc;
+    // 1. every frame's extrema, ordered by frame; 2. per-frame selection; 3. one contiguous list + frame ids
+    launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride,
+                          h->n_layers, int(width), int(height), int(n_frames), kBorder, kSkipLayers, kContrastThreshold,
+                          h->d_slots, h->d_cube_counts, h->d_cube_sums, h->d_det_extrema, nullptr, h->d_mf_frame_start,
+                          all_cap, h->d_totals + 0, s);
+    launch_topk_filter(h->d_det_extrema, h->d_mf_frame_start, h->d_totals + 0, 0, n_frames, unsigned(cap_f),
+                       unsigned(keep), top_n ? min_size : -INFINITY, h->d_mf_padded, nullptr, h->d_sel_count, nullptr, s);
+    launch_segments_compact(h->d_mf_padded, h->d_sel_count, h->d_mf_frame_start, h->d_totals + 0, n_frames,
+                            unsigned(cap_f), unsigned(keep), h->d_mf_offsets, h->d_mf_list, h->d_mf_frame_of,
+                            h->d_totals + 2, s);
+    LF_HIP(h, hipGetLastError());
+    unsigned long long totals[4] = {0, 0, 0, 0};
+    LF_HIP(h, hipMemcpyAsync(totals, h->d_totals, sizeof(totals), hipMemcpyDeviceToHost, s));
+    LF_HIP(h, hipStreamSynchronize(s));
+    const uint64_t n_sel = totals[2];
+    if (dropped_blobs) *dropped_blobs = totals[1] + totals[3];
+    if (n_sel == 0 || max_out == 0) return LF_MKD_OK;
+    // 4. orientation over the whole list, 5. sampling + description by frame id
+    if (int rc = ensure_orient_scratch(h, n_sel, false, 0)) return rc;
+    uint64_t n_kp = 0;
+    if (int rc = orient_device(h, h->d_mf_list, h->d_mf_frame_of, n_sel, reinterpret_cast<float *>(d_keypoints),
+                               d_frame_of_kp, max_out, &n_kp, dropped_features, s))
+        return rc;
+    *n_out = n_kp;
+    if (n_kp == 0) return LF_MKD_OK;
+    return lf_mkd_describe_keypoints_frames_device(h, d_keypoints, d_frame_of_kp, n_kp, d_descriptors, s);
+}
+
 int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t top_n, float min_size, uint64_t max_out,
                          const float *d_image, lf_mkd_keypoint *d_keypoints, float *d_descriptors, uint64_t *d_counts) {
     if (!h) return LF_MKD_ERR_BAD_ARG;
@@ -719,7 +776,7 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
     const float *d_sel = h->d_det_extrema;
     const unsigned long long *n_sel = cnt + 0;
     if (top_n) {
-        launch_topk_filter(h->d_det_extrema, nullptr, cnt + 0, 0, 1, top_n, min_size, h->d_det_selected, nullptr,
+        launch_topk_filter(h->d_det_extrema, nullptr, cnt + 0, 0, 1, 0xFFFFFFFFu, top_n, min_size, h->d_det_selected, nullptr,
                            h->d_sel_count, cnt + 2, s);
         d_sel = h->d_det_selected;
         n_sel = cnt + 2;

@@ -65,8 +65,15 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, const float 
 // per frame: blobs with size >= min_size, the n_keep best by contrast, index order; out [n_frames][n_keep][4]
 // (the number of extrema is read from n_in on the device, or taken from n_host when n_in is null)
 void launch_topk_filter(const float *extrema, const unsigned *seg_start, const unsigned long long *n_in,
-                        unsigned long long n_host, unsigned n_frames, unsigned n_keep, float min_size, float *out,
-                        unsigned *out_index, unsigned *out_count, unsigned long long *out_count64, hipStream_t stream);
+                        unsigned long long n_host, unsigned n_frames, unsigned seg_cap, unsigned n_keep, float min_size,
+                        float *out, unsigned *out_index, unsigned *out_count, unsigned long long *out_count64,
+                        hipStream_t stream);
+// per-frame padded selections [frames][n_keep] + counts -> contiguous list + frame ids; totals[0] = entries,
+// totals[1] = extrema dropped by the per-frame cap seg_cap
+void launch_segments_compact(const float *padded, const unsigned *counts, const unsigned *seg_start,
+                             const unsigned long long *n_total, unsigned n_frames, unsigned seg_cap, unsigned n_keep,
+                             unsigned *offsets, float *out, unsigned *frame_of, unsigned long long *totals,
+                             hipStream_t stream);
 
 // brute-force matcher (csrc/mkd_match.hip): x [n][128] f32 -> f16 hi/lo operand tiles (match_tiles_bytes(n) bytes);
 // a tiles against b tiles -> match [na] (index into b or -1) and optionally the best / second-best similarity.

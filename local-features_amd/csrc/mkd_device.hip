@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__(1024) void cubes_scatter(const unsigned *__restrict
 // out: gathered extrema from out_base(f) = f * n_keep; out_count[f].
 __global__ __launch_bounds__(1024) void topk_filter(const float *__restrict__ extrema, const unsigned *__restrict__ seg_start,
                                                     const unsigned long long *__restrict__ n_in,
-                                                    unsigned long long n_host, unsigned n_frames,
+                                                    unsigned long long n_host, unsigned n_frames, unsigned seg_cap,
                                                     unsigned n_keep, float min_size, float *__restrict__ out,
                                                     unsigned *__restrict__ out_index, unsigned *__restrict__ out_count,
                                                     unsigned long long *__restrict__ out_count64) {
@@ -1261,6 +1261,7 @@ __global__ __launch_bounds__(1024) void topk_filter(const float *__restrict__ ex
     unsigned hi = seg_start ? (f + 1 < n_frames ? seg_start[f + 1] : total) : total;
     lo = lo < total ? lo : total;
     hi = hi < total ? hi : total;
+    hi = hi - lo > seg_cap ? lo + seg_cap : hi;   // a frame's extrema beyond max_extrema are dropped (mod.rs:627)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // One sweep over the segment, four extrema per thread and step so that their loads are in flight together (the
     // segment is a few thousand to a few ten thousand entries: the sweeps are latency-, not bandwidth-bound).
@@ -1500,10 +1501,78 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, const float 
 }
 
 void launch_topk_filter(const float *extrema, const unsigned *seg_start, const unsigned long long *n_in,
-                        unsigned long long n_host, unsigned n_frames, unsigned n_keep, float min_size, float *out,
-                        unsigned *out_index, unsigned *out_count, unsigned long long *out_count64, hipStream_t stream) {
+                        unsigned long long n_host, unsigned n_frames, unsigned seg_cap, unsigned n_keep, float min_size,
+                        float *out, unsigned *out_index, unsigned *out_count, unsigned long long *out_count64,
+                        hipStream_t stream) {
     hipLaunchKernelGGL(topk_filter, dim3(n_frames), dim3(1024), 0, stream, extrema, seg_start, n_in, n_host, n_frames,
-                       n_keep, min_size, out, out_index, out_count, out_count64);
+                       seg_cap, n_keep, min_size, out, out_index, out_count, out_count64);
+}
+
+// [frames][n_keep] padded per-frame selections + counts -> one contiguous list with the frame of every entry.
+// totals[0] = entries, totals[1] = extrema the per-frame cap dropped (dropped_blobs summed over the frames).
+__global__ __launch_bounds__(1024) void segments_offsets(const unsigned *__restrict__ counts, unsigned n_frames,
+                                                         const unsigned *__restrict__ seg_start,
+                                                         const unsigned long long *__restrict__ n_total, unsigned seg_cap,
+                                                         unsigned *__restrict__ offsets,
+                                                         unsigned long long *__restrict__ totals) {
+    __shared__ unsigned ws[16];
+    __shared__ unsigned long long dropped;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) dropped = 0;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (unsigned chunk = 0; chunk < n_frames; chunk += 1024) {
+        const unsigned f = chunk + threadIdx.x;
+        const unsigned c = f < n_frames ? counts[f] : 0u;
+        if (f < n_frames) {
+            const unsigned total = (unsigned)n_total[0];
+            const unsigned lo = seg_start[f], hi = f + 1 < n_frames ? seg_start[f + 1] : total;
+            if (hi - lo > seg_cap) atomicAdd(&dropped, (unsigned long long)(hi - lo - seg_cap));
+        }
+        unsigned incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        unsigned before = 0, all = 0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const unsigned t = ws[v];
+            before += v < wave ? t : 0u;
+            all += t;
+        }
+        if (f < n_frames) offsets[f] = (unsigned)(base + before + incl - c);
+        base += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[0] = base;
+        totals[1] = dropped;
+    }
+}
+
+__global__ __launch_bounds__(256) void segments_gather(const float *__restrict__ padded, const unsigned *__restrict__ counts,
+                                                       const unsigned *__restrict__ offsets, unsigned n_keep,
+                                                       float *__restrict__ out, unsigned *__restrict__ frame_of) {
+    const unsigned f = blockIdx.x, c = counts[f], o = offsets[f];
+    for (unsigned i = threadIdx.x; i < c; i += 256) {
+        *reinterpret_cast<f32x4 *>(out + (size_t)(o + i) * 4) =
+            *reinterpret_cast<const f32x4 *>(padded + ((size_t)f * n_keep + i) * 4);
+        frame_of[o + i] = f;
+    }
+}
+
+void launch_segments_compact(const float *padded, const unsigned *counts, const unsigned *seg_start,
+                             const unsigned long long *n_total, unsigned n_frames, unsigned seg_cap, unsigned n_keep,
+                             unsigned *offsets, float *out, unsigned *frame_of, unsigned long long *totals,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(segments_offsets, dim3(1), dim3(1024), 0, stream, counts, n_frames, seg_start, n_total, seg_cap,
+                       offsets, totals);
+    hipLaunchKernelGGL(segments_gather, dim3(n_frames), dim3(256), 0, stream, padded, counts, (const unsigned *)offsets,
+                       n_keep, out, frame_of);
 }
 
 }  // namespace lfmkd

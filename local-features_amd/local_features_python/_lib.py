@@ -26,6 +26,7 @@ SYMBOLS = (
     "lf_mkd_orient_keypoints", "lf_mkd_orient_keypoints_device", "lf_mkd_get_coarse_layer",
     "lf_mkd_detect_extrema", "lf_mkd_detect_extrema_device", "lf_mkd_filter_extrema_device", "lf_mkd_detect",
     "lf_mkd_match", "lf_mkd_match_device", "lf_mkd_stream_create", "lf_mkd_stream_frame",
+    "lf_mkd_detect_frames_device",
 )
 
 
@@ -100,6 +101,8 @@ def load_library():
     L.lf_mkd_match.argtypes = [vp, vp, u64, vp, u64, ctypes.c_float, vp]
     L.lf_mkd_stream_create.argtypes = [vp, u32, u32, u32, ctypes.c_float, u64, vp, vp, vp, vp]
     L.lf_mkd_stream_frame.argtypes = [vp, vp]
+    L.lf_mkd_detect_frames_device.argtypes = [vp, vp, u32, u32, u32, u32, ctypes.c_float, vp, vp, vp, u64, pu64, pu64,
+                                              pu64, vp]
     L.lf_mkd_build_constants.argtypes = [vp] * 7
     L.lf_mkd_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(u64)]
@@ -271,6 +274,16 @@ class MkdHandle:
                      d_second=None, stream=None):
         self._check(self.L.lf_mkd_match_device(self._h, d_a, na, d_b, nb, d_exclude_lo, d_exclude_hi, ratio, d_match,
                                                d_best, d_second, stream), "lf_mkd_match_device")
+
+    def detect_frames_device(self, d_images, n_frames, width, height, top_n, min_size, d_keypoints, d_frame_of_kp,
+                             d_descriptors, max_out, stream=None):
+        """Batch of frames through the whole pipeline; returns (keypoints written, dropped_blobs, dropped_features)."""
+        m, db, df = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.L.lf_mkd_detect_frames_device(self._h, d_images, n_frames, width, height, top_n, min_size,
+                                                       d_keypoints, d_frame_of_kp, d_descriptors, max_out,
+                                                       ctypes.byref(m), ctypes.byref(db), ctypes.byref(df), stream),
+                    "lf_mkd_detect_frames_device")
+        return m.value, db.value, df.value
 
     def stream_create(self, width, height, top_n, min_size, max_out, d_image, d_keypoints, d_descriptors, d_counts):
         """Records the per-frame detect+describe pipeline as a hipGraph over fixed device buffers."""

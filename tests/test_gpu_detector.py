@@ -201,3 +201,40 @@ def test_graph_captured_stream_pipeline_equals_detect(lfp, torch, top_n):
                 assert cnt[2] == min(top_n, cnt[0])
             assert np.array_equal(d_k[:cnt[3]].cpu().numpy(), want_k)
             assert np.array_equal(d_d[:cnt[3]].cpu().numpy(), want_d)
+
+
+@pytest.mark.parametrize("top_n", [0, 90])
+def test_batched_frames_equal_frame_by_frame(lfp, torch, top_n):
+    """lf_mkd_detect_frames_device: every stage launched once for all frames; same results as detect per frame."""
+    w, hgt, frames, cap = 200, 152, 5, 4096
+    imgs = np.stack([blob_image(w, hgt, 80 + f, 40 + 50 * f) for f in range(frames)])
+    h = lfp.MkdHandle(max_features=512, max_image_width=w, max_image_height=hgt, max_blobs=512, max_frames=frames,
+                      pool_mode=lfp.POOL_F16X3)
+    one = lfp.MkdHandle(max_features=2048, max_image_width=w, max_image_height=hgt, max_blobs=512,
+                        pool_mode=lfp.POOL_F16X3)
+    d_img = torch.from_numpy(imgs).cuda().contiguous()
+    d_k = torch.zeros((cap, 5), device="cuda")
+    d_f = torch.zeros((cap,), dtype=torch.int32, device="cuda")
+    d_d = torch.zeros((cap, 128), device="cuda")
+    m, dropped_blobs, dropped_features = h.detect_frames_device(
+        d_img.data_ptr(), frames, w, hgt, top_n, 0.0, d_k.data_ptr(), d_f.data_ptr(), d_d.data_ptr(), cap,
+        torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = [one.detect(imgs[f], top_n, 0.0, 2048) for f in range(frames)]
+    assert dropped_blobs == sum(x[2] for x in want) == 0 and dropped_features == 0
+    assert m == sum(len(x[0]) for x in want) > 150
+    assert np.array_equal(d_k[:m].cpu().numpy(), np.concatenate([x[0] for x in want]))
+    assert np.array_equal(d_f[:m].cpu().numpy(), np.concatenate([np.full(len(x[0]), f) for f, x in enumerate(want)]))
+    assert np.array_equal(d_d[:m].cpu().numpy(), np.concatenate([x[1] for x in want]))
+    # a frame with more extrema than max_blobs keeps the head of its list, like a single detect call does
+    w, hgt = 640, 480
+    big = np.stack([blob_image(w, hgt, 641, 900), blob_image(w, hgt, 642, 300)])
+    tight = lfp.MkdHandle(max_features=512, max_image_width=w, max_image_height=hgt, max_blobs=256, max_frames=2)
+    tight1 = lfp.MkdHandle(max_features=2048, max_image_width=w, max_image_height=hgt, max_blobs=256)
+    d_big = torch.from_numpy(big).cuda().contiguous()
+    m2, db2, _ = tight.detect_frames_device(d_big.data_ptr(), 2, w, hgt, top_n, 0.0, d_k.data_ptr(), d_f.data_ptr(),
+                                            d_d.data_ptr(), cap, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want2 = [tight1.detect(big[f], top_n, 0.0, 2048) for f in range(2)]
+    assert db2 == sum(x[2] for x in want2) > 0
+    assert np.array_equal(d_k[:m2].cpu().numpy(), np.concatenate([x[0] for x in want2]))
