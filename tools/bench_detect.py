@@ -87,6 +87,30 @@ def run_graph(w, h, top_n, frames, tag, sigma=2.5):
           f"({n_kp/dt/1e6:.1f} M desc/s)", flush=True)
 
 
+def run_batch(w, h, top_n, frames, tag, sigma=1.8):
+    """configs[2]: all frames in one lf_mkd_detect_frames_device call"""
+    cap = 2 * top_n * frames
+    hnd = lfp.MkdHandle(max_features=cap, max_image_width=w, max_image_height=h, pool_mode=lfp.POOL_F16X3,
+                        max_blobs=8000, max_frames=frames)
+    s = torch.cuda.current_stream().cuda_stream
+    imgs = torch.stack([frame(h, w, 100 + (f % 8), sigma) for f in range(frames)]).contiguous()
+    kps = torch.empty((cap, 5), device="cuda")
+    fo = torch.empty((cap,), dtype=torch.int32, device="cuda")
+    out = torch.empty((cap, 128), device="cuda")
+    def one():
+        return hnd.detect_frames_device(imgs.data_ptr(), frames, w, h, top_n, 0.0, kps.data_ptr(), fo.data_ptr(),
+                                        out.data_ptr(), cap, s)
+    one(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); it = 5
+    for _ in range(it):
+        m, db, df = one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / it
+    print(f"{tag}: {frames} frames {w}x{h}, top {top_n} per frame, ONE batch: {m} keypoints in {dt*1e3:.3f} ms = "
+          f"{dt/frames*1e3:.4f} ms/frame, {m/dt/1e6:.1f} M desc/s (dropped blobs {db}, features {df})", flush=True)
+
+
+run_batch(640, 480, 1400, 256, "configs[2] batched")
 run(3840, 2160, 6000, 20, "configs[4]")
 run_graph(3840, 2160, 6000, 20, "configs[4]")
 run_graph(1920, 1080, 7000, 20, "configs[1]-sized")
