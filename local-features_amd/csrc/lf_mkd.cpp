@@ -38,7 +38,7 @@ struct lf_mkd {
     bool coarse_valid = false, coarse_l1_valid = false;
     uint64_t orient_cap = 0;                   // extrema the scratch arrays below hold
     float *d_extrema = nullptr, *d_angles = nullptr, *d_kps_out = nullptr;
-    unsigned *d_counts = nullptr;
+    unsigned *d_counts = nullptr, *d_orient_sums = nullptr;
     uint64_t kps_out_cap = 0;
     unsigned long long *d_totals = nullptr;
     // detector scratch (allocated on first use): per-cube slots and counts for max_frames frames of the maximum size
@@ -225,15 +225,16 @@ int ensure_coarse_stack(lf_mkd *h, hipStream_t s) {
 int ensure_orient_scratch(lf_mkd *h, uint64_t n, bool staging, uint64_t max_out) {
     if (n > h->orient_cap) {
         for (void *p : {static_cast<void *>(h->d_extrema), static_cast<void *>(h->d_angles),
-                        static_cast<void *>(h->d_counts)})
+                        static_cast<void *>(h->d_counts), static_cast<void *>(h->d_orient_sums)})
             if (p) (void)hipFree(p);
         h->d_extrema = h->d_angles = nullptr;
-        h->d_counts = nullptr;
+        h->d_counts = h->d_orient_sums = nullptr;
         h->orient_cap = 0;
         const uint64_t cap = std::max<uint64_t>(n, h->batch);
         LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_extrema), cap * sizeof(lf_mkd_extremum)));
         LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_angles), cap * LF_MKD_MAX_ANGLES_PER_EXTREMUM * 4));
         LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_counts), cap * 4));
+        LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_orient_sums), (cap / 1024 + 2) * 4));
         h->orient_cap = cap;
     }
     if (staging && max_out > h->kps_out_cap) {
@@ -299,8 +300,8 @@ int orient_device(lf_mkd *h, const float *d_extrema, const uint32_t *d_frame_of,
                   uint32_t *d_frame_of_kp, uint64_t max_out, uint64_t *n_out, uint64_t *n_dropped, hipStream_t s) {
     if (int rc = ensure_coarse_stack(h, s)) return rc;
     launch_orient(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride, h->n_layers,
-                  h->pd.w[0], h->pd.h[0], d_extrema, d_frame_of, long(n), nullptr, h->d_angles, h->d_counts, d_out,
-                  d_frame_of_kp, max_out, h->d_totals, s);
+                  h->pd.w[0], h->pd.h[0], d_extrema, d_frame_of, long(n), nullptr, h->d_angles, h->d_counts,
+                  h->d_orient_sums, d_out, d_frame_of_kp, max_out, h->d_totals, s);
     LF_HIP(h, hipGetLastError());
     unsigned long long totals[2] = {0, 0};
     LF_HIP(h, hipMemcpyAsync(totals, h->d_totals, sizeof(totals), hipMemcpyDeviceToHost, s));
@@ -364,6 +365,7 @@ void lf_mkd_destroy(lf_mkd *h) {
                     h->d_extrema,      h->d_angles,      h->d_counts,      h->d_kps_out,     h->d_totals,
                     h->d_slots,        h->d_det_extrema, h->d_det_selected, h->d_det_kps,    h->d_det_desc,
                     h->d_cube_counts,  h->d_cube_sums,   h->d_sel_count,   h->d_match_a,     h->d_match_b,
+                    h->d_orient_sums,
                     h->d_match_part,   h->d_match_in,    h->d_match_out,   h->d_mf_padded,   h->d_mf_list,
                     h->d_mf_frame_start, h->d_mf_offsets, h->d_mf_frame_of};
     for (void *p : ptrs)
@@ -782,7 +784,7 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
         n_sel = cnt + 2;
     }
     launch_orient(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride, h->n_layers,
-                  int(width), int(height), d_sel, nullptr, long(cap), n_sel, h->d_angles, h->d_counts,
+                  int(width), int(height), d_sel, nullptr, long(cap), n_sel, h->d_angles, h->d_counts, h->d_orient_sums,
                   reinterpret_cast<float *>(d_keypoints), nullptr, max_out, cnt + 3, s);
     launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr,
                           long(max_out), cnt + 3, h->params.patch_scale_factor, h->d_stream_patches, s);

@@ -46,12 +46,13 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
 void launch_build_coarse_stack(const float *layer0, long layer0_stride, float *coarse, long coarse_stride,
                                long layer_stride, float *tmp, int n_layers, int first_layer, int w, int h, int frames,
                                hipStream_t stream);
-// extrema [n][4] -> kps [<= max_out][5] ordered by extremum then bin; angles [n][18], counts [n] are scratch;
+// extrema [n][4] -> kps [<= max_out][5] ordered by extremum then bin; angles [n][18], counts [n], sums [n/1024+1]
+// are scratch (sums may be null for n <= 8192);
 // totals[0] = written, totals[1] = dropped
 void launch_orient(const float *layer0, long layer0_stride, const float *coarse, long coarse_stride, long layer_stride,
                    int n_layers, int w, int h, const float *extrema, const unsigned *frame_of, long n,
-                   const unsigned long long *n_dev, float *angles, unsigned *counts, float *kps, unsigned *frame_of_kp,
-                   unsigned long long max_out, unsigned long long *totals, hipStream_t stream);
+                   const unsigned long long *n_dev, float *angles, unsigned *counts, unsigned *sums, float *kps,
+                   unsigned *frame_of_kp, unsigned long long max_out, unsigned long long *totals, hipStream_t stream);
 
 // cubes of the extremum scan for a w x h frame with n_fine DoG layers (tasks_detect.rs:300-310)
 void scan_grid(int w, int h, int n_fine, int border, int skip_layers, int &gx, int &gy, int &gz);

@@ -1043,6 +1043,65 @@ __global__ __launch_bounds__(1024) void orient_compact(const float *__restrict__
     }
 }
 
+// The same ordered compaction as orient_compact for long lists (batched frames: hundreds of thousands of extrema),
+// in the three-launch form of cubes_*: sums of 1024 counts, one workgroup scans the sums, every workgroup rescans its
+// counts and writes its keypoints.
+__global__ __launch_bounds__(1024) void orient_block_sums(const unsigned *__restrict__ counts, long n_host,
+                                                          const unsigned long long *__restrict__ n_dev,
+                                                          unsigned *__restrict__ sums) {
+    __shared__ unsigned ws[16];
+    const long n = n_dev ? (long)*n_dev : n_host;
+    const long i = (long)blockIdx.x * 1024 + threadIdx.x;
+    unsigned v = i < n ? counts[i] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int k = 0; k < 16; ++k) t += ws[k];
+        sums[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void orient_scatter(const float *__restrict__ extrema,
+                                                       const unsigned *__restrict__ frame_of,
+                                                       const float *__restrict__ angles,
+                                                       const unsigned *__restrict__ counts,
+                                                       const unsigned *__restrict__ block_offsets, long n_host,
+                                                       const unsigned long long *__restrict__ n_dev,
+                                                       float *__restrict__ kps, unsigned *__restrict__ frame_of_kp,
+                                                       unsigned long long max_out) {
+    __shared__ unsigned ws[16];
+    const long n = n_dev ? (long)*n_dev : n_host;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 1024 + threadIdx.x;
+    const unsigned c = i < n ? counts[i] : 0u;
+    unsigned incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    unsigned before = 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) before += v < wave ? ws[v] : 0u;
+    const unsigned long long first = (unsigned long long)block_offsets[blockIdx.x] + before + incl - c;
+    for (unsigned j = 0; j < c; ++j) {
+        const unsigned long long o = first + j;
+        if (o < max_out) {
+            kps[o * 5 + 0] = extrema[i * 4 + 0];
+            kps[o * 5 + 1] = extrema[i * 4 + 1];
+            kps[o * 5 + 2] = extrema[i * 4 + 2];
+            kps[o * 5 + 3] = angles[i * kOriMaxPeaks + j];
+            kps[o * 5 + 4] = extrema[i * 4 + 3];
+            if (frame_of_kp) frame_of_kp[o] = frame_of ? frame_of[i] : 0u;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Detector: DoG + 3-D extremum scan + quadratic refinement + edge test (swt_sub.glsl:17-30,
 // scan_extrema.glsl:36-241).  The reference works in 4x4x4 cubes with at most 8 candidates each; a cube is
@@ -1074,12 +1133,13 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
         const int x = tx0 - 1 + xx, y = ty0 - 1 + yy;
         const bool in = x >= 0 && x < w && y >= 0 && y < h;
         const size_t o = in ? (size_t)y * w + x : 0;
-        float prev = in ? l0[o] : 0.f;
-        for (int z = 0; z < n_fine; ++z) {
-            const float next = in ? cs[(size_t)z * layer_stride + o] : 0.f;
-            s_dog[z * kScanPlane + i] = prev - next;
-            prev = next;
-        }
+        float c[kScanMaxFine + 1];   // all layers of this texel requested at once
+        c[0] = in ? l0[o] : 0.f;
+#pragma unroll
+        for (int z = 0; z < kScanMaxFine; ++z) c[z + 1] = (in && z < n_fine) ? cs[(size_t)z * layer_stride + o] : 0.f;
+#pragma unroll
+        for (int z = 0; z < kScanMaxFine; ++z)
+            if (z < n_fine) s_dog[z * kScanPlane + i] = c[z] - c[z + 1];
     }
     __syncthreads();
     const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
@@ -1461,14 +1521,23 @@ void launch_build_coarse_stack(const float *layer0, long layer0_stride, float *c
 
 void launch_orient(const float *layer0, long layer0_stride, const float *coarse, long coarse_stride, long layer_stride,
                    int n_layers, int w, int h, const float *extrema, const unsigned *frame_of, long n,
-                   const unsigned long long *n_dev, float *angles, unsigned *counts, float *kps, unsigned *frame_of_kp,
-                   unsigned long long max_out, unsigned long long *totals, hipStream_t stream) {
+                   const unsigned long long *n_dev, float *angles, unsigned *counts, unsigned *sums, float *kps,
+                   unsigned *frame_of_kp, unsigned long long max_out, unsigned long long *totals, hipStream_t stream) {
     if (n > 0)
         hipLaunchKernelGGL(orient_peaks, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, layer0, layer0_stride,
                            coarse, coarse_stride, layer_stride, n_layers, w, h, extrema, frame_of, n, n_dev, angles,
                            counts);
-    hipLaunchKernelGGL(orient_compact, dim3(1), dim3(1024), 0, stream, extrema, frame_of, (const float *)angles,
-                       (const unsigned *)counts, n, n_dev, kps, frame_of_kp, max_out, totals);
+    if (n <= 8192 || !sums) {   // a few thousand extrema (one frame): one workgroup walks them
+        hipLaunchKernelGGL(orient_compact, dim3(1), dim3(1024), 0, stream, extrema, frame_of, (const float *)angles,
+                           (const unsigned *)counts, n, n_dev, kps, frame_of_kp, max_out, totals);
+        return;
+    }
+    const long nb = (n + 1023) / 1024;
+    hipLaunchKernelGGL(orient_block_sums, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts, n, n_dev,
+                       sums);
+    hipLaunchKernelGGL(cubes_scan_sums, dim3(1), dim3(1024), 0, stream, sums, nb, max_out, totals);
+    hipLaunchKernelGGL(orient_scatter, dim3((unsigned)nb), dim3(1024), 0, stream, extrema, frame_of, (const float *)angles,
+                       (const unsigned *)counts, (const unsigned *)sums, n, n_dev, kps, frame_of_kp, max_out);
 }
 
 void scan_grid(int w, int h, int n_fine, int border, int skip_layers, int &gx, int &gy, int &gz) {
