@@ -840,6 +840,29 @@ __global__ __launch_bounds__(256) void sample_patches(const float *__restrict__ 
     const int lx = lane & 31;
     const float dx = (float)lx - 16.f;
     float *dst = patches + k * 1024 + lane;
+    // When the rotated patch footprint (half diagonal 16 sqrt2 rem, plus the bilinear neighbour) stays inside the level,
+    // MirroredRepeat is the identity and its index arithmetic is skipped: same texels, same weights.
+    const float reach = 22.7f * rem + 2.f, pcx = kp[0] * inv, pcy = kp[1] * inv;
+    const bool interior = pcx - reach >= 0.f && pcx + reach <= (float)(w - 1) && pcy - reach >= 0.f &&
+                          pcy + reach <= (float)(h - 1);   // uniform over the wave
+    if (interior) {
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int ly = 2 * i + (lane >> 5);
+            const float dy = (float)ly - 16.f;
+            const float xx = dx * ca - dy * sa, yy = dx * sa + dy * ca;
+            const float sx = xx * rem + kp[0] * inv, sy = yy * rem + kp[1] * inv;
+            // tex_bilinear(img, w, h, sx + 0.5f, sy + 0.5f) without the mirror
+            const float fu = (sx + 0.5f) - 0.5f, fv = (sy + 0.5f) - 0.5f;
+            const float x0f = floorf(fu), y0f = floorf(fv);
+            const float ax = fu - x0f, ay = fv - y0f;
+            const float *r0 = img + (int)y0f * w + (int)x0f, *r1 = r0 + w;
+            const float top = r0[0] * (1.f - ax) + r0[1] * ax;
+            const float bot = r1[0] * (1.f - ax) + r1[1] * ax;
+            dst[i * 64] = top * (1.f - ay) + bot * ay;
+        }
+        return;
+    }
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
         const int ly = 2 * i + (lane >> 5);
