@@ -206,6 +206,15 @@ int run_batch(lf_mkd *h, const float *d_patches, uint64_t n, float *d_out, float
     return LF_MKD_OK;
 }
 
+// A recorded stream pipeline holds raw pointers into the scratch buffers: re-allocating one of them retires the graph
+// (lf_mkd_stream_frame then asks for a new lf_mkd_stream_create instead of touching freed memory).
+void retire_graph(lf_mkd *h) {
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    h->graph_exec = nullptr;
+    h->graph = nullptr;
+}
+
 // Extends the loaded frames' level 0 into the a-trous stack (once per set_image*), allocating it on first use.
 int ensure_coarse_stack(lf_mkd *h, hipStream_t s) {
     if (h->coarse_valid) return LF_MKD_OK;
@@ -224,6 +233,7 @@ int ensure_coarse_stack(lf_mkd *h, hipStream_t s) {
 
 int ensure_orient_scratch(lf_mkd *h, uint64_t n, bool staging, uint64_t max_out) {
     if (n > h->orient_cap) {
+        retire_graph(h);
         for (void *p : {static_cast<void *>(h->d_extrema), static_cast<void *>(h->d_angles),
                         static_cast<void *>(h->d_counts), static_cast<void *>(h->d_orient_sums)})
             if (p) (void)hipFree(p);
@@ -238,6 +248,7 @@ int ensure_orient_scratch(lf_mkd *h, uint64_t n, bool staging, uint64_t max_out)
         h->orient_cap = cap;
     }
     if (staging && max_out > h->kps_out_cap) {
+        retire_graph(h);
         if (h->d_kps_out) (void)hipFree(h->d_kps_out);
         h->d_kps_out = nullptr;
         h->kps_out_cap = 0;
@@ -288,6 +299,7 @@ int detect_extrema_device(lf_mkd *h, float *d_out, uint32_t *d_frame_of, uint64_
 template <typename T>
 int grow(lf_mkd *h, T **p, uint64_t *cap, uint64_t want, size_t elem_bytes) {
     if (want <= *cap && *p) return LF_MKD_OK;
+    retire_graph(h);
     if (*p) (void)hipFree(*p);
     *p = nullptr;
     *cap = 0;
@@ -803,7 +815,9 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
 
 int lf_mkd_stream_frame(lf_mkd *h, void *stream) {
     if (!h) return LF_MKD_ERR_BAD_ARG;
-    if (!h->graph_exec) return fail(h, LF_MKD_ERR_BAD_ARG, "stream_frame: call lf_mkd_stream_create first");
+    if (!h->graph_exec)
+        return fail(h, LF_MKD_ERR_BAD_ARG, "stream_frame: no recorded pipeline (call lf_mkd_stream_create; a call that "
+                                           "grew the handle's scratch buffers retires an earlier recording)");
     LF_HIP(h, hipSetDevice(h->params.device));
     LF_HIP(h, hipGraphLaunch(h->graph_exec, stream ? static_cast<hipStream_t>(stream) : h->stream));
     return LF_MKD_OK;

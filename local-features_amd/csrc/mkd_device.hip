@@ -4,7 +4,11 @@
 //   mkd_pool          mkd/patch_gradients.glsl:72-104 + mkd/embedding.glsl:53-121 (both variants)
 //                     + mkd/normalize.glsl:22-142 + mkd/whitening.glsl:22-77 + mkd/normalize_final.glsl
 //   sample_patches    mkd/patch_gradients.glsl:42-70
-//   pyr_*             blur.glsl, swt.glsl (level 0), blur_pyramid.glsl, patch_pyramid.rs blits
+//   pyr_*             blur.glsl, swt.glsl (all levels of the a-trous stack), blur_pyramid.glsl, patch_pyramid.rs blits
+//   orient_*          keypoint_orientation.glsl:36-171 (+ the ordered compaction that replaces its atomic append)
+//   scan_extrema      swt_sub.glsl:17-30 + scan_extrema.glsl:36-241; cubes_* = its ordered compaction
+//   topk_filter       the host blob filter of detect_top_n (vulkan/mod.rs:1753-1786) on the device; segments_* batch it
+//   (the matcher lives in mkd_match.hip)
 //
 // Pooling is a GEMM with M = patches, K = pixels, N = (stream, spatial kernel) columns.  One wave
 // owns 16 patches; lane l = (patch p = l & 15, segment q = l >> 4) holds the 8 pixels
@@ -43,11 +47,10 @@ constexpr float kB0 = 0.0096f, kB1 = 0.2054f, kB2 = 0.5699f;
 
 // LDS map of the pooling kernel (bytes)
 constexpr int kRowBytes = kUniqueTiles * 2 * 1024;   // 24576: one LUT row image, 2 x 1 KiB pieces per tile
-constexpr int kRowPieces = kUniqueTiles * 2;
 constexpr int kPhiOff = 2 * kRowBytes;               // cos/sin(phi) table, 8 KiB
 constexpr int kRingOff = kPhiOff + 8192;             // raw patch rows: [wave 8][slot 6][2 KiB]
 constexpr int kRingSlots = 6;
-constexpr int kPoolLds = kRingOff + 8 * kRingSlots * 2048;   // 155648
+// total: kRingOff + waves * kRingSlots * 2048 = 155648 B for 8 waves, 106496 B for 4
 
 __device__ __forceinline__ float lane_fetch(int byte_addr, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
