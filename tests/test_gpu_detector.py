@@ -238,3 +238,25 @@ def test_batched_frames_equal_frame_by_frame(lfp, torch, top_n):
     want2 = [tight1.detect(big[f], top_n, 0.0, 2048) for f in range(2)]
     assert db2 == sum(x[2] for x in want2) > 0
     assert np.array_equal(d_k[:m2].cpu().numpy(), np.concatenate([x[0] for x in want2]))
+
+
+def test_stream_pipeline_is_retired_when_its_buffers_move(lfp, torch):
+    """The recorded graph holds raw scratch pointers: a later call that has to grow them retires the recording, and
+    stream_frame says so instead of running on freed memory."""
+    w, hgt, cap = 160, 120, 256
+    h = lfp.MkdHandle(max_features=cap, max_image_width=w, max_image_height=hgt, max_blobs=256)
+    d_img = torch.from_numpy(blob_image(w, hgt, 3, 60)).cuda()
+    d_k, d_d = torch.zeros((cap, 5), device="cuda"), torch.zeros((cap, 128), device="cuda")
+    d_c = torch.zeros((8,), dtype=torch.int64, device="cuda")
+    h.stream_create(w, hgt, 100, 0.0, cap, d_img.data_ptr(), d_k.data_ptr(), d_d.data_ptr(), d_c.data_ptr())
+    h.stream_frame()
+    h.synchronize()
+    first = int(d_c[3].item())
+    assert first > 10
+    h.orient_keypoints(np.tile(np.array([[80.0, 60.0, 3.0, 0.1]], np.float32), (5000, 1)))   # grows the scratch arrays
+    with pytest.raises(RuntimeError, match="stream_create"):
+        h.stream_frame()
+    h.stream_create(w, hgt, 100, 0.0, cap, d_img.data_ptr(), d_k.data_ptr(), d_d.data_ptr(), d_c.data_ptr())
+    h.stream_frame()
+    h.synchronize()
+    assert int(d_c[3].item()) == first
