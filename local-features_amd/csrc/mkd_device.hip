@@ -1458,7 +1458,11 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
                      int angle_mode, int pool_mode, float *out, float *raw_out, int num_cus, hipStream_t stream) {
     if (n <= 0) return;
     // one 100-152 KiB-LDS workgroup per CU; requests of at most one round of 64-patch workgroups take the 4-wave form
+#ifdef LF_ABLATE_FORCE_W4   // timing-only build: the 4-wave form at every size
+    const bool small = true;
+#else
     const bool small = n <= 64L * num_cus;
+#endif
     const long nbatch = small ? (n + 63) / 64 : (n + 127) / 128;
     const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);
     const bool f16 = pool_mode == LF_POOL_F16X3;
