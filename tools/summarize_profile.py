@@ -11,12 +11,12 @@ bench = None
 for l in open(os.path.join(src, "stats.log")):
     if l.startswith("{"):
         bench = json.loads(l)
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 kern_ms = None
 # the timed kernel variant: mkd_pool<ANGLE, POOL>; bench.py also runs the exact-angle variant once as a
 # secondary figure, which must not be mixed into the headline kernel's numbers
-variant = "mkd_pool<%d, %d>" % (0 if (not bench or bench["config"]["angle_mode"] == "shader") else 1,
-                                1 if (not bench or bench["config"]["pool_mode"] == "f16x3") else 0)
+variant = "mkd_pool<%d, %d, 8>" % (0 if (not bench or bench["config"]["angle_mode"] == "shader") else 1,
+                                   1 if (not bench or bench["config"]["pool_mode"] == "f16x3") else 0)
 if stats:
     lines += ["## `--kernel-trace --stats` (kernel_stats.csv)", "", "| kernel | calls | avg ms | min ms | max ms | % |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(stats[0])):
@@ -25,7 +25,7 @@ if stats:
             kern_ms = float(r["AverageNs"]) / 1e6
     lines.append("")
 def pmc(sub):
-    f = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
     agg = collections.defaultdict(list)
     if f:
         for r in csv.DictReader(open(f[0])):
