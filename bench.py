@@ -58,6 +58,88 @@ def cpu_baseline(n_sample, seed):
                       "LUTs and whitening matrix built once (the reference rebuilds them per patch)"}
 
 
+def pipeline_extras(lfp, torch, device):
+    """Secondary figures (rank 0, N = 1, never allowed to break the headline line): the rows built around the describe
+    path, on BASELINE.json's other configurations.  Smooth-noise frames synthesised on the GPU."""
+    def frames(count, h, w, sigma, seed):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        x = torch.rand((count, 1, h, w), device="cuda", generator=g)
+        r = int(3 * sigma)
+        k = torch.exp(-0.5 * (torch.arange(-r, r + 1, device="cuda") / sigma) ** 2)
+        k /= k.sum()
+        x = torch.nn.functional.conv2d(x, k.view(1, 1, 1, -1), padding=(0, r))
+        x = torch.nn.functional.conv2d(x, k.view(1, 1, -1, 1), padding=(r, 0))
+        lo, hi = x.amin(dim=(2, 3), keepdim=True), x.amax(dim=(2, 3), keepdim=True)
+        return ((x - lo) / (hi - lo))[:, 0].contiguous()
+
+    side = torch.cuda.Stream()       # the library reads a NULL stream as "its own": time on a real one
+    out = {}
+    with torch.cuda.stream(side):
+        s = side.cuda_stream
+        # configs[4]: 4K frame, detect + describe as one hipGraph launch per frame
+        w, h, top_n = 3840, 2160, 6000
+        cap = 2 * top_n
+        hnd = lfp.MkdHandle(max_features=cap, max_image_width=w, max_image_height=h, pool_mode=lfp.POOL_F16X3,
+                            max_blobs=1 << 16, device=device)
+        imgs = frames(2, h, w, 2.5, 7)
+        d_img = torch.empty((h, w), device="cuda")
+        kps, desc = torch.empty((cap, 5), device="cuda"), torch.empty((cap, 128), device="cuda")
+        cnt = torch.zeros((8,), dtype=torch.int64, device="cuda")
+        hnd.stream_create(w, h, top_n, 0.0, cap, d_img.data_ptr(), kps.data_ptr(), desc.data_ptr(), cnt.data_ptr())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        lat = []
+        for f in range(12):
+            d_img.copy_(imgs[f % 2])
+            e0.record(side)
+            hnd.stream_frame(s)
+            e1.record(side)
+            side.synchronize()
+            if f >= 2:
+                lat.append(e0.elapsed_time(e1))
+        lat.sort()
+        out["configs4_4k_frame_hipgraph"] = {"ms_per_frame": lat[len(lat) // 2], "keypoints": int(cnt[3].item()),
+                                             "extrema": int(cnt[0].item()), "what": "detect top-6000 + orient + describe"}
+        del hnd, imgs, d_img, kps, desc
+        # configs[2]: 256 frames 640x480 in one batch, detect + describe
+        w, h, top_n, nf = 640, 480, 1400, 256
+        cap = 2 * top_n * nf
+        hnd = lfp.MkdHandle(max_features=cap, max_image_width=w, max_image_height=h, pool_mode=lfp.POOL_F16X3,
+                            max_frames=nf, device=device)
+        imgs = frames(nf, h, w, 1.8, 8)
+        kps, desc = torch.empty((cap, 5), device="cuda"), torch.empty((cap, 128), device="cuda")
+        fo = torch.empty((cap,), dtype=torch.int32, device="cuda")
+        run = lambda: hnd.detect_frames_device(imgs.data_ptr(), nf, w, h, top_n, 0.0, kps.data_ptr(), fo.data_ptr(),
+                                               desc.data_ptr(), cap, s)
+        run()
+        side.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            m, _, _ = run()
+        side.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        out["configs2_256x640x480_batch"] = {"ms_per_batch": dt * 1e3, "keypoints": m, "descriptors_per_s": m / dt,
+                                             "what": "detect top-1400 per frame + orient + describe, one call"}
+        del hnd, imgs, kps, desc, fo
+        # matcher (the stage the configs[3] all-gather feeds): 65536 x 65536 descriptors
+        n = 65536
+        g = torch.Generator(device="cuda").manual_seed(9)
+        a = torch.nn.functional.normalize(torch.randn((n, 128), device="cuda", generator=g), dim=1)
+        b = torch.nn.functional.normalize(torch.randn((n, 128), device="cuda", generator=g), dim=1)
+        mt = torch.empty(n, dtype=torch.int32, device="cuda")
+        hnd = lfp.MkdHandle(max_features=64, device=device)
+        hnd.match_device(a.data_ptr(), n, b.data_ptr(), n, mt.data_ptr(), 0.8, stream=s)
+        side.synchronize()
+        e0.record(side)
+        for _ in range(3):
+            hnd.match_device(a.data_ptr(), n, b.data_ptr(), n, mt.data_ptr(), 0.8, stream=s)
+        e1.record(side)
+        side.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        out["matcher_65536x65536"] = {"ms": ms, "similarities_per_s": n * n / (ms * 1e-3),
+                                      "f16_mfma_pflops": n * n * 128 * 2 * 3 / (ms * 1e-3) / 1e15}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +149,7 @@ def main():
     ap.add_argument("--angle", choices=["shader", "exact"], default="shader")
     ap.add_argument("--pool", choices=["f32", "f16x3"], default=os.environ.get("LF_MKD_POOL", "f16x3"))
     ap.add_argument("--cpu-sample", type=int, default=-1, help="patches for the CPU baseline (0: skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary pipeline figures")
     args = ap.parse_args()
 
     import torch
@@ -170,6 +253,13 @@ def main():
                          "kernel": "mkd_pool", "kernel_ms": kern_s * 1e3,
                          "algorithmic_bytes_per_launch": BYTES_PER_DESC * n},
         }
+        if world == 1 and not args.no_extras:
+            del patches, out
+            torch.cuda.empty_cache()
+            try:
+                line["pipelines"] = pipeline_extras(lfp, torch, local_rank)
+            except Exception as e:       # secondary figures must never cost the headline
+                line["pipelines"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1:
             ns = args.cpu_sample
             if ns < 0:
