@@ -683,6 +683,7 @@ __device__ __forceinline__ float tex_bilinear(const float *__restrict__ img, int
 // centre (both fractions 0), the side taps have fraction 0 across the pass direction.
 __device__ __forceinline__ float sep3_pixel(const float *__restrict__ in, int w, int h, int x, int y, float w0, float w1,
                                             float off, int vertical) {
+#pragma clang fp contract(off)   // the detector's decisions sit on these values: round like the restatement they are tested against
     const float c = (float)(vertical ? y : x) + 0.5f;
     const int n = vertical ? h : w;
     const long stride = vertical ? w : 1;
@@ -725,6 +726,7 @@ __global__ __launch_bounds__(256) void pyr_sep3(const float *__restrict__ in, fl
 // swt.glsl:24-58: [1 4 6 4 1]/16 at texel centres, taps d = 2^in_level apart, mirrored.
 __global__ __launch_bounds__(256) void pyr_swt(const float *__restrict__ in, float *__restrict__ out, long in_stride,
                                                long out_stride, int w, int h, int vertical, int d) {
+#pragma clang fp contract(off)
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (y >= h) return;
     in += blockIdx.z * in_stride;
@@ -792,6 +794,7 @@ __global__ void pyr_decimate(const float *__restrict__ in, float *__restrict__ o
 // blur_pyramid.glsl:36-49 vertical pass: binomial taps centred on texel (2x, 2y) of the H result.
 __global__ void pyr_down_v(const float *__restrict__ in, float *__restrict__ out, long in_stride, long out_stride,
                            int w, int h, int ow, int oh) {
+#pragma clang fp contract(off)
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= ow || y >= oh) return;
     in += blockIdx.z * in_stride;

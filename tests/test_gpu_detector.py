@@ -260,3 +260,44 @@ def test_stream_pipeline_is_retired_when_its_buffers_move(lfp, torch):
     h.stream_frame()
     h.synchronize()
     assert int(d_c[3].item()) == first
+
+
+def test_4k_frame_at_baseline_size(lfp, torch, oracle):
+    """BASELINE configs[4] size: a 3840x2160 frame.  Extrema and keypoints against the oracle at full size (the
+    oracle needs a few seconds for it), and the hipGraph pipeline against lf_mkd_detect."""
+    w, hgt = 3840, 2160
+    rng = np.random.default_rng(4)
+    img = rng.random((hgt, w)).astype(np.float32)
+    for _ in range(2):
+        img = (img + np.roll(img, 1, 0) + np.roll(img, -1, 0) + np.roll(img, 1, 1) + np.roll(img, -1, 1)) / 5
+    img = np.ascontiguousarray((img - img.min()) / (img.max() - img.min()), np.float32)
+    cap = 1 << 18
+    h = lfp.MkdHandle(max_features=8192, max_image_width=w, max_image_height=hgt, max_blobs=cap,
+                      pool_mode=lfp.POOL_F16X3)
+    h.set_image(img)
+    st = oracle.build_coarse_stack(img)
+    want, total = oracle.scan_extrema(oracle.dog(st))
+    got, dropped = h.detect_extrema(max_out=cap)
+    assert dropped == 0 and total == len(want) > 50000
+    assert_same_extrema(got, want, "4K")
+    # orientation of the 6000 strongest, as detect_top_n would pick them
+    keep = oracle.topk_filter(want, 6000)
+    k_want = oracle.orient(st, want[keep])
+    k_got, _ = h.orient_keypoints(got[keep])
+    assert k_got.shape == k_want.shape
+    d = np.abs(k_got[:, 3] - k_want[:, 3])
+    assert (np.minimum(d, 360 - d) < 1e-3).mean() > 0.995     # int(x) of a position 1e-4 from an integer may differ
+    # the recorded pipeline gives what lf_mkd_detect gives
+    kcap = 16384
+    d_img = torch.from_numpy(img).cuda()
+    d_k, d_d = torch.zeros((kcap, 5), device="cuda"), torch.zeros((kcap, 128), device="cuda")
+    d_c = torch.zeros((8,), dtype=torch.int64, device="cuda")
+    h.stream_create(w, hgt, 6000, 0.0, kcap, d_img.data_ptr(), d_k.data_ptr(), d_d.data_ptr(), d_c.data_ptr())
+    h.stream_frame()
+    h.synchronize()
+    ref = lfp.MkdHandle(max_features=kcap, max_image_width=w, max_image_height=hgt, max_blobs=cap, pool_mode=lfp.POOL_F16X3)
+    rk, rd, _, _ = ref.detect(img, 6000, 0.0, kcap)
+    n = int(d_c[3].item())
+    assert n == len(rk) > 6000 and int(d_c[0].item()) == total and int(d_c[2].item()) == 6000
+    assert np.array_equal(d_k[:n].cpu().numpy(), rk) and np.array_equal(d_d[:n].cpu().numpy(), rd)
+    assert np.allclose(np.linalg.norm(rd, axis=1), 1.0, atol=1e-5)

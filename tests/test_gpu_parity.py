@@ -143,6 +143,21 @@ def test_keypoint_mode_vs_oracle_larger_frame(lfp, oracle):
     assert_keypoint_parity(oracle, lf._inner, img, k5, d)
 
 
+def test_pyramid_levels_are_bit_exact(lfp, oracle):
+    """Every level of the patch pyramid equals the oracle's bit for bit (blur, a-trous, blits and the binomial
+    decimation are evaluated in the shader's operation order, without fma contraction)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_golden import smooth_image
+    for w, hgt in ((640, 480), (333, 257), (97, 64), (1920, 1080)):
+        img = np.ascontiguousarray(smooth_image(hgt, w, w), np.float32)
+        h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt)
+        h.set_image(img)
+        pyr = oracle.split_pyramid(oracle.build_pyramid(img), w, hgt)
+        for l, lv in enumerate(pyr):
+            assert np.array_equal(h.pyramid_level(l), lv), (w, hgt, l)
+
+
 def test_full_size_properties(lfp, torch):
     """BASELINE-sized batch (2^18 patches = 1 GiB) checked through size-independent properties:
     unit norm, equality with the small-batch path on a subset, and invariance to batch layout."""
