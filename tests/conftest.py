@@ -65,8 +65,10 @@ def assert_patch_parity(oracle, patches, desc, atan_mode, gate=GATE, what=""):
     return max(e_c.max(initial=0.0), e_s[clean].max(initial=0.0))
 
 
-def assert_keypoint_parity(oracle, handle, img, kps5, desc, gate=GATE, what=""):
-    """desc = the library's descriptors of keypoints kps5 [n,5] on img (already set on `handle`)."""
+def assert_keypoint_parity(oracle, handle, img, kps5, desc, gate=GATE, what="", patch_tol=1e-5):
+    """desc = the library's descriptors of keypoints kps5 [n,5] on img (already set on `handle`).
+    patch_tol: the sampling positions of the two sides differ by ~1e-5 texel (different libm sin/cos/exp2); on smooth
+    test frames that is 1e-6 in the sampled values, on a sharp photograph up to the local gradient times that."""
     import torch
     from oracle import ATAN_SHADER
     img = np.ascontiguousarray(img, np.float32)
@@ -79,7 +81,7 @@ def assert_keypoint_parity(oracle, handle, img, kps5, desc, gate=GATE, what=""):
     handle.synchronize()
     got_p = d_p.cpu().numpy()
     ref_p = oracle.sample_patches(oracle.build_pyramid(img), w, hgt, kps5[:, :4])
-    assert np.abs(got_p - ref_p).max(initial=0.0) < 1e-5, (what, "sampled patches")
+    assert np.abs(got_p - ref_p).max(initial=0.0) < patch_tol, (what, "sampled patches", np.abs(got_p - ref_p).max())
     assert_patch_parity(oracle, got_p, desc, ATAN_SHADER, gate, what)        # describe stage, shared input bits
     clean = (oracle.quirk_pixels(got_p) == 0) & (oracle.quirk_pixels(ref_p) == 0)
     e = rel_l2(desc, oracle.describe_patches(ref_p, nthreads=8))             # end to end
