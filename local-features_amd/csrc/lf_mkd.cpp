@@ -43,8 +43,7 @@ struct lf_mkd {
     unsigned long long *d_totals = nullptr;
     // detector scratch (allocated on first use): per-cube slots and counts for max_frames frames of the maximum size
     uint64_t max_extrema = 8192;
-    float *d_slots = nullptr, *d_det_extrema = nullptr, *d_det_selected = nullptr, *d_det_kps = nullptr,
-          *d_det_desc = nullptr;
+    float *d_slots = nullptr, *d_det_extrema = nullptr, *d_det_selected = nullptr, *d_det_desc = nullptr;
     unsigned *d_cube_counts = nullptr, *d_cube_sums = nullptr, *d_sel_count = nullptr;
     uint64_t det_out_cap = 0, det_sel_cap = 0;
     // multi-frame detect (lf_mkd_detect_frames_device)
@@ -182,7 +181,7 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     return LF_MKD_OK;
 }
 
-// pooled sums -> descriptors for one batch already resident on the device
+// LF_MKD_FLAG_KERNEL_TIMING: an event on the launch stream before and after every describe launch
 int mark(lf_mkd *h, hipStream_t s) {
     if (!(h->params.flags & LF_MKD_FLAG_KERNEL_TIMING)) return LF_MKD_OK;
     hipEvent_t e;
@@ -197,6 +196,7 @@ int mark(lf_mkd *h, hipStream_t s) {
     return LF_MKD_OK;
 }
 
+// patches of one batch, already resident on the device -> descriptors (or the un-whitened 238-D vectors)
 int run_batch(lf_mkd *h, const float *d_patches, uint64_t n, float *d_out, float *d_raw, hipStream_t s) {
     if (int rc = mark(h, s)) return rc;
     launch_describe(d_patches, long(n), nullptr, h->dc, h->params.angle_mode, h->params.pool_mode, d_out ? d_out : h->d_out,
@@ -209,6 +209,7 @@ int run_batch(lf_mkd *h, const float *d_patches, uint64_t n, float *d_out, float
 // A recorded stream pipeline holds raw pointers into the scratch buffers: re-allocating one of them retires the graph
 // (lf_mkd_stream_frame then asks for a new lf_mkd_stream_create instead of touching freed memory).
 void retire_graph(lf_mkd *h) {
+    if (h->graph_exec) (void)hipDeviceSynchronize();   // a launch of it may still be running (on any stream)
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     h->graph_exec = nullptr;
@@ -274,7 +275,7 @@ int ensure_detect_scratch(lf_mkd *h) {
     LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_slots), cubes * 8 * 4 * sizeof(float)));
     LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_cube_counts), cubes * 4));
     LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_cube_sums), ((cubes + 1023) / 1024 + 1) * 4));
-    LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_sel_count), 4 * h->max_frames));
+    if (!h->d_sel_count) LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_sel_count), 4 * h->max_frames));
     return LF_MKD_OK;
 }
 
@@ -370,12 +371,12 @@ int lf_mkd_create_from_file(const lf_mkd_params *params, const char *path, lf_mk
 void lf_mkd_destroy(lf_mkd *h) {
     if (!h) return;
     (void)hipSetDevice(h->params.device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipDeviceSynchronize();   // work of this handle may be in flight on the caller's streams too
     void *ptrs[] = {h->dc.phi_cs,      h->dc.colmap,     h->dc.pool_b_f32, h->dc.pool_b_f16, h->dc.white_a_f16,
                     h->dc.white_a_f32, h->dc.white_bias, h->d_patches,     h->d_out,         h->d_kps,
                     h->d_image,        h->d_pyr,         h->d_tmp_a,       h->d_tmp_b,       h->d_coarse,
                     h->d_extrema,      h->d_angles,      h->d_counts,      h->d_kps_out,     h->d_totals,
-                    h->d_slots,        h->d_det_extrema, h->d_det_selected, h->d_det_kps,    h->d_det_desc,
+                    h->d_slots,        h->d_det_extrema, h->d_det_selected, h->d_det_desc,
                     h->d_cube_counts,  h->d_cube_sums,   h->d_sel_count,   h->d_match_a,     h->d_match_b,
                     h->d_orient_sums,
                     h->d_match_part,   h->d_match_in,    h->d_match_out,   h->d_mf_padded,   h->d_mf_list,
