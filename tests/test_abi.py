@@ -64,3 +64,15 @@ def test_no_gpu_fails_loudly():
         pytest.skip("a GPU is present")
     with pytest.raises(RuntimeError, match="Failed to initialize local features"):
         lfp.LocalFeatures(640, 480, 100)
+
+
+def test_cpp_header_compiles_against_the_library(tmp_path):
+    """include/local_features.hpp (C++ mirror of the reference crate's API) builds with plain g++ and links."""
+    import subprocess
+    from conftest import ROOT
+    lib_dir = os.path.join(ROOT, "local-features_amd")
+    if not os.path.exists(os.path.join(lib_dir, "liblf_mkd.so")):
+        pytest.skip("liblf_mkd.so not built")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "demo_local_features.cpp"), "-L", lib_dir, "-llf_mkd",
+                           "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(tmp_path / "demo")])
