@@ -673,9 +673,8 @@ __device__ __forceinline__ float tex_bilinear(const float *__restrict__ img, int
 
 // All pyramid kernels work on a batch of frames of one size: blockIdx.z = frame, consecutive frames are
 // in_stride / out_stride floats apart.
-// Full-resolution passes: a workgroup of (64, 4) threads covers a 256 x 4 strip, each thread four pixels 64 apart,
-// so that every thread has its 20 (a-trous) or 20 (sep3) loads in flight at once.  Strips that cannot touch the
-// frame border skip the mirror arithmetic.
+// Full-resolution blur passes: a workgroup of (64, 4) threads covers a 256 x 4 strip, each thread four pixels 64
+// apart, so that every thread has its 20 loads in flight at once.
 //
 // blur.glsl:34-65 (sigma 0.6) and blur_pyramid.glsl horizontal pass share this shape:
 // out = w0 * tex(c) + w1 * (tex(c - off) + tex(c + off)) along one axis.  The bilinear fetch is evaluated exactly as
@@ -723,57 +722,55 @@ __global__ __launch_bounds__(256) void pyr_sep3(const float *__restrict__ in, fl
     }
 }
 
-// swt.glsl:24-58: [1 4 6 4 1]/16 at texel centres, taps d = 2^in_level apart, mirrored.
-__global__ __launch_bounds__(256) void pyr_swt(const float *__restrict__ in, float *__restrict__ out, long in_stride,
-                                               long out_stride, int w, int h, int vertical, int d) {
+// swt.glsl:24-58, both passes in one launch: [1 4 6 4 1]/16 at texel centres, taps d = 2^in_level apart, mirrored,
+// horizontal pass then vertical pass.  The reference runs them as two dispatches through a scratch layer; here a
+// workgroup keeps the horizontal results it needs in LDS, so a layer costs one read and one write of the frame
+// instead of two of each.  A workgroup owns a 256-column strip and kSwtRows output rows of ONE residue class modulo d
+// (rows r, r + d, r + 2d, ...): their vertical taps are rows of the same class, so kSwtRows + 4 horizontal rows
+// serve kSwtRows outputs whatever the dilation.  Slot m of the LDS tile stands for the virtual row r + m d and holds
+// the horizontal pass of the row that index mirrors to -- which is the row the two-pass form would have read.
+// Operation order and rounding are those of the two dispatches (no contraction): results are bit-identical.
+constexpr int kSwtRows = 12, kSwtCols = 256;
+
+__global__ __launch_bounds__(256) void pyr_swt_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
+                                                     long out_stride, int w, int h, int d, int blocks_per_class) {
 #pragma clang fp contract(off)
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (y >= h) return;
+    __shared__ float s_h[kSwtRows + 4][kSwtCols];
+    const float k0 = 6.f / 16.f, k1 = 4.f / 16.f, k2 = 1.f / 16.f;
     in += blockIdx.z * in_stride;
     out += blockIdx.z * out_stride;
-    const float k0 = 6.f / 16.f, k1 = 4.f / 16.f, k2 = 1.f / 16.f;
-    const int xs = blockIdx.x * 256;
-    float v[4][5];
-    if (!vertical) {
-        const float *row = in + (size_t)y * w;
-        const bool interior = xs - 2 * d >= 0 && xs + 255 + 2 * d < w;   // uniform over the workgroup
+    const int r = blockIdx.y / blocks_per_class;                    // residue class of the rows
+    const int kb = (blockIdx.y - r * blocks_per_class) * kSwtRows;  // first lattice index of this workgroup
+    const int xs = (int)blockIdx.x * kSwtCols;   // signed: xs - 2 d must be able to go negative
+    const int xr = xs + (int)threadIdx.x, x = xr < w ? xr : w - 1;
+    const bool interior = xs - 2 * d >= 0 && xs + kSwtCols - 1 + 2 * d < w;
+    int xi[5];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int xr = xs + threadIdx.x + 64 * j, x = xr < w ? xr : w - 1;
-#pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                const int i = x + (t - 2) * d;
-                v[j][t] = row[interior ? i : mirror_idx(i, w)];
-            }
-        }
-    } else {
-        const bool interior = y - 2 * d >= 0 && y + 2 * d < h;
-        int yy[5];
-#pragma unroll
-        for (int t = 0; t < 5; ++t) yy[t] = interior ? y + (t - 2) * d : mirror_idx(y + (t - 2) * d, h);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int xr = xs + threadIdx.x + 64 * j, x = xr < w ? xr : w - 1;
-#pragma unroll
-            for (int t = 0; t < 5; ++t) v[j][t] = in[(size_t)yy[t] * w + x];
-        }
+    for (int t = 0; t < 5; ++t) xi[t] = interior ? x + (t - 2) * d : mirror_idx(x + (t - 2) * d, w);
+    // horizontal pass of the kSwtRows + 4 rows this workgroup's outputs reach
+#pragma unroll 4
+    for (int m = 0; m < kSwtRows + 4; ++m) {
+        const int v = r + (kb + m - 2) * d;                // virtual row of slot m
+        const float *row = in + (size_t)mirror_idx(v, h) * w;
+        float sum = row[xi[2]] * k0;
+        sum += row[xi[0]] * k2;
+        sum += row[xi[1]] * k1;
+        sum += row[xi[3]] * k1;
+        sum += row[xi[4]] * k2;
+        s_h[m][threadIdx.x] = sum;
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int x = xs + threadIdx.x + 64 * j;
-        float s = v[j][2] * k0;
-        if (!vertical) {   // the shader's tap order differs between the passes (swt.glsl:38-56)
-            s += v[j][0] * k2;
-            s += v[j][1] * k1;
-            s += v[j][3] * k1;
-            s += v[j][4] * k2;
-        } else {
-            s += v[j][1] * k1;
-            s += v[j][0] * k2;
-            s += v[j][4] * k2;
-            s += v[j][3] * k1;
-        }
-        if (x < w) out[(size_t)y * w + x] = s;
+    __syncthreads();
+    // vertical pass: output row r + (kb + k) d reads slots k .. k + 4
+#pragma unroll 4
+    for (int k = 0; k < kSwtRows; ++k) {
+        const int y = r + (kb + k) * d;
+        if (y >= h) break;
+        float sum = s_h[k + 2][threadIdx.x] * k0;
+        sum += s_h[k + 1][threadIdx.x] * k1;
+        sum += s_h[k][threadIdx.x] * k2;
+        sum += s_h[k + 4][threadIdx.x] * k2;
+        sum += s_h[k + 3][threadIdx.x] * k1;
+        if (xr < w) out[(size_t)y * w + xr] = sum;
     }
 }
 
@@ -837,7 +834,8 @@ __global__ __launch_bounds__(256) void sample_patches(const float *__restrict__ 
     float lvl = floorf(l2);
     lvl = lvl < 0.f ? 0.f : (lvl > (float)(pd.levels - 1) ? (float)(pd.levels - 1) : lvl);
     const float rem = exp2f(l2 - lvl);
-    const int l = (int)lvl;
+    int l = (int)lvl;   // a non-finite size (caller-supplied keypoints) must not index outside the pyramid
+    l = l < 0 ? 0 : (l > pd.levels - 1 ? pd.levels - 1 : l);
     const float ang = kp[3] * (3.14159265358979323846f / 180.f);
     const float ca = cosf(ang), sa = sinf(ang);
     const float inv = 1.f / exp2f(lvl);
@@ -1502,6 +1500,16 @@ void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc 
 
 // Builds the pyramids of `frames` frames (image_stride floats apart) into pyr (pyr_stride apart); tmp_a and tmp_b
 // hold frames x w x h floats each.
+// one a-trous layer (both passes) for `frames` frames
+static void launch_swt(const float *in, long in_stride, float *out, long out_stride, int w, int h, int d, int frames,
+                       hipStream_t stream) {
+    const int classes = d < h ? d : h;                                   // residue classes that hold rows
+    const int lattice = (h + d - 1) / d;                                 // rows of the longest class
+    const int per_class = (lattice + kSwtRows - 1) / kSwtRows;
+    hipLaunchKernelGGL(pyr_swt_fused, dim3((w + kSwtCols - 1) / kSwtCols, classes * per_class, frames), dim3(256), 0, stream,
+                       in, out, in_stride, out_stride, w, h, d, per_class);
+}
+
 // With layer1 != nullptr the a-trous layer 1 the pyramid needs anyway is written there (frames layer1_stride apart) instead
 // of tmp_b: it is layer 1 of the stack orientation and the detector read, so they need not build it again.
 void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,
@@ -1519,11 +1527,9 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
                        w, h, 0.66381836f, 0.16809084f, 1.015267163f, 1);
     if (pd.levels < 2) return;
     // level 1: one a-trous pass over level 0, nearest-decimated
-    hipLaunchKernelGGL(pyr_swt, sgrid(w, h), strip, 0, stream, (const float *)(pyr + pd.offset[0]), tmp_a, pyr_stride,
-                       ts, w, h, 0, 1);
     float *l1 = layer1 ? layer1 : tmp_b;
     const long l1s = layer1 ? layer1_stride : ts;
-    hipLaunchKernelGGL(pyr_swt, sgrid(w, h), strip, 0, stream, (const float *)tmp_a, l1, ts, l1s, w, h, 1, 1);
+    launch_swt(pyr + pd.offset[0], pyr_stride, l1, l1s, w, h, 1, frames, stream);
     hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)l1, pyr + pd.offset[1],
                        l1s, pyr_stride, w, h, pd.w[1], pd.h[1]);
     // levels >= 2: binomial H at the resolution of level l-1, then V with 2x decimation
@@ -1541,14 +1547,11 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
 void launch_build_coarse_stack(const float *layer0, long layer0_stride, float *coarse, long coarse_stride,
                                long layer_stride, float *tmp, int n_layers, int first_layer, int w, int h, int frames,
                                hipStream_t stream) {
-    const long ts = (long)w * h;
-    const dim3 blk(64, 4), grid((w + 255) / 256, (h + 3) / 4, frames);
+    (void)tmp;
     for (int l = first_layer; l + 1 < n_layers; ++l) {   // first_layer = 1: layer 1 came with the pyramid
         const float *in = l == 0 ? layer0 : coarse + (long)(l - 1) * layer_stride;
         const long in_stride = l == 0 ? layer0_stride : coarse_stride;
-        hipLaunchKernelGGL(pyr_swt, grid, blk, 0, stream, in, tmp, in_stride, ts, w, h, 0, 1 << l);
-        hipLaunchKernelGGL(pyr_swt, grid, blk, 0, stream, (const float *)tmp, coarse + (long)l * layer_stride, ts,
-                           coarse_stride, w, h, 1, 1 << l);
+        launch_swt(in, in_stride, coarse + (long)l * layer_stride, coarse_stride, w, h, 1 << l, frames, stream);
     }
 }
 

@@ -277,6 +277,23 @@ def test_keypoint_edge_cases_vs_oracle(lfp, oracle):
     assert rel_l2(d, ref).max() < GATE
 
 
+def test_non_finite_keypoints_do_not_reach_outside_the_pyramid(lfp):
+    """Caller-supplied keypoints are data: NaN / inf / negative sizes and positions must at worst give NaN descriptors for
+    those rows, never an out-of-range level index (the call returns and the other rows are untouched)."""
+    w, hgt = 160, 120
+    img = np.random.default_rng(8).random((hgt, w)).astype(np.float32)
+    h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt)
+    h.set_image(img)
+    good = np.array([[80.0, 60.0, 4.0, 30.0, 0.0]], np.float32)
+    bad = np.array([[80, 60, np.nan, 0, 0], [80, 60, np.inf, 0, 0], [80, 60, -3.0, 0, 0], [80, 60, 0.0, 0, 0],
+                    [np.nan, 60, 4, 0, 0], [80, np.inf, 4, 0, 0], [80, 60, 4, np.nan, 0], [1e30, -1e30, 1e30, 1e30, 0]],
+                   np.float32)
+    d = h.describe_keypoints(np.concatenate([good, bad, good]))
+    assert d.shape == (10, 128)
+    assert np.array_equal(d[0], d[9]) and np.isfinite(d[0]).all() and abs(np.linalg.norm(d[0]) - 1) < 1e-5
+    assert np.array_equal(d[0], h.describe_keypoints(good)[0])
+
+
 def test_non_square_and_odd_sized_frames(lfp, oracle):
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
