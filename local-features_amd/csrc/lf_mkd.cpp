@@ -44,7 +44,8 @@ struct lf_mkd {
     // detector scratch (allocated on first use): per-cube slots and counts for max_frames frames of the maximum size
     uint64_t max_extrema = 8192;
     float *d_slots = nullptr, *d_det_extrema = nullptr, *d_det_selected = nullptr, *d_det_desc = nullptr;
-    unsigned *d_cube_counts = nullptr, *d_cube_sums = nullptr, *d_sel_count = nullptr;
+    unsigned *d_cube_counts = nullptr, *d_cube_sums = nullptr, *d_sel_count = nullptr, *d_topk_work = nullptr;
+    uint64_t topk_work_cap = 0;
     uint64_t det_out_cap = 0, det_sel_cap = 0;
     // multi-frame detect (lf_mkd_detect_frames_device)
     float *d_mf_padded = nullptr, *d_mf_list = nullptr;
@@ -378,7 +379,7 @@ void lf_mkd_destroy(lf_mkd *h) {
                     h->d_extrema,      h->d_angles,      h->d_counts,      h->d_kps_out,     h->d_totals,
                     h->d_slots,        h->d_det_extrema, h->d_det_selected, h->d_det_desc,
                     h->d_cube_counts,  h->d_cube_sums,   h->d_sel_count,   h->d_match_a,     h->d_match_b,
-                    h->d_orient_sums,
+                    h->d_orient_sums,  h->d_topk_work,
                     h->d_match_part,   h->d_match_in,    h->d_match_out,   h->d_mf_padded,   h->d_mf_list,
                     h->d_mf_frame_start, h->d_mf_offsets, h->d_mf_frame_of};
     for (void *p : ptrs)
@@ -640,8 +641,9 @@ int lf_mkd_filter_extrema_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, ui
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     if (!h->d_sel_count) LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_sel_count), 4 * h->max_frames));
+    if (int rc = grow(h, &h->d_topk_work, &h->topk_work_cap, topk_work_words(n), 4)) return rc;
     launch_topk_filter(reinterpret_cast<const float *>(d_extrema), nullptr, nullptr, n, 1, 0xFFFFFFFFu, top_n, min_size,
-                       reinterpret_cast<float *>(d_out), d_index, h->d_sel_count, nullptr, s);
+                       reinterpret_cast<float *>(d_out), d_index, h->d_sel_count, nullptr, n, h->d_topk_work, s);
     LF_HIP(h, hipGetLastError());
     unsigned cnt = 0;
     LF_HIP(h, hipMemcpyAsync(&cnt, h->d_sel_count, 4, hipMemcpyDeviceToHost, s));
@@ -726,7 +728,8 @@ int lf_mkd_detect_frames_device(lf_mkd *h, const float *d_images, uint32_t n_fra
                           h->d_slots, h->d_cube_counts, h->d_cube_sums, h->d_det_extrema, nullptr, h->d_mf_frame_start,
                           all_cap, h->d_totals + 0, s);
     launch_topk_filter(h->d_det_extrema, h->d_mf_frame_start, h->d_totals + 0, 0, n_frames, unsigned(cap_f),
-                       unsigned(keep), top_n ? min_size : -INFINITY, h->d_mf_padded, nullptr, h->d_sel_count, nullptr, s);
+                       unsigned(keep), top_n ? min_size : -INFINITY, h->d_mf_padded, nullptr, h->d_sel_count, nullptr, 0,
+                       nullptr, s);
     launch_segments_compact(h->d_mf_padded, h->d_sel_count, h->d_mf_frame_start, h->d_totals + 0, n_frames,
                             unsigned(cap_f), unsigned(keep), h->d_mf_offsets, h->d_mf_list, h->d_mf_frame_of,
                             h->d_totals + 2, s);
@@ -771,8 +774,10 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
     if (int rc = ensure_detect_scratch(h)) return rc;
     if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, h->max_extrema, sizeof(lf_mkd_extremum))) return rc;
     const uint64_t cap = top_n ? top_n : h->max_extrema;   // extrema that can reach orientation
-    if (top_n)
+    if (top_n) {
         if (int rc = grow(h, &h->d_det_selected, &h->det_sel_cap, top_n, sizeof(lf_mkd_extremum))) return rc;
+        if (int rc = grow(h, &h->d_topk_work, &h->topk_work_cap, topk_work_words(h->max_extrema), 4)) return rc;
+    }
     if (int rc = ensure_orient_scratch(h, cap, false, 0)) return rc;
     if (int rc = grow(h, &h->d_stream_patches, &h->stream_patch_cap, max_out * kPx, sizeof(float))) return rc;
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(d_counts);
@@ -792,7 +797,7 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
     const unsigned long long *n_sel = cnt + 0;
     if (top_n) {
         launch_topk_filter(h->d_det_extrema, nullptr, cnt + 0, 0, 1, 0xFFFFFFFFu, top_n, min_size, h->d_det_selected, nullptr,
-                           h->d_sel_count, cnt + 2, s);
+                           h->d_sel_count, cnt + 2, h->max_extrema, h->d_topk_work, s);
         d_sel = h->d_det_selected;
         n_sel = cnt + 2;
     }

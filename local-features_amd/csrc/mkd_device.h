@@ -68,7 +68,9 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, const float 
 void launch_topk_filter(const float *extrema, const unsigned *seg_start, const unsigned long long *n_in,
                         unsigned long long n_host, unsigned n_frames, unsigned seg_cap, unsigned n_keep, float min_size,
                         float *out, unsigned *out_index, unsigned *out_count, unsigned long long *out_count64,
-                        hipStream_t stream);
+                        unsigned long long n_cap, unsigned *work, hipStream_t stream);
+// u32 words of `work` for lists of up to n_cap extrema (work may be null: one workgroup per frame is used then)
+size_t topk_work_words(unsigned long long n_cap);
 // per-frame padded selections [frames][n_keep] + counts -> contiguous list + frame ids; totals[0] = entries,
 // totals[1] = extrema dropped by the per-frame cap seg_cap
 void launch_segments_compact(const float *padded, const unsigned *counts, const unsigned *seg_start,

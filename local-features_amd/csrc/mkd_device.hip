@@ -1451,6 +1451,139 @@ __global__ __launch_bounds__(1024) void topk_filter(const float *__restrict__ ex
     }
 }
 
+// The same selection for ONE long list (a 4K frame yields tens of thousands of extrema), spread over the chip: per
+// radix byte one histogram launch over all workgroups and one 256-thread launch that picks the bin, then the ordered
+// compaction in the three-launch form.  work (u32): [0,256) histogram, [256] prefix, [257] rank, [258] done,
+// [259] cutoff key, [264,268) two u64 totals, [272...) sums of the compaction.
+constexpr int kTopkState = 256, kTopkTotals = 264, kTopkSums = 272;
+
+__global__ void topk_init(unsigned *__restrict__ work, unsigned n_keep) {
+    work[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        work[kTopkState + 0] = 0;        // prefix
+        work[kTopkState + 1] = n_keep;   // rank wanted (0-based, descending)
+        work[kTopkState + 2] = 0;        // done: every blob that passes min_size is kept
+        work[kTopkState + 3] = 0;        // cutoff key
+    }
+}
+
+__global__ __launch_bounds__(1024) void topk_hist(const float *__restrict__ extrema, const unsigned long long *__restrict__ n_in,
+                                                  unsigned long long n_host, float min_size, int shift,
+                                                  unsigned *__restrict__ work) {
+    __shared__ unsigned lh[16][256];   // one histogram per wave: lanes of different waves never collide
+    if (work[kTopkState + 2]) return;
+    const unsigned n = (unsigned)(n_in ? n_in[0] : n_host);
+    const unsigned prefix = work[kTopkState + 0];
+    const unsigned mask = shift == 24 ? 0u : 0xFFFFFFFFu << (shift + 8);
+    const int wave = threadIdx.x >> 6;
+    for (int b = threadIdx.x; b < 16 * 256; b += 1024) (&lh[0][0])[b] = 0;
+    __syncthreads();
+    float sz[4], ct[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned i = blockIdx.x * 4096u + threadIdx.x + 1024u * j;
+        sz[j] = i < n ? extrema[(size_t)i * 4 + 2] : 0.f;
+        ct[j] = i < n ? extrema[(size_t)i * 4 + 3] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned i = blockIdx.x * 4096u + threadIdx.x + 1024u * j;
+        const unsigned k = __float_as_uint(fabsf(ct[j]));
+        if (i < n && sz[j] >= min_size && (k & mask) == prefix) atomicAdd(&lh[wave][(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        unsigned t = 0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) t += lh[v][threadIdx.x];
+        if (t) atomicAdd(&work[threadIdx.x], t);
+    }
+}
+
+__global__ __launch_bounds__(256) void topk_pick(unsigned *__restrict__ work, unsigned n_keep, int shift) {
+    __shared__ unsigned ws[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool done = work[kTopkState + 2] != 0;
+    const unsigned prefix = work[kTopkState + 0], rank = work[kTopkState + 1];
+    const unsigned c = work[255 - threadIdx.x];   // thread t takes bin 255 - t: prefix sums walk down from the top
+    unsigned incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    unsigned before = 0, all = 0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        before += v < wave ? ws[v] : 0u;
+        all += ws[v];
+    }
+    const unsigned excl = before + incl - c;
+    work[threadIdx.x] = 0;   // histogram ready for the next byte
+    if (done) return;
+    if (shift == 24 && all <= n_keep) {   // the first histogram counts everything that passes min_size
+        if (threadIdx.x == 0) { work[kTopkState + 2] = 1; work[kTopkState + 3] = 0; }
+        return;
+    }
+    if (c != 0 && rank >= excl && rank < excl + c) {
+        const unsigned np = prefix | ((255u - threadIdx.x) << shift);
+        work[kTopkState + 0] = np;
+        work[kTopkState + 1] = rank - excl;
+        if (shift == 0) work[kTopkState + 3] = np;
+    }
+}
+
+// take flags of the compaction: passes min_size and reaches the cutoff key
+__device__ __forceinline__ bool topk_take(const float *__restrict__ extrema, unsigned i, unsigned n, float min_size,
+                                          unsigned cutoff) {
+    return i < n && extrema[(size_t)i * 4 + 2] >= min_size && __float_as_uint(fabsf(extrema[(size_t)i * 4 + 3])) >= cutoff;
+}
+
+__global__ __launch_bounds__(1024) void topk_sums(const float *__restrict__ extrema, const unsigned long long *__restrict__ n_in,
+                                                  unsigned long long n_host, float min_size, unsigned *__restrict__ work) {
+    __shared__ unsigned ws[16];
+    const unsigned n = (unsigned)(n_in ? n_in[0] : n_host);
+    const bool take = topk_take(extrema, blockIdx.x * 1024u + threadIdx.x, n, min_size, work[kTopkState + 3]);
+    const unsigned long long bm = __ballot(take);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = (unsigned)__popcll(bm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int v = 0; v < 16; ++v) t += ws[v];
+        work[kTopkSums + blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void topk_scatter(const float *__restrict__ extrema, const unsigned long long *__restrict__ n_in,
+                                                     unsigned long long n_host, float min_size, unsigned n_keep,
+                                                     const unsigned *__restrict__ work, float *__restrict__ out,
+                                                     unsigned *__restrict__ out_index, unsigned *__restrict__ out_count,
+                                                     unsigned long long *__restrict__ out_count64) {
+    __shared__ unsigned ws[16];
+    const unsigned n = (unsigned)(n_in ? n_in[0] : n_host);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned i = blockIdx.x * 1024u + threadIdx.x;
+    const bool take = topk_take(extrema, i, n, min_size, work[kTopkState + 3]);
+    const unsigned long long bm = __ballot(take);
+    if (lane == 0) ws[wave] = (unsigned)__popcll(bm);
+    __syncthreads();
+    unsigned before = 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) before += v < wave ? ws[v] : 0u;
+    const unsigned o = work[kTopkSums + blockIdx.x] + before + (unsigned)__popcll(bm & ((1ull << lane) - 1ull));
+    if (take && o < n_keep) {
+        *reinterpret_cast<f32x4 *>(out + (size_t)o * 4) = *reinterpret_cast<const f32x4 *>(extrema + (size_t)i * 4);
+        if (out_index) out_index[o] = i;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long kept = *reinterpret_cast<const unsigned long long *>(work + kTopkTotals);
+        out_count[0] = (unsigned)kept;
+        if (out_count64) out_count64[0] = kept;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -1608,10 +1741,27 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, const float 
 void launch_topk_filter(const float *extrema, const unsigned *seg_start, const unsigned long long *n_in,
                         unsigned long long n_host, unsigned n_frames, unsigned seg_cap, unsigned n_keep, float min_size,
                         float *out, unsigned *out_index, unsigned *out_count, unsigned long long *out_count64,
-                        hipStream_t stream) {
+                        unsigned long long n_cap, unsigned *work, hipStream_t stream) {
+    // one frame with a long list and scratch to work in: the multi-workgroup form; otherwise one workgroup per frame
+    if (n_frames == 1 && !seg_start && work && n_cap > 8192 && seg_cap >= n_cap) {
+        const unsigned nb4 = (unsigned)((n_cap + 4095) / 4096), nb1 = (unsigned)((n_cap + 1023) / 1024);
+        hipLaunchKernelGGL(topk_init, dim3(1), dim3(256), 0, stream, work, n_keep);
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hipLaunchKernelGGL(topk_hist, dim3(nb4), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, shift, work);
+            hipLaunchKernelGGL(topk_pick, dim3(1), dim3(256), 0, stream, work, n_keep, shift);
+        }
+        hipLaunchKernelGGL(topk_sums, dim3(nb1), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, work);
+        hipLaunchKernelGGL(cubes_scan_sums, dim3(1), dim3(1024), 0, stream, work + kTopkSums, (long)nb1,
+                           (unsigned long long)n_keep, reinterpret_cast<unsigned long long *>(work + kTopkTotals));
+        hipLaunchKernelGGL(topk_scatter, dim3(nb1), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, n_keep,
+                           (const unsigned *)work, out, out_index, out_count, out_count64);
+        return;
+    }
     hipLaunchKernelGGL(topk_filter, dim3(n_frames), dim3(1024), 0, stream, extrema, seg_start, n_in, n_host, n_frames,
                        seg_cap, n_keep, min_size, out, out_index, out_count, out_count64);
 }
+
+size_t topk_work_words(unsigned long long n_cap) { return kTopkSums + (size_t)((n_cap + 1023) / 1024) + 2; }
 
 // [frames][n_keep] padded per-frame selections + counts -> one contiguous list with the frame of every entry.
 // totals[0] = entries, totals[1] = extrema the per-frame cap dropped (dropped_blobs summed over the frames).

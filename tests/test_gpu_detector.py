@@ -88,15 +88,15 @@ def test_extrema_edge_cases(lfp, oracle):
             assert len(got) == 0
 
 
-def test_topk_filter_vs_oracle(lfp, torch, oracle):
+@pytest.mark.parametrize("n", [5000, 40000])      # one workgroup / the multi-workgroup form for long lists
+def test_topk_filter_vs_oracle(lfp, torch, oracle, n):
     rng = np.random.default_rng(3)
-    n = 5000
     ex = np.stack([rng.uniform(5, 600, n), rng.uniform(5, 400, n), 0.82 * np.sqrt(2) * 2 ** rng.uniform(1, 4.4, n),
                    rng.uniform(0.035, 0.5, n)], axis=1).astype(np.float32)
     ex[rng.integers(0, n, 400), 3] = np.float32(0.2)          # ties, some of them exactly at a cut
     h = lfp.MkdHandle(max_features=64)
     d_ex = torch.from_numpy(ex).cuda()
-    for top_n, min_size in ((1, 0.0), (100, 0.0), (2000, 0.0), (4999, 0.0), (5000, 0.0), (9000, 0.0), (700, 6.0),
+    for top_n, min_size in ((1, 0.0), (100, 0.0), (2000, 0.0), (n - 1, 0.0), (n, 0.0), (n + 4000, 0.0), (700, 6.0),
                             (3000, 20.0), (10, 1e9)):
         d_out = torch.zeros((top_n, 4), device="cuda")
         d_idx = torch.zeros((top_n,), dtype=torch.int32, device="cuda")
