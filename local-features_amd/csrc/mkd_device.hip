@@ -789,13 +789,8 @@ __global__ void pyr_decimate(const float *__restrict__ in, float *__restrict__ o
 }
 
 // blur_pyramid.glsl:36-49 vertical pass: binomial taps centred on texel (2x, 2y) of the H result.
-__global__ void pyr_down_v(const float *__restrict__ in, float *__restrict__ out, long in_stride, long out_stride,
-                           int w, int h, int ow, int oh) {
+__device__ __forceinline__ float down_v_pixel(const float *__restrict__ in, int w, int h, int x, int y) {
 #pragma clang fp contract(off)
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= ow || y >= oh) return;
-    in += blockIdx.z * in_stride;
-    out += blockIdx.z * out_stride;
     // taps centred on texel (2x, 2y): same arithmetic as tex_bilinear, zero-weight terms left out (see sep3_pixel)
     const int sx = mirror_idx(2 * x, w);
     const float cy = 2.f * (float)y + 0.5f;
@@ -811,7 +806,42 @@ __global__ void pyr_down_v(const float *__restrict__ in, float *__restrict__ out
     }
     float s = in[(size_t)mirror_idx(2 * y, h) * w + sx] * 0.375f;
     s += (side[0] + side[1]) * 0.3125f;
-    out[(size_t)y * ow + x] = s;
+    return s;
+}
+
+__global__ void pyr_down_v(const float *__restrict__ in, float *__restrict__ out, long in_stride, long out_stride,
+                           int w, int h, int ow, int oh) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= ow || y >= oh) return;
+    in += blockIdx.z * in_stride;
+    out += blockIdx.z * out_stride;
+    out[(size_t)y * ow + x] = down_v_pixel(in, w, h, x, y);
+}
+
+// The small end of the pyramid in one launch: from level l0 on (where the horizontal result of level l-1 fits the
+// 64 KiB LDS tile) one workgroup per frame walks the remaining levels, the horizontal pass into LDS, the decimating
+// vertical pass from it.  Same pixel functions as the per-level kernels; it only replaces a dozen tiny launches.
+constexpr int kTailPixels = 16384;
+
+__global__ __launch_bounds__(1024) void pyr_tail(float *__restrict__ pyr, long pyr_stride, PyramidDesc pd, int l0) {
+    __shared__ float s_tmp[kTailPixels];
+    float *base = pyr + blockIdx.x * pyr_stride;
+    for (int l = l0; l < pd.levels; ++l) {
+        const int pw = pd.w[l - 1], ph = pd.h[l - 1], ow = pd.w[l], oh = pd.h[l];
+        const float *in = base + pd.offset[l - 1];
+        for (int i = threadIdx.x; i < pw * ph; i += 1024) {
+            const int y = i / pw, x = i - y * pw;
+            s_tmp[i] = sep3_pixel(in, pw, ph, x, y, 0.375f, 0.3125f, 1.2f, 0);
+        }
+        __syncthreads();
+        float *out = base + pd.offset[l];
+        for (int i = threadIdx.x; i < ow * oh; i += 1024) {
+            const int y = i / ow, x = i - y * ow;
+            out[i] = down_v_pixel(s_tmp, pw, ph, x, y);
+        }
+        __threadfence_block();   // level l is the input of level l + 1, read by other threads of this workgroup
+        __syncthreads();
+    }
 }
 
 // patch_gradients.glsl:42-70.  One wave per keypoint (4 per block): the per-keypoint scale/level/rotation math is
@@ -1665,14 +1695,17 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     launch_swt(pyr + pd.offset[0], pyr_stride, l1, l1s, w, h, 1, frames, stream);
     hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)l1, pyr + pd.offset[1],
                        l1s, pyr_stride, w, h, pd.w[1], pd.h[1]);
-    // levels >= 2: binomial H at the resolution of level l-1, then V with 2x decimation
-    for (int l = 2; l < pd.levels; ++l) {
+    // levels >= 2: binomial H at the resolution of level l-1, then V with 2x decimation; the small levels in one launch
+    int l0 = pd.levels;
+    while (l0 > 2 && pd.w[l0 - 2] * pd.h[l0 - 2] <= kTailPixels) --l0;
+    for (int l = 2; l < l0; ++l) {
         const int pw = pd.w[l - 1], ph = pd.h[l - 1];
         hipLaunchKernelGGL(pyr_sep3, sgrid(pw, ph), strip, 0, stream, (const float *)(pyr + pd.offset[l - 1]), tmp_a,
                            pyr_stride, ts, pw, ph, 0.375f, 0.3125f, 1.2f, 0);
         hipLaunchKernelGGL(pyr_down_v, grid(pd.w[l], pd.h[l]), blk, 0, stream, (const float *)tmp_a, pyr + pd.offset[l],
                            ts, pyr_stride, pw, ph, pd.w[l], pd.h[l]);
     }
+    if (l0 < pd.levels) hipLaunchKernelGGL(pyr_tail, dim3(frames), dim3(1024), 0, stream, pyr, pyr_stride, pd, l0);
 }
 
 // Layers 1 .. n_layers-1 of the a-trous stack (mod.rs:1093-1130): layer l+1 = [1 4 6 4 1]/16 H then V over layer l
