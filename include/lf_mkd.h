@@ -248,6 +248,21 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
 int lf_mkd_match(lf_mkd *h, const float *a, uint64_t na, const float *b, uint64_t nb, float ratio,
                  int32_t *match);
 
+/* The same stage on the reference's own buffer formats, for a caller that keeps the reference's detect graph and host
+ * filter and swaps only the extract graph.  Host pointers; synchronous.
+ *   extremum_data  ExtremumLocations.data: blocks of block_len (256, mod.rs:279) extrema laid out
+ *                  [x * block_len][y * block_len][size * block_len][contrast * block_len] f32
+ *                  (common.glsl:45-81 `_coord_idx`, host mirror shaders.rs:257-319), n_extrema entries in all;
+ *   indices        FilteredExtrema.indices (common.glsl:83-89): the extrema the host filter kept, n_indices of them.
+ * Outputs as KeypointIndices holds them (common.glsl:93-101, shaders.rs:321-353): kp_extremum_index[i] = index of
+ * keypoint i's extremum (into extremum_data, i.e. one of the values in `indices`) and kp_orientation[i] in degrees,
+ * for *n_out <= max_out keypoints, ordered by position in `indices`, then histogram bin.  keypoints (may be NULL) additionally receives
+ * the assembled lf_mkd_keypoint records the describe entry points take. */
+int lf_mkd_orient_keypoints_blocked(lf_mkd *h, const float *extremum_data, uint64_t n_extrema, uint32_t block_len,
+                                    const uint32_t *indices, uint64_t n_indices, uint32_t *kp_extremum_index,
+                                    float *kp_orientation, lf_mkd_keypoint *keypoints, uint64_t max_out,
+                                    uint64_t *n_out, uint64_t *n_dropped);
+
 /* Verification tap: copies layer `layer` (0 .. n_scales + 2) of frame 0's a-trous stack to a host
  * buffer of width x height floats, building the stack first if needed. */
 int lf_mkd_get_coarse_layer(lf_mkd *h, uint32_t layer, float *out);

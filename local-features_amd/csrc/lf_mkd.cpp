@@ -873,6 +873,42 @@ int lf_mkd_match(lf_mkd *h, const float *a, uint64_t na, const float *b, uint64_
     return LF_MKD_OK;
 }
 
+int lf_mkd_orient_keypoints_blocked(lf_mkd *h, const float *extremum_data, uint64_t n_extrema, uint32_t block_len,
+                                    const uint32_t *indices, uint64_t n_indices, uint32_t *kp_extremum_index,
+                                    float *kp_orientation, lf_mkd_keypoint *keypoints, uint64_t max_out, uint64_t *n_out,
+                                    uint64_t *n_dropped) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!n_out) return fail(h, LF_MKD_ERR_BAD_ARG, "orient_keypoints_blocked: n_out is null");
+    *n_out = 0;
+    if (n_dropped) *n_dropped = 0;
+    if (n_indices == 0) return LF_MKD_OK;
+    if (!extremum_data || !indices || block_len == 0 || (max_out && (!kp_extremum_index || !kp_orientation)))
+        return fail(h, LF_MKD_ERR_BAD_ARG, "orient_keypoints_blocked: null pointer");
+    // gather the blocked coordinate arrays into records (BlobLocations::get, shaders.rs:307-318)
+    std::vector<lf_mkd_extremum> ex(n_indices);
+    for (uint64_t i = 0; i < n_indices; ++i) {
+        const uint64_t idx = indices[i];
+        if (idx >= n_extrema) return fail(h, LF_MKD_ERR_BAD_ARG, "orient_keypoints_blocked: index beyond n_extrema");
+        const uint64_t base = idx / block_len * 4 * block_len, off = idx % block_len;
+        ex[i] = lf_mkd_extremum{extremum_data[base + off], extremum_data[base + block_len + off],
+                                extremum_data[base + 2 * block_len + off], extremum_data[base + 3 * block_len + off]};
+    }
+    std::vector<lf_mkd_keypoint> kps(max_out);
+    if (int rc = lf_mkd_orient_keypoints(h, ex.data(), n_indices, kps.data(), max_out, n_out, n_dropped)) return rc;
+    // keypoints come ordered by extremum: walk both lists together to recover each keypoint's extremum
+    uint64_t j = 0;
+    for (uint64_t i = 0; i < *n_out; ++i) {
+        while (j < n_indices && !(ex[j].x == kps[i].x && ex[j].y == kps[i].y && ex[j].size == kps[i].size &&
+                                  ex[j].response == kps[i].response))
+            ++j;
+        if (j == n_indices) return fail(h, LF_MKD_ERR_HIP, "orient_keypoints_blocked: keypoint without an extremum");
+        kp_extremum_index[i] = indices[j];
+        kp_orientation[i] = kps[i].angle;
+        if (keypoints) keypoints[i] = kps[i];
+    }
+    return LF_MKD_OK;
+}
+
 int lf_mkd_get_coarse_layer(lf_mkd *h, uint32_t layer, float *out) {
     if (!h) return LF_MKD_ERR_BAD_ARG;
     if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "get_coarse_layer: call lf_mkd_set_image first");

@@ -26,7 +26,7 @@ SYMBOLS = (
     "lf_mkd_orient_keypoints", "lf_mkd_orient_keypoints_device", "lf_mkd_get_coarse_layer",
     "lf_mkd_detect_extrema", "lf_mkd_detect_extrema_device", "lf_mkd_filter_extrema_device", "lf_mkd_detect",
     "lf_mkd_match", "lf_mkd_match_device", "lf_mkd_stream_create", "lf_mkd_stream_frame",
-    "lf_mkd_detect_frames_device",
+    "lf_mkd_detect_frames_device", "lf_mkd_orient_keypoints_blocked",
 )
 
 
@@ -101,6 +101,7 @@ def load_library():
     L.lf_mkd_match.argtypes = [vp, vp, u64, vp, u64, ctypes.c_float, vp]
     L.lf_mkd_stream_create.argtypes = [vp, u32, u32, u32, ctypes.c_float, u64, vp, vp, vp, vp]
     L.lf_mkd_stream_frame.argtypes = [vp, vp]
+    L.lf_mkd_orient_keypoints_blocked.argtypes = [vp, vp, u64, u32, vp, u64, vp, vp, vp, u64, pu64, pu64]
     L.lf_mkd_detect_frames_device.argtypes = [vp, vp, u32, u32, u32, u32, ctypes.c_float, vp, vp, vp, u64, pu64, pu64,
                                               pu64, vp]
     L.lf_mkd_build_constants.argtypes = [vp] * 7
@@ -209,6 +210,21 @@ class MkdHandle:
         self._check(self.L.lf_mkd_match(self._h, a.ctypes.data, len(a), b.ctypes.data, len(b), ratio, out.ctypes.data),
                     "lf_mkd_match")
         return out
+
+    def orient_keypoints_blocked(self, extremum_data, n_extrema, indices, max_out, block_len=256):
+        """The reference's ExtremumLocations.data (blocked) + FilteredExtrema.indices in, KeypointIndices-style arrays out:
+        (extremum index per keypoint, orientation per keypoint, keypoints [m,5])."""
+        data = np.ascontiguousarray(extremum_data, np.float32)
+        idx = np.ascontiguousarray(indices, np.uint32)
+        kei = np.empty(max(max_out, 1), np.uint32)
+        ori = np.empty(max(max_out, 1), np.float32)
+        kps = np.empty((max(max_out, 1), 5), np.float32)
+        m, dropped = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.L.lf_mkd_orient_keypoints_blocked(self._h, data.ctypes.data, n_extrema, block_len, idx.ctypes.data,
+                                                           len(idx), kei.ctypes.data, ori.ctypes.data, kps.ctypes.data,
+                                                           max_out, ctypes.byref(m), ctypes.byref(dropped)),
+                    "lf_mkd_orient_keypoints_blocked")
+        return kei[:m.value].copy(), ori[:m.value].copy(), kps[:m.value].copy(), dropped.value
 
     def coarse_layer(self, layer, width, height):
         out = np.empty((height, width), np.float32)

@@ -159,3 +159,25 @@ def test_local_features_describe_extrema(lfp, oracle):
     assert desc.shape == (len(want), 128)
     assert_keypoint_parity(oracle, lf._inner, img, got, desc, what="class")
     assert [k.angle for k in lf.orient(img, ex)] == [k.angle for k in kps]
+
+
+def test_orientation_on_the_reference_buffer_formats(lfp, oracle):
+    """ExtremumLocations.data (blocks of 256: x | y | size | contrast, common.glsl:45-81) + FilteredExtrema.indices in,
+    KeypointIndices-style (extremum index, orientation) out: what a caller that keeps the reference's detect graph has."""
+    w, hgt, n = 320, 240, 700
+    img = smooth_image(w, hgt, 9)
+    ex = random_extrema(n, w, hgt, 10, border=4.0)
+    blocked = np.zeros(((n + 255) // 256) * 4 * 256, np.float32)
+    for i in range(n):
+        base, off = (i // 256) * 4 * 256, i % 256
+        blocked[base + off], blocked[base + 256 + off] = ex[i, 0], ex[i, 1]
+        blocked[base + 512 + off], blocked[base + 768 + off] = ex[i, 2], ex[i, 3]
+    kept = np.random.default_rng(11).permutation(n)[:300].astype(np.uint32)      # the host filter's choice, any order
+    h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt)
+    h.set_image(img)
+    kei, ori, kps, dropped = h.orient_keypoints_blocked(blocked, n, kept, 18 * 300)
+    want = oracle.orient(oracle.build_coarse_stack(img), ex[kept])
+    assert dropped == 0
+    assert_same_keypoints(kps, want, "blocked")
+    assert np.array_equal(ori, kps[:, 3])
+    assert np.array_equal(ex[kei][:, [0, 1, 2]], kps[:, :3]) and set(kei) <= set(kept)
