@@ -81,12 +81,16 @@ __device__ __forceinline__ void issue_raw_row(const float *__restrict__ src_lane
 // cos/sin of the gradient angle theta = -atan2(gy over gx), for a pair of pixels.
 template <int ANGLE>
 __device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 &ct, f32x2 &st) {
-    if (ANGLE == LF_ANGLE_EXACT) {
+    if (ANGLE == LF_ANGLE_EXACT || ANGLE == LF_ANGLE_EXACT_ZERO) {
         const f32x2 r2 = pk_fma(gx, gx, gy * gy);
         const f32x2 inv = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
         const f32x2 c = gx * inv, s = -gy * inv;
-        ct = f32x2{r2.x == 0.f ? 1.f : c.x, r2.y == 0.f ? 1.f : c.y};
-        st = f32x2{r2.x == 0.f ? 0.f : s.x, r2.y == 0.f ? 0.f : s.y};
+        // EXACT: angle 0 only for the null gradient (the CPU twin's atan2(0, 0)); EXACT_ZERO: wherever gx == 0, which is
+        // the shader's convention (atan2.glsl:33-38) -- the one place where the two angle definitions are far apart
+        const bool z0 = ANGLE == LF_ANGLE_EXACT ? r2.x == 0.f : gx.x == 0.f;
+        const bool z1 = ANGLE == LF_ANGLE_EXACT ? r2.y == 0.f : gx.y == 0.f;
+        ct = f32x2{z0 ? 1.f : c.x, z1 ? 1.f : c.y};
+        st = f32x2{z0 ? 0.f : s.x, z1 ? 0.f : s.y};
     } else {
         // atan2.glsl:19-46 called as atan2(x = gx, y = gy).  With p = poly(a), |a| <= 1, the
         // branches of the shader are quadrant symmetries of (cos p, sin p):
@@ -1644,9 +1648,11 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
     } while (0)
     if (f16) {
         if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH(LF_ANGLE_EXACT, LF_POOL_F16X3);
+        else if (angle_mode == LF_ANGLE_EXACT_ZERO) LF_LAUNCH(LF_ANGLE_EXACT_ZERO, LF_POOL_F16X3);
         else LF_LAUNCH(LF_ANGLE_SHADER, LF_POOL_F16X3);
     } else {
         if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH(LF_ANGLE_EXACT, LF_POOL_F32);
+        else if (angle_mode == LF_ANGLE_EXACT_ZERO) LF_LAUNCH(LF_ANGLE_EXACT_ZERO, LF_POOL_F32);
         else LF_LAUNCH(LF_ANGLE_SHADER, LF_POOL_F32);
     }
 #undef LF_LAUNCH_W

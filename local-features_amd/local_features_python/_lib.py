@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("LF_MKD_LIB", os.path.join(_ROOT, "liblf_mkd.so"))   #
 MODEL_DIR = os.path.join(_ROOT, "models", "mkd")
 
 FLAG_KERNEL_TIMING = 1
-ANGLE_SHADER, ANGLE_EXACT = 0, 1
+ANGLE_SHADER, ANGLE_EXACT, ANGLE_EXACT_ZERO = 0, 1, 2
 POOL_F32, POOL_F16X3 = 0, 1
 PCA_NAMES = ("liberty", "notredame", "yosemite")   # enum MKDPCA, lib.rs:26-32
 

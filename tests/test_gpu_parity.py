@@ -77,6 +77,25 @@ def test_pixels_on_the_atan2_discontinuity_follow_the_contracted_blur(lfp, oracl
     assert q.sum() >= 50 and (flip > 1e-3).sum() >= 5       # the test has teeth: the two roundings do disagree
 
 
+def test_exact_zero_angle_mode_stays_inside_the_gate_on_every_patch(lfp, oracle):
+    """LF_MKD_ANGLE_EXACT_ZERO: exact direction + the shader's angle 0 at gx == 0.  Against the SHADER reference it must
+    meet the 1e-4 gate everywhere, the patches on the atan2 discontinuity included (plain EXACT misses there by 1e-2)."""
+    from oracle import ATAN_SHADER, BLUR_CONTRACT
+    rng = np.random.default_rng(123)
+    p = rng.random((1 << 15, 32, 32)).astype(np.float32)
+    half = rng.random((64, 32, 16)).astype(np.float32)      # mirrored about column 15: gx == 0 (or +-1 ulp) down a column
+    sym = np.concatenate([half[:, :, :15], half[:, :, 15:16], half[:, :, 14::-1], half[:, :, :1]], axis=2)
+    p = np.concatenate([p, sym])
+    ref = oracle.describe_patches(p, atan_mode=ATAN_SHADER | BLUR_CONTRACT, nthreads=8)
+    quirk = oracle.quirk_pixels(p) > 0
+    assert quirk[-64:].all() and quirk[:-64].sum() >= 30
+    for pool in (lfp.POOL_F16X3, lfp.POOL_F32):
+        e = rel_l2(lfp.MkdHandle(max_features=1 << 14, angle_mode=lfp.ANGLE_EXACT_ZERO, pool_mode=pool).describe_patches(p), ref)
+        assert e.max() < GATE and e.max() < 5e-5, (pool, e.max(), int(e.argmax()))
+    plain = rel_l2(lfp.MkdHandle(max_features=1 << 14, angle_mode=lfp.ANGLE_EXACT).describe_patches(p[quirk]), ref[quirk])
+    assert (plain > 1e-3).sum() >= 20          # what the zero convention is there for
+
+
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 129])
 def test_ragged_batch_sizes(lfp, oracle, n):
     rng = np.random.default_rng(n)
