@@ -5,7 +5,7 @@ import csv, glob, json, os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-lines = [f"# rocprofv3 summary {tag}", "", "Command profiled: `python3 bench.py --steps 5 --warmup 2 --cpu-sample 0` (default workload:",
+lines = [f"# rocprofv3 summary {tag}", "", "Command profiled: `python3 bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-extras` (default workload:",
          "2^20 patches, shader angle mode, f16x3 pooling) on one MI355X via `tools/profile_round.sh`.", ""]
 bench = None
 for l in open(os.path.join(src, "stats.log")):
