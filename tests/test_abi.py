@@ -76,3 +76,12 @@ def test_cpp_header_compiles_against_the_library(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "demo_local_features.cpp"), "-L", lib_dir, "-llf_mkd",
                            "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(tmp_path / "demo")])
+
+
+def test_c_header_is_plain_c99():
+    """include/lf_mkd.h is a C ABI: it must parse as C99 (no C++-isms) as well as C++."""
+    import subprocess
+    from conftest import ROOT
+    hdr = os.path.join(ROOT, "include", "lf_mkd.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
