@@ -656,7 +656,8 @@ __device__ __forceinline__ int mirror_idx(int i, int n) {
     int t = i - (int)q * pp;
     t = t < 0 ? t + pp : t;
     t = t >= pp ? t - pp : t;
-    return t < n ? t : pp - 1 - t;
+    const int r = t < n ? t : pp - 1 - t;
+    return r < 0 ? 0 : (r > n - 1 ? n - 1 : r);   // only binding for absurd |i| (non-finite caller data): never out of range
 }
 
 __device__ __forceinline__ float tex_bilinear(const float *__restrict__ img, int w, int h, float u, float v) {
