@@ -849,15 +849,21 @@ __global__ __launch_bounds__(1024) void pyr_tail(float *__restrict__ pyr, long p
     }
 }
 
+constexpr int kSampleBox = 96;   // >= 32 * 2 * sqrt2 + 4: the bounding box of every footprint with rem < 2
+
 // patch_gradients.glsl:42-70.  One wave per keypoint (4 per block): the per-keypoint scale/level/rotation math is
-// done once per wave instruction, each lane then samples 16 pixels (two patch rows per step, so every store
-// instruction writes 256 contiguous bytes).  frame_of_kp (optional) selects the keypoint's pyramid among the
-// frames of the batch (pyr_stride floats apart).
+// done once per wave instruction, each lane then samples 16 pixels.  The kernel is bound by the number of cache lines
+// its gathers touch (counters: 67 % of wave time waiting on loads, 10 % issuing), so a load instruction covers an
+// 8 x 8 block of the patch -- a compact footprint of ~11 texel rows -- rather than two 32-pixel patch rows along a
+// rotated line (~30 lines); the patch is transposed through LDS so that it still leaves in 256-byte row stores.
+// frame_of_kp (optional) selects the keypoint's pyramid among the frames of the batch (pyr_stride floats apart).
 __global__ __launch_bounds__(256) void sample_patches(const float *__restrict__ pyr, long pyr_stride, PyramidDesc pd,
                                                       const float *__restrict__ kps /*[n][5]*/,
                                                       const unsigned *__restrict__ frame_of_kp, long n_host,
                                                       const unsigned long long *__restrict__ n_dev, float psf,
                                                       float *__restrict__ patches) {
+    __shared__ int s_mirror[4][2 * kSampleBox];
+    __shared__ float s_patch[4][1024];
     const long n = n_dev ? (long)*n_dev : n_host;
     const long k = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= n) return;
@@ -876,40 +882,72 @@ __global__ __launch_bounds__(256) void sample_patches(const float *__restrict__ 
     const float inv = 1.f / exp2f(lvl);
     const float *img = pyr + pd.offset[l];
     const int w = pd.w[l], h = pd.h[l];
-    const int lx = lane & 31;
-    const float dx = (float)lx - 16.f;
-    float *dst = patches + k * 1024 + lane;
+    float *tile = s_patch[threadIdx.x >> 6];
+    // pixel of this lane in step i: block (i & 3, i >> 2) of 8 x 8 pixels, lane = 8 * row + column inside it
+    const int lx0 = lane & 7, ly0 = lane >> 3;
     // When the rotated patch footprint (half diagonal 16 sqrt2 rem, plus the bilinear neighbour) stays inside the level,
     // MirroredRepeat is the identity and its index arithmetic is skipped: same texels, same weights.
     const float reach = 22.7f * rem + 2.f, pcx = kp[0] * inv, pcy = kp[1] * inv;
     const bool interior = pcx - reach >= 0.f && pcx + reach <= (float)(w - 1) && pcy - reach >= 0.f &&
                           pcy + reach <= (float)(h - 1);   // uniform over the wave
-    if (interior) {
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int ly = 2 * i + (lane >> 5);
-            const float dy = (float)ly - 16.f;
-            const float xx = dx * ca - dy * sa, yy = dx * sa + dy * ca;
-            const float sx = xx * rem + kp[0] * inv, sy = yy * rem + kp[1] * inv;
-            // tex_bilinear(img, w, h, sx + 0.5f, sy + 0.5f) without the mirror
-            const float fu = (sx + 0.5f) - 0.5f, fv = (sy + 0.5f) - 0.5f;
-            const float x0f = floorf(fu), y0f = floorf(fv);
-            const float ax = fu - x0f, ay = fv - y0f;
-            const float *r0 = img + (int)y0f * w + (int)x0f, *r1 = r0 + w;
-            const float top = r0[0] * (1.f - ax) + r0[1] * ax;
-            const float bot = r1[0] * (1.f - ax) + r1[1] * ax;
-            dst[i * 64] = top * (1.f - ay) + bot * ay;
+    // Otherwise MirroredRepeat is needed, but only for the <= 96 texel columns and rows of the footprint's bounding
+    // box: computed once per keypoint into a small LDS table instead of four times per sample.
+    bool boxed = false;
+    int bx0 = 0, by0 = 0, bw = 2, bh = 2;
+    int *tab = s_mirror[threadIdx.x >> 6];   // [0, 96): columns, [96, 192): row offsets y * w
+    if (!interior) {
+        float xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float cdx = (c & 1) ? 15.f : -16.f, cdy = (c & 2) ? 15.f : -16.f;
+            const float sx = (cdx * ca - cdy * sa) * rem + pcx, sy = (cdx * sa + cdy * ca) * rem + pcy;
+            xlo = fminf(xlo, sx); xhi = fmaxf(xhi, sx);
+            ylo = fminf(ylo, sy); yhi = fmaxf(yhi, sy);
         }
-        return;
+        const float bxf = floorf(xlo) - 1.f, byf = floorf(ylo) - 1.f;   // one texel of margin: +1 neighbour, rounding
+        const float bwf = floorf(xhi) + 3.f - bxf, bhf = floorf(yhi) + 3.f - byf;
+        // (comparisons are false for NaN: a non-finite keypoint takes the general path)
+        boxed = bwf >= 1.f && bwf <= (float)kSampleBox && bhf >= 1.f && bhf <= (float)kSampleBox &&
+                fabsf(bxf) < 1e9f && fabsf(byf) < 1e9f;
+        if (boxed) {
+            bx0 = (int)bxf; by0 = (int)byf; bw = (int)bwf; bh = (int)bhf;
+            for (int i = lane; i < bw; i += 64) tab[i] = mirror_idx(bx0 + i, w);
+            for (int i = lane; i < bh; i += 64) tab[kSampleBox + i] = mirror_idx(by0 + i, h) * w;
+            __builtin_amdgcn_wave_barrier();   // written and read by this wave only; LDS keeps a wave's accesses in order
+        }
     }
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
-        const int ly = 2 * i + (lane >> 5);
-        const float dy = (float)ly - 16.f;
+        const int lx = 8 * (i & 3) + lx0, ly = 8 * (i >> 2) + ly0;
+        const float dx = (float)lx - 16.f, dy = (float)ly - 16.f;
         const float xx = dx * ca - dy * sa, yy = dx * sa + dy * ca;
         const float sx = xx * rem + kp[0] * inv, sy = yy * rem + kp[1] * inv;
-        dst[i * 64] = tex_bilinear(img, w, h, sx + 0.5f, sy + 0.5f);
+        float v;
+        if (interior || boxed) {   // tex_bilinear(img, w, h, sx + 0.5f, sy + 0.5f), texel indices without / from the table
+            const float fu = (sx + 0.5f) - 0.5f, fv = (sy + 0.5f) - 0.5f;
+            const float x0f = floorf(fu), y0f = floorf(fv);
+            const float ax = fu - x0f, ay = fv - y0f;
+            int x0, x1, r0, r1;
+            if (interior) {
+                x0 = (int)x0f; x1 = x0 + 1; r0 = (int)y0f * w; r1 = r0 + w;
+            } else {
+                int ix = (int)x0f - bx0, iy = (int)y0f - by0;
+                ix = ix < 0 ? 0 : (ix > bw - 2 ? bw - 2 : ix);   // never binding (margin); keeps the table reads in range
+                iy = iy < 0 ? 0 : (iy > bh - 2 ? bh - 2 : iy);
+                x0 = tab[ix]; x1 = tab[ix + 1]; r0 = tab[kSampleBox + iy]; r1 = tab[kSampleBox + iy + 1];
+            }
+            const float top = img[r0 + x0] * (1.f - ax) + img[r0 + x1] * ax;
+            const float bot = img[r1 + x0] * (1.f - ax) + img[r1 + x1] * ax;
+            v = top * (1.f - ay) + bot * ay;
+        } else {
+            v = tex_bilinear(img, w, h, sx + 0.5f, sy + 0.5f);
+        }
+        tile[ly * 32 + lx] = v;
     }
+    __builtin_amdgcn_wave_barrier();
+    float *dst = patches + k * 1024 + lane;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dst[j * 64] = tile[j * 64 + lane];
 }
 
 // ---------------------------------------------------------------------------------------------
