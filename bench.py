@@ -267,8 +267,8 @@ def main():
             if ns < 0:
                 ns = 131072
             if ns > 0:
-                cb = cpu_baseline(8192, 1)          # calibrate: aim at ~15 s
-                ns = int(min(max(cb["value"] * 15, 8192), ns * 4))
+                cb = cpu_baseline(8192, 1)          # calibrate: aim at ~15 s of CPU work
+                ns = int(min(max(cb["value"] * 15, 8192), ns * 16))
                 line["cpu_baseline"] = cpu_baseline(ns, 0x4D4B44)
         print(json.dumps(line), flush=True)
     if dist is not None:
