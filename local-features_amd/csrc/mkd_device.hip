@@ -1030,13 +1030,14 @@ __global__ __launch_bounds__(256) void orient_peaks(const float *__restrict__ la
         }
     }
     __syncthreads();
+    int voters = 0;   // uniform over the wave
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = lane + 64 * j;
-        if (i < kOriPx) {
+        {
             int b = kOriBins + 1;
             float wgt = 0.f;
-            if (ingrad & (1u << j)) {
+            if (i < kOriPx && (ingrad & (1u << j))) {
                 const float gx = patch[i + 1] - patch[i - 1];
                 const float gy = patch[i - kOriWin] - patch[i + kOriWin];
                 if (gx != 0.f || gy != 0.f) {
@@ -1048,14 +1049,21 @@ __global__ __launch_bounds__(256) void orient_peaks(const float *__restrict__ la
                     b = rb < 0 ? rb + kOriBins : (rb >= kOriBins ? rb - kOriBins : rb);
                 }
             }
-            bin[i] = b;
-            weight[i] = wgt;
+            // texels that vote (bin < 36) are appended in texel order: chunk j holds texels 64 j .. 64 j + 63, one per
+            // lane, so a ballot gives each its rank -- the histogram walk below then skips the texels that do not vote
+            const unsigned long long vm = __ballot(b < kOriBins);
+            if (b < kOriBins) {
+                const int pos = voters + __popcll(vm & ((1ull << lane) - 1ull));
+                bin[pos] = b;
+                weight[pos] = wgt;
+            }
+            voters += __popcll(vm);
         }
     }
     __syncthreads();
     float raw = 0.f;
     if (lane < kOriBins)
-        for (int i = 0; i < kOriPx; ++i)
+        for (int i = 0; i < voters; ++i)   // still the reference's single-thread, row-major addition order per bin
             if (bin[i] == lane) raw += weight[i];
     __syncthreads();
     if (lane < kOriBins) hist[lane] = raw;   // raw histogram, circular
