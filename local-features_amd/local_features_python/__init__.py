@@ -54,18 +54,19 @@ class LocalFeatures:
     `dropped_blobs` / `dropped_features`."""
 
     def __init__(self, max_image_width, max_image_height, max_features, max_blobs=8000, n_scales=4,
-                 pca="liberty", device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_F32):
+                 pca="liberty", device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_F32, max_frames=1):
         if pca not in PCA_NAMES:
             raise RuntimeError("Invalid PCA argument")
         try:
             self._inner = MkdHandle(pca=pca, max_features=max_features, max_image_width=max_image_width,
                                     max_image_height=max_image_height, device=device,
                                     angle_mode=angle_mode, pool_mode=pool_mode, n_scales=n_scales,
-                                    max_blobs=max_blobs)
+                                    max_blobs=max_blobs, max_frames=max_frames)
         except RuntimeError as e:   # python/src/lib.rs:77-82
             raise RuntimeError("Failed to initialize local features", str(e)) from e
         self._lock = threading.Lock()   # Mutex<LocalFeaturesVulkan>, python/src/lib.rs:38
-        self.max_blobs, self.n_scales = max_blobs, n_scales
+        self.max_blobs, self.n_scales, self.max_frames = max_blobs, n_scales, max_frames
+        self.max_features = max_features
         self.dropped_blobs = self.dropped_features = 0
 
     def describe(self, img, keypoints):
@@ -134,6 +135,35 @@ class LocalFeatures:
     def detect(self, img):
         """python/src/lib.rs:86-113 (detect_extract_all): every extremum the detector finds, at most max_blobs."""
         return self._detect(img, 0, 0.0)
+
+    def detect_top_n_batch(self, imgs, n, min_size=0.0):
+        """detect_top_n over a batch of equally sized frames ([f, h, w] float32, f <= max_frames) with every stage
+        launched once for all frames (lf_mkd_detect_frames_device).  Returns one (list[Keypoint], ndarray[k,128]) per
+        frame, each equal to what detect_top_n gives for that frame alone; max_features is the budget per frame."""
+        import torch
+        arr = np.ascontiguousarray(imgs, np.float32)
+        if arr.ndim != 3:
+            raise RuntimeError("Failed to extract features", "images must be [frames, height, width]")
+        f, h, w = arr.shape
+        cap = self.max_features * f
+        with self._lock:
+            try:
+                d_img = torch.from_numpy(arr).cuda()
+                d_k = torch.empty((cap, 5), device="cuda")
+                d_f = torch.empty((cap,), dtype=torch.int32, device="cuda")
+                d_d = torch.empty((cap, 128), device="cuda")
+                m, self.dropped_blobs, self.dropped_features = self._inner.detect_frames_device(
+                    d_img.data_ptr(), f, w, h, int(n), float(min_size), d_k.data_ptr(), d_f.data_ptr(), d_d.data_ptr(),
+                    cap, torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+            except RuntimeError as e:
+                raise RuntimeError("Failed to extract features", str(e)) from e
+        kps, fid, desc = d_k[:m].cpu().numpy(), d_f[:m].cpu().numpy(), d_d[:m].cpu().numpy()
+        out = []
+        for i in range(f):
+            sel = fid == i
+            out.append(([Keypoint(*row) for row in kps[sel]], desc[sel]))
+        return out
 
     def detect_top_n(self, img, n, min_size):
         """python/src/lib.rs:115-149: the n extrema of largest contrast among those of size >= min_size."""

@@ -301,3 +301,15 @@ def test_4k_frame_at_baseline_size(lfp, torch, oracle):
     assert n == len(rk) > 6000 and int(d_c[0].item()) == total and int(d_c[2].item()) == 6000
     assert np.array_equal(d_k[:n].cpu().numpy(), rk) and np.array_equal(d_d[:n].cpu().numpy(), rd)
     assert np.allclose(np.linalg.norm(rd, axis=1), 1.0, atol=1e-5)
+
+
+def test_python_class_batch_call(lfp):
+    w, hgt = 200, 152
+    imgs = np.stack([blob_image(w, hgt, 90 + f, 60 + 40 * f) for f in range(4)])
+    lf = lfp.LocalFeatures(w, hgt, 600, max_blobs=512, max_frames=4, pool_mode=lfp.POOL_F16X3)
+    batch = lf.detect_top_n_batch(imgs, 80, 0.0)
+    assert len(batch) == 4
+    for f, (kps, desc) in enumerate(batch):
+        one_k, one_d = lf.detect_top_n(imgs[f], 80, 0.0)
+        assert [(k.x, k.y, k.size, k.angle) for k in kps] == [(k.x, k.y, k.size, k.angle) for k in one_k]
+        assert np.array_equal(desc, one_d) and len(kps) > 40
