@@ -15,6 +15,11 @@ MODELS = os.path.join(ROOT, "local-features_amd", "models", "mkd")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the product library and the oracle are build artefacts (git-ignored): make sure both exist and are current, so
+    # that a fresh checkout can run the suite without a separate build step (hipcc cross-compiles without a GPU)
+    import subprocess
+    for target in (os.path.join(ROOT, "local-features_amd"), os.path.join(ROOT, "oracle")):
+        subprocess.check_call(["make", "-s", "-C", target])
 
 
 def rel_l2(a, b):
