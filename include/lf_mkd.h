@@ -237,8 +237,10 @@ int lf_mkd_stream_frame(lf_mkd *h, void *stream);
 /* Brute-force matcher: match_features of examples/match_images/src/main.rs:8-27.  For every row of a [na][128]:
  * similarity = dot product with every row of b [nb][128]; best = the largest (the HIGHEST index among equal maxima,
  * as the reference's stable sort leaves it), second = the next one down; match[i] = index of the best if
- * best * ratio > second (the reference uses ratio = 0.8), else -1.  d_best / d_second (may be NULL) receive the
- * two similarities.  d_exclude_lo / d_exclude_hi (may both be NULL): b rows [lo[i], hi[i]) are not candidates for
+ * best * ratio > second (the reference uses ratio = 0.8), else -1; ratio <= 0 skips the test and returns the best
+ * index as is.  d_best / d_second (may be NULL) receive the two similarities, with which a caller can apply another
+ * acceptance rule -- e.g. the webcam example's inner-product-distance form, (1 - best) < 0.75 (1 - second)
+ * (examples/webcam/src/main.rs:261-265).  d_exclude_lo / d_exclude_hi (may both be NULL): b rows [lo[i], hi[i]) are not candidates for
  * a row i -- the cross-image form of BASELINE configs[3], where b is the all-gathered descriptor set and a row
  * must not match its own image.  nb must be at least 2 (the reference indexes the second-to-last candidate).
  * The similarities are computed on the matrix cores from f16 hi+lo splits of both sides (f32 accumulate,

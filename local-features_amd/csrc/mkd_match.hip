@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void match_merge(const float *__restrict__ p_b
         bi = other ? oi : bi;
         b = other ? ob : b;
     }
-    match[i] = (bi >= 0 && b * ratio > s) ? bi : -1;
+    match[i] = (bi >= 0 && (ratio <= 0.f || b * ratio > s)) ? bi : -1;   // ratio <= 0: no test, the best index as is
     if (best_out) best_out[i] = b;
     if (second_out) second_out[i] = s;
 }

@@ -964,7 +964,8 @@ static void *match_worker(void *arg)
                 s2 = s;
             }
         }
-        j->match[i] = (i1 >= 0 && s1 * j->ratio > s2) ? (int)i1 : -1; /* line 22: sim[first] * 0.8 > sim[second] */
+        /* line 22: sim[first] * 0.8 > sim[second]; ratio <= 0 (an extension of the ABI) skips the test */
+        j->match[i] = (i1 >= 0 && (j->ratio <= 0.f || s1 * j->ratio > s2)) ? (int)i1 : -1;
         if (j->best) j->best[i] = s1;
         if (j->second) j->second[i] = s2;
     }

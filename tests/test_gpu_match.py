@@ -77,6 +77,9 @@ def test_match_ties_and_errors(lfp, oracle):
     # ratio 1.0 accepts every strict best; a duplicated best is still rejected (best * 1 > second is false)
     got1 = h.match(a, b, ratio=1.0)
     assert np.array_equal(got1, oracle.match(a, b, ratio=1.0)[0]) and got1[0] == -1 and (got1[2:] >= 0).all()
+    # ratio <= 0: no test, the best index as is (with best / second a caller applies its own rule, e.g. the webcam's)
+    raw = h.match(a, b, ratio=0.0)
+    assert np.array_equal(raw, oracle.match(a, b, ratio=0.0)[0]) and (raw >= 0).all() and raw[0] == 250 and raw[1] == 299
     with pytest.raises(RuntimeError, match="two candidates"):
         h.match(a, b[:1])
     assert len(h.match(np.zeros((0, 128), np.float32), b)) == 0
