@@ -727,6 +727,44 @@ __global__ __launch_bounds__(256) void pyr_sep3(const float *__restrict__ in, fl
     }
 }
 
+// blur.glsl's two passes (horizontal, then vertical) in one launch, for tap offsets in (1, 2): the same LDS tiling as
+// pyr_swt_fused with dilation 1 -- a workgroup computes the horizontal pass of kSwtRows + 4 rows of a 256-column strip
+// (slot m = virtual row y0 - 2 + m, holding the row that index mirrors to) and the vertical pass of the kSwtRows rows
+// in the middle from them.  The vertical taps of row y blend rows floor(y - off) .. +1 and floor(y + off) .. +1, i.e.
+// rows y-2 .. y+2.  Same arithmetic as the two pyr_sep3 dispatches: bit-identical.
+__global__ __launch_bounds__(256) void pyr_sep3_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
+                                                      long out_stride, int w, int h, float w0, float w1, float off) {
+#pragma clang fp contract(off)
+    __shared__ float s_h[16][256];   // kSwtRows + 4 rows
+    in += blockIdx.z * in_stride;
+    out += blockIdx.z * out_stride;
+    const int y0 = (int)blockIdx.y * 12;
+    const int xr = (int)blockIdx.x * 256 + (int)threadIdx.x, x = xr < w ? xr : w - 1;
+#pragma unroll 4
+    for (int m = 0; m < 16; ++m) s_h[m][threadIdx.x] = sep3_pixel(in, w, h, x, mirror_idx(y0 - 2 + m, h), w0, w1, off, 0);
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 12; ++k) {
+        const int y = y0 + k;
+        if (y >= h) break;
+        const float c = (float)y + 0.5f;
+        float side[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float u = t == 0 ? c - off : c + off;
+            const float fu = u - 0.5f;
+            const float f0 = floorf(fu);
+            const float a = fu - f0;
+            int m0 = (int)f0 - (y0 - 2);
+            m0 = m0 < 0 ? 0 : (m0 > 14 ? 14 : m0);   // never binding for off in (1, 2)
+            side[t] = s_h[m0][threadIdx.x] * (1.f - a) + s_h[m0 + 1][threadIdx.x] * a;
+        }
+        float sum = s_h[k + 2][threadIdx.x] * w0;
+        sum += (side[0] + side[1]) * w1;
+        if (xr < w) out[(size_t)y * w + xr] = sum;
+    }
+}
+
 // swt.glsl:24-58, both passes in one launch: [1 4 6 4 1]/16 at texel centres, taps d = 2^in_level apart, mirrored,
 // horizontal pass then vertical pass.  The reference runs them as two dispatches through a scratch layer; here a
 // workgroup keeps the horizontal results it needs in LDS, so a layer costs one read and one write of the frame
@@ -1742,10 +1780,8 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     auto grid = [&](int gw, int gh) { return dim3((gw + 31) / 32, (gh + 7) / 8, frames); };
     auto sgrid = [&](int gw, int gh) { return dim3((gw + 255) / 256, (gh + 3) / 4, frames); };
     // level 0: sigma-0.6 blur, H then V (tasks_detect.rs:150-161, mod.rs:1043-1067)
-    hipLaunchKernelGGL(pyr_sep3, sgrid(w, h), strip, 0, stream, image, tmp_a, image_stride, ts, w, h, 0.66381836f,
-                       0.16809084f, 1.015267163f, 0);
-    hipLaunchKernelGGL(pyr_sep3, sgrid(w, h), strip, 0, stream, (const float *)tmp_a, pyr + pd.offset[0], ts, pyr_stride,
-                       w, h, 0.66381836f, 0.16809084f, 1.015267163f, 1);
+    hipLaunchKernelGGL(pyr_sep3_fused, dim3((w + 255) / 256, (h + 11) / 12, frames), dim3(256), 0, stream, image,
+                       pyr + pd.offset[0], image_stride, pyr_stride, w, h, 0.66381836f, 0.16809084f, 1.015267163f);
     if (pd.levels < 2) return;
     // level 1: one a-trous pass over level 0, nearest-decimated
     float *l1 = layer1 ? layer1 : tmp_b;
