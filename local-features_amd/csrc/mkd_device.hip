@@ -678,9 +678,6 @@ __device__ __forceinline__ float tex_bilinear(const float *__restrict__ img, int
 
 // All pyramid kernels work on a batch of frames of one size: blockIdx.z = frame, consecutive frames are
 // in_stride / out_stride floats apart.
-// Full-resolution blur passes: a workgroup of (64, 4) threads covers a 256 x 4 strip, each thread four pixels 64
-// apart, so that every thread has its 20 loads in flight at once.
-//
 // blur.glsl:34-65 (sigma 0.6) and blur_pyramid.glsl horizontal pass share this shape:
 // out = w0 * tex(c) + w1 * (tex(c - off) + tex(c + off)) along one axis.  The bilinear fetch is evaluated exactly as
 // tex_bilinear does, minus the terms that are multiplied by a weight of exactly 0: the centre tap sits on a texel
@@ -705,26 +702,6 @@ __device__ __forceinline__ float sep3_pixel(const float *__restrict__ in, int w,
     float s = in[(size_t)y * w + x] * w0;
     s += (side[0] + side[1]) * w1;
     return s;
-}
-
-__global__ __launch_bounds__(256) void pyr_sep3(const float *__restrict__ in, float *__restrict__ out, long in_stride,
-                                                long out_stride, int w, int h, float w0, float w1, float off,
-                                                int vertical) {
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (y >= h) return;
-    in += blockIdx.z * in_stride;
-    out += blockIdx.z * out_stride;
-    float r[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int x = blockIdx.x * 256 + threadIdx.x + 64 * j;
-        r[j] = sep3_pixel(in, w, h, x < w ? x : w - 1, y, w0, w1, off, vertical);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int x = blockIdx.x * 256 + threadIdx.x + 64 * j;
-        if (x < w) out[(size_t)y * w + x] = r[j];
-    }
 }
 
 // blur.glsl's two passes (horizontal, then vertical) in one launch, for tap offsets in (1, 2): the same LDS tiling as
@@ -852,13 +829,45 @@ __device__ __forceinline__ float down_v_pixel(const float *__restrict__ in, int 
     return s;
 }
 
-__global__ void pyr_down_v(const float *__restrict__ in, float *__restrict__ out, long in_stride, long out_stride,
-                           int w, int h, int ow, int oh) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= ow || y >= oh) return;
+// blur_pyramid.glsl's two passes for one level in one launch: the horizontal pass is only needed at the even columns and
+// at the 2 kDownRows + 3 rows around the output rows (taps at 2y -+ 1.2 blend rows 2y-2 .. 2y+2), kept in LDS; the
+// two-dispatch form computes it for every texel of level l-1 and writes it out.  Same pixel arithmetic: bit-identical.
+constexpr int kDownRows = 6;
+
+__global__ __launch_bounds__(256) void pyr_down_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
+                                                      long out_stride, int pw, int ph, int ow, int oh) {
+#pragma clang fp contract(off)
+    __shared__ float s_h[2 * kDownRows + 3][256];
     in += blockIdx.z * in_stride;
     out += blockIdx.z * out_stride;
-    out[(size_t)y * ow + x] = down_v_pixel(in, w, h, x, y);
+    const int y0 = (int)blockIdx.y * kDownRows;
+    const int xr = (int)blockIdx.x * 256 + (int)threadIdx.x, x = xr < ow ? xr : ow - 1;
+    const int sx = mirror_idx(2 * x, pw);
+    const int v0 = 2 * y0 - 2;   // virtual row of slot 0
+#pragma unroll 5
+    for (int m = 0; m < 2 * kDownRows + 3; ++m)
+        s_h[m][threadIdx.x] = sep3_pixel(in, pw, ph, sx, mirror_idx(v0 + m, ph), 0.375f, 0.3125f, 1.2f, 0);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kDownRows; ++k) {
+        const int y = y0 + k;
+        if (y >= oh) break;
+        const float cy = 2.f * (float)y + 0.5f;
+        float side[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float u = t == 0 ? cy - 1.2f : cy + 1.2f;
+            const float fu = u - 0.5f;
+            const float f0 = floorf(fu);
+            const float a = fu - f0;
+            int m0 = (int)f0 - v0;
+            m0 = m0 < 0 ? 0 : (m0 > 2 * kDownRows + 1 ? 2 * kDownRows + 1 : m0);   // never binding
+            side[t] = s_h[m0][threadIdx.x] * (1.f - a) + s_h[m0 + 1][threadIdx.x] * a;
+        }
+        float sum = s_h[2 * k + 2][threadIdx.x] * 0.375f;
+        sum += (side[0] + side[1]) * 0.3125f;
+        if (xr < ow) out[(size_t)y * ow + xr] = sum;
+    }
 }
 
 // The small end of the pyramid in one launch: from level l0 on (where the horizontal result of level l-1 fits the
@@ -1776,9 +1785,8 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
                           hipStream_t stream) {
     const int w = pd.w[0], h = pd.h[0];
     const long ts = (long)w * h;
-    const dim3 blk(32, 8), strip(64, 4);   // strip kernels: 256 x 4 pixels per workgroup
+    const dim3 blk(32, 8);
     auto grid = [&](int gw, int gh) { return dim3((gw + 31) / 32, (gh + 7) / 8, frames); };
-    auto sgrid = [&](int gw, int gh) { return dim3((gw + 255) / 256, (gh + 3) / 4, frames); };
     // level 0: sigma-0.6 blur, H then V (tasks_detect.rs:150-161, mod.rs:1043-1067)
     hipLaunchKernelGGL(pyr_sep3_fused, dim3((w + 255) / 256, (h + 11) / 12, frames), dim3(256), 0, stream, image,
                        pyr + pd.offset[0], image_stride, pyr_stride, w, h, 0.66381836f, 0.16809084f, 1.015267163f);
@@ -1792,13 +1800,10 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     // levels >= 2: binomial H at the resolution of level l-1, then V with 2x decimation; the small levels in one launch
     int l0 = pd.levels;
     while (l0 > 2 && pd.w[l0 - 2] * pd.h[l0 - 2] <= kTailPixels) --l0;
-    for (int l = 2; l < l0; ++l) {
-        const int pw = pd.w[l - 1], ph = pd.h[l - 1];
-        hipLaunchKernelGGL(pyr_sep3, sgrid(pw, ph), strip, 0, stream, (const float *)(pyr + pd.offset[l - 1]), tmp_a,
-                           pyr_stride, ts, pw, ph, 0.375f, 0.3125f, 1.2f, 0);
-        hipLaunchKernelGGL(pyr_down_v, grid(pd.w[l], pd.h[l]), blk, 0, stream, (const float *)tmp_a, pyr + pd.offset[l],
-                           ts, pyr_stride, pw, ph, pd.w[l], pd.h[l]);
-    }
+    for (int l = 2; l < l0; ++l)
+        hipLaunchKernelGGL(pyr_down_fused, dim3((pd.w[l] + 255) / 256, (pd.h[l] + kDownRows - 1) / kDownRows, frames),
+                           dim3(256), 0, stream, (const float *)(pyr + pd.offset[l - 1]), pyr + pd.offset[l], pyr_stride,
+                           pyr_stride, pd.w[l - 1], pd.h[l - 1], pd.w[l], pd.h[l]);
     if (l0 < pd.levels) hipLaunchKernelGGL(pyr_tail, dim3(frames), dim3(1024), 0, stream, pyr, pyr_stride, pd, l0);
 }
 
