@@ -550,6 +550,10 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
 #ifdef LF_ABLATE_FRONT  // timing-only build: no blur, no gradient direction
 #define blur_row(rl, s, al, ar, hl, hr, o, ol, or_) do { const f32x4 a_ = *reinterpret_cast<const f32x4 *>(rl + (s) * 2048); const f32x4 b_ = *reinterpret_cast<const f32x4 *>(rl + (s) * 2048 + 256); for (int x_ = 0; x_ < 4; ++x_) { o[x_] = a_[x_]; o[4 + x_] = b_[x_]; } ol = o[0]; or_ = o[7]; } while (0)
 #endif
+            // Raw row g+4 goes into the slot of row g-2, whose last reader was the blur of the previous iteration: for
+            // g >= 1 it is requested here, a whole row before the vmcnt(0) that waits for it (counters: the waves spend
+            // 29 % of their time in s_waitcnt and only 2 % of that on LDS), for g == 0 after the first blur below.
+            if (g >= 1 && g <= 29) issue_raw_row(src, g + 4, ring, s0 == 0 ? kRingSlots - 1 : s0 - 1);
             if (g == 0) {  // first blurred row of the batch: rows -2..2 sit in slots 0..4
                 blur_row(ring_lane, 0, addr_l, addr_r, has_l, has_r, cur, cur_l, cur_r);
 #pragma unroll
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
             }
             // the slot of raw row g-2 is free now (its last reader was the blur above when g == 0)
             asm volatile("" ::: "memory");
-            if (g <= 29) {
+            if (g == 0) {
                 issue_raw_row(src, g + 4, ring, s0 == 0 ? kRingSlots - 1 : s0 - 1);
             } else if (g == 31 && more) {
 #pragma unroll
