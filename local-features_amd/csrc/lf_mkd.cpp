@@ -164,9 +164,8 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     LF_CREATE_HIP(upload(&h->dc.white_a_f16, hc.white_a_f16.data(), hc.white_a_f16.size() * 2));
     LF_CREATE_HIP(upload(&h->dc.white_a_f32, hc.white_a_f32.data(), hc.white_a_f32.size() * 4));
     LF_CREATE_HIP(upload(&h->dc.white_bias, hc.white_bias.data(), hc.white_bias.size() * 4));
-    LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_patches), h->batch * kPx * 4));
-    LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_out), h->batch * kOut * 4));
-    LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_kps), h->batch * 5 * 4));
+    // (the staging buffers of the host-pointer and keypoint entry points -- 4.6 KiB per descriptor of the internal batch --
+    // are allocated on first use: a caller of the device-pointer patch API never needs them)
     LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_totals), 8 * sizeof(unsigned long long)));
     if (params->max_image_width && params->max_image_height) {
         h->max_frames = params->max_frames ? params->max_frames : 1;
@@ -179,6 +178,15 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     }
 #undef LF_CREATE_HIP
     *out = h;
+    return LF_MKD_OK;
+}
+
+// staging for one internal batch: sampled / uploaded patches, descriptors on their way to the host, uploaded keypoints
+int ensure_staging(lf_mkd *h) {
+    if (h->d_patches) return LF_MKD_OK;
+    LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_patches), h->batch * kPx * 4));
+    LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_out), h->batch * kOut * 4));
+    LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_kps), h->batch * 5 * 4));
     return LF_MKD_OK;
 }
 
@@ -440,6 +448,7 @@ int lf_mkd_raw_descriptors_device(lf_mkd *h, const float *d_patches, uint64_t n,
     if (n == 0) return LF_MKD_OK;
     if (!d_patches || !d_raw) return fail(h, LF_MKD_ERR_BAD_ARG, "raw_descriptors_device: null pointer");
     LF_HIP(h, hipSetDevice(h->params.device));
+    if (int rc = ensure_staging(h)) return rc;   // the kernel also writes the whitened descriptors: into the staging buffer
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     for (uint64_t off = 0; off < n; off += h->batch) {
         const uint64_t m = std::min<uint64_t>(h->batch, n - off);
@@ -454,6 +463,7 @@ int lf_mkd_describe_patches(lf_mkd *h, const float *patches, uint64_t n, float *
     if (n == 0) return LF_MKD_OK;
     if (!patches || !out) return fail(h, LF_MKD_ERR_BAD_ARG, "describe_patches: null pointer");
     LF_HIP(h, hipSetDevice(h->params.device));
+    if (int rc = ensure_staging(h)) return rc;
     for (uint64_t off = 0; off < n; off += h->batch) {
         const uint64_t m = std::min<uint64_t>(h->batch, n - off);
         LF_HIP(h, hipMemcpyAsync(h->d_patches, patches + off * kPx, m * kPx * 4, hipMemcpyHostToDevice, h->stream));
@@ -531,6 +541,7 @@ int lf_mkd_describe_keypoints_frames_device(lf_mkd *h, const lf_mkd_keypoint *d_
     if (!d_kps || !d_out) return fail(h, LF_MKD_ERR_BAD_ARG, "describe_keypoints_device: null pointer");
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    if (int rc = ensure_staging(h)) return rc;
     for (uint64_t off = 0; off < n; off += h->batch) {
         const uint64_t m = std::min<uint64_t>(h->batch, n - off);
         launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_kps + off),
@@ -554,6 +565,7 @@ int lf_mkd_describe_keypoints(lf_mkd *h, const lf_mkd_keypoint *kps, uint64_t n,
     if (n == 0) return LF_MKD_OK;
     if (!kps || !out) return fail(h, LF_MKD_ERR_BAD_ARG, "describe_keypoints: null pointer");
     LF_HIP(h, hipSetDevice(h->params.device));
+    if (int rc = ensure_staging(h)) return rc;
     for (uint64_t off = 0; off < n; off += h->batch) {
         const uint64_t m = std::min<uint64_t>(h->batch, n - off);
         LF_HIP(h, hipMemcpyAsync(h->d_kps, kps + off, m * sizeof(lf_mkd_keypoint), hipMemcpyHostToDevice, h->stream));
