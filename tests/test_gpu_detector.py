@@ -313,3 +313,32 @@ def test_python_class_batch_call(lfp):
         one_k, one_d = lf.detect_top_n(imgs[f], 80, 0.0)
         assert [(k.x, k.y, k.size, k.angle) for k in kps] == [(k.x, k.y, k.size, k.angle) for k in one_k]
         assert np.array_equal(desc, one_d) and len(kps) > 40
+
+
+def test_handle_lifecycle_does_not_leak(lfp, torch):
+    """Create / use every family of entry points / destroy, many times: device memory returns to where it was."""
+    import gc
+    w, hgt = 256, 192
+    img = blob_image(w, hgt, 1, 80)
+    free0 = None
+    for rep in range(14):
+        if rep == 2:   # the first rounds load code objects, size the runtime's scratch and event pools: not the handle's
+            gc.collect()
+            torch.cuda.synchronize()
+            free0 = torch.cuda.mem_get_info()[0]
+        h = lfp.MkdHandle(max_features=512, max_image_width=w, max_image_height=hgt, max_blobs=512, max_frames=2,
+                          pool_mode=lfp.POOL_F16X3 if rep % 2 else lfp.POOL_F32)
+        kps, desc, _, _ = h.detect(img, 100 if rep % 3 else 0, 0.0)
+        assert len(kps) > 20
+        h.set_image(img)
+        ex, _ = h.detect_extrema()
+        k2, _ = h.orient_keypoints(ex)
+        d2 = h.describe_keypoints(k2)
+        assert h.match(desc, d2).shape == (len(desc),)
+        assert h.describe_patches(np.random.default_rng(rep).random((70, 32, 32)).astype(np.float32)).shape == (70, 128)
+        h.close()
+        del h
+    gc.collect()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)
