@@ -70,6 +70,25 @@ __device__ __forceinline__ void issue_lut_row(const unsigned char *__restrict__ 
     for (int j = 0; j < 24 / W; ++j) lds_dma16(g + (wave + W * j) * 1024, lds_row + (wave + W * j) * 1024);
 }
 
+// Whitening fragments are staged through the two LUT row buffers (idle during the epilogue) one 16 KiB step at a
+// time, shared by the workgroup's waves: three slots, placed so that step 0 lies in row buffer 0 (it is requested during
+// patch row 31, when only that buffer is free) and the last step in row buffer 1 (so that LUT row 0 of the next batch
+// can be requested into buffer 0 while the last step is still being consumed).
+constexpr int kWStepBytes = 16384;
+__device__ __forceinline__ constexpr int wstage_slot(int step) { return step % 3 == 0 ? 0 : (step % 3 == 1 ? 32768 : 16384); }
+static_assert(wstage_slot(0) + kWStepBytes <= kRowBytes && wstage_slot(10) >= kRowBytes && 3 * kWStepBytes <= 2 * kRowBytes, "");
+
+template <int W>
+__device__ __forceinline__ void issue_w_step(const unsigned char *__restrict__ wfrag, int step, unsigned char *lds,
+                                             int wave, int lane) {
+    const unsigned char *g = wfrag + (size_t)step * kWStepBytes + lane * 16;
+    unsigned char *d = lds + wstage_slot(step);
+#pragma unroll
+    for (int j = 0; j < 16 / W; ++j) lds_dma16(g + (wave + W * j) * 1024, d + (wave + W * j) * 1024);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // one raw patch row (16 patches x 128 B) of this wave into ring slot `slot`; rows outside [0,31] replicate
 __device__ __forceinline__ void issue_raw_row(const float *__restrict__ src_lane, int row, unsigned char *ring,
                                               int slot) {
@@ -331,13 +350,21 @@ __device__ __forceinline__ void pool_family(const f32x2 (&m)[4], const f32x2 (&c
 // accumulators as B operand (out^T = W_T x raw, the mean folded into a bias), normalize_final.glsl.
 // Whitening fragments (host: mkd_consts.cpp): f16: [step 11][row tile 8][hi|lo][lane][8], step s covers
 // accumulator tiles 2s, 2s+1; f32: [tile 21][i 4][row tile 8][lane].
-template <int POOL>
-__device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lane, bool valid, long patch,
+// f16 path: on entry step 0 of the fragments is on its way into its slot (requested by the caller during patch row 31);
+// on exit LUT row 0 of the next batch is on its way into row buffer 0 if `more`.  Every wave of the workgroup must call.
+template <int POOL, int W>
+__device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lane, int wave, bool valid, long patch,
                                                    const short *__restrict__ colmap,
                                                    const unsigned char *__restrict__ wfrag,
                                                    const float *__restrict__ bias, float *__restrict__ out,
-                                                   float *__restrict__ raw_out) {
+                                                   float *__restrict__ raw_out, unsigned char *s_mem,
+                                                   const unsigned char *__restrict__ lut_rows, bool more) {
     const int q = lane >> 4;
+    if constexpr (POOL == LF_POOL_F16X3) {
+        __syncthreads();   // every wave has left patch row 31: row buffer 1 is free too
+        issue_w_step<W>(wfrag, 1, s_mem, wave, lane);
+        issue_w_step<W>(wfrag, 2, s_mem, wave, lane);
+    }
     // tile 1 mixes polar (packed columns 0-8 of the tile) and cartesian (9-15) kernels of the m stream
     bool t1_polar[4];
 #pragma unroll
@@ -383,29 +410,49 @@ __device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lan
     f32x4 o[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) o[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // W fragments stream from L2 one unit ahead of the MFMAs that use them (two register buffers); the
-    // scheduling barriers keep hipcc from hoisting all 176 loads to the top (which spills).
     if constexpr (POOL == LF_POOL_F16X3) {
-        // uniform base + (constant + lane) index: lets hipcc address with SGPR base + one VGPR offset; a
-        // per-lane base pointer instead makes it precompute (and spill) one 64-bit address per load
-        const u32x4 *w = reinterpret_cast<const u32x4 *>(wfrag);
-        u32x4 wbuf[2][8];   // unit = (step s, 4 row tiles): [row tile rr][hi|lo]
-        auto load_unit = [&](int u, u32x4 (&dst)[8]) {
-            const int s = u >> 1, r0 = (u & 1) * 4;
+        // The whitening is bound by operand delivery (each wave needs all 176 KiB of fragments per batch): from LDS, where
+        // the 8 waves share one copy, they arrive at twice the rate the vector L1 gives each wave its own.
+        constexpr int kDma = 16 / W;   // DMA instructions per lane and step
+        if (raw_out) wait_vmcnt<0>();  // stores and loads retire out of order with respect to each other
+        // Within a wave the LDS reads run one unit (4 row tiles, hi + lo = 8 KiB) ahead of the MFMAs, in two register
+        // buffers: the waves of a workgroup move in lock step here, so without that the LDS and the matrix pipe would
+        // take turns idling.
+        u32x4 wbuf[2][8];   // [buffer][row tile rr][hi|lo]
+        auto read_unit = [&](int u, u32x4 (&dst)[8]) {
+            const u32x4 *w = reinterpret_cast<const u32x4 *>(s_mem + wstage_slot(u >> 1)) + (u & 1) * 8 * 64 + lane;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                dst[2 * rr] = w[((s * 8 + r0 + rr) * 2 + 0) * 64 + lane];
-                dst[2 * rr + 1] = w[((s * 8 + r0 + rr) * 2 + 1) * 64 + lane];
-            }
+            for (int j = 0; j < 8; ++j) dst[j] = w[j * 64];
         };
-        load_unit(0, wbuf[0]);
         f16x8 yh, yl;
+        auto mma_unit = [&](int u, const u32x4 (&src)[8]) {
+            const int r0 = (u & 1) * 4;
 #pragma unroll
-        for (int u = 0; u < 22; ++u) {
-            if (u + 1 < 22) load_unit(u + 1, wbuf[(u + 1) & 1]);
+            for (int rr = 0; rr < 4; ++rr)
+                o[r0 + rr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, src[2 * rr + 1]), yh, o[r0 + rr], 0, 0, 0);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                o[r0 + rr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, src[2 * rr]), yl, o[r0 + rr], 0, 0, 0);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                o[r0 + rr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, src[2 * rr]), yh, o[r0 + rr], 0, 0, 0);
+        };
+#pragma unroll
+        for (int s = 0; s < 11; ++s) {
+            // own share of step s has landed (steps s+1, and s+2 for s = 0, may still be in flight) and own reads of
+            // step s-1 have returned; after the barrier that holds for every wave, so the slot of step s-1 can take
+            // step s+2
+            if (s == 0) wait_vmcnt<2 * kDma>();
+            else if (s < 10) wait_vmcnt<kDma>();
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (s >= 1 && s + 2 < 11) issue_w_step<W>(wfrag, s + 2, s_mem, wave, lane);
+            if (s == 10 && more) issue_lut_row<W>(lut_rows, 0, s_mem, wave, lane);
+            read_unit(2 * s, wbuf[0]);
             __builtin_amdgcn_sched_barrier(0);
-            const int s = u >> 1;
-            if ((u & 1) == 0) {
+            if (s > 0) mma_unit(2 * s - 1, wbuf[1]);
+            {
                 const f32x4 y0 = acc[2 * s];
                 const f32x4 y1 = 2 * s + 1 < kTiles ? acc[(2 * s + 1 < kTiles) ? 2 * s + 1 : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
                 const f32x2 y[4] = {{y0[0], y0[1]}, {y0[2], y0[3]}, {y1[0], y1[1]}, {y1[2], y1[3]}};
@@ -414,17 +461,13 @@ __device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lan
                 yh = __builtin_bit_cast(f16x8, yb.hi);
                 yl = __builtin_bit_cast(f16x8, yb.lo);
             }
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int r = (u & 1) * 4 + rr;
-                const f16x8 wh = __builtin_bit_cast(f16x8, wbuf[u & 1][2 * rr]);
-                const f16x8 wl = __builtin_bit_cast(f16x8, wbuf[u & 1][2 * rr + 1]);
-                o[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, yh, o[r], 0, 0, 0);
-                o[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, yl, o[r], 0, 0, 0);
-                o[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, yh, o[r], 0, 0, 0);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            read_unit(2 * s + 1, wbuf[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_unit(2 * s, wbuf[0]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        mma_unit(21, wbuf[1]);
     } else {
         const float *w = reinterpret_cast<const float *>(wfrag);
         float wbuf[2][16];  // unit = two (tile, i) steps x 8 row tiles
@@ -459,15 +502,10 @@ __device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lan
         for (int i = 0; i < 4; ++i) ss = fmaf(o[r][i], o[r][i], ss);
     }
     ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
-    const float nrm = __builtin_amdgcn_sqrtf(ss);
+    const float inv = 1.f / __builtin_amdgcn_sqrtf(ss);   // one division, 32 multiplications: 1 ulp from 32 divisions
     if (valid) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            f32x4 v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = o[r][i] / nrm;
-            *reinterpret_cast<f32x4 *>(out + patch * 128 + 16 * r + 4 * q) = v;
-        }
+        for (int r = 0; r < 8; ++r) *reinterpret_cast<f32x4 *>(out + patch * 128 + 16 * r + 4 * q) = o[r] * inv;
     }
 }
 
@@ -543,7 +581,11 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
             __syncthreads();
 #endif
             const unsigned char *brow = s_mem + par * kRowBytes + lane * 16;
-            if (g < 31 || more) issue_lut_row<W>(lut_rows, (g + 1) & 31, s_mem + (par ^ 1) * kRowBytes, wave, lane);
+            // row buffer par ^ 1 is free: next LUT row; during row 31 the f16 epilogue's first whitening step instead
+            if (POOL == LF_POOL_F16X3 ? g < 31 : (g < 31 || more))
+                issue_lut_row<W>(lut_rows, (g + 1) & 31, s_mem + (par ^ 1) * kRowBytes, wave, lane);
+            else if (POOL == LF_POOL_F16X3)
+                issue_w_step<W>(wfrag, 0, s_mem, wave, lane);
             par ^= 1;
             BFrag bm[3] = {load_b<0>(brow), load_b<1>(brow), load_b<2>(brow)};   // m-stream fragments
 
@@ -639,9 +681,11 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
         asm volatile("" : "+s"(wf), "+s"(bs));
 #ifdef LF_ABLATE_EPILOGUE  // timing-only build
         { f32x4 sum = acc[0]; for (int t = 1; t < kTiles; ++t) sum += acc[t];
-          if (base + p < n) *reinterpret_cast<f32x4 *>(out + (base + p) * 128 + 4 * q) = sum; }
+          if (base + p < n) *reinterpret_cast<f32x4 *>(out + (base + p) * 128 + 4 * q) = sum;
+          if (POOL == LF_POOL_F16X3) { __syncthreads(); if (more) issue_lut_row<W>(lut_rows, 0, s_mem, wave, lane); } }
 #else
-        finish_descriptors<POOL>(acc, lane, base + p < n, base + p, colmap, wf, bs, out, raw_out);
+        finish_descriptors<POOL, W>(acc, lane, wave, base + p < n, base + p, colmap, wf, bs, out, raw_out, s_mem, lut_rows,
+                                    more);
 #endif
     }
 }
