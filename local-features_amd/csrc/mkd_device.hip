@@ -519,6 +519,14 @@ __device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lan
 // Algorithmic HBM bytes per patch: 4096 read + 512 written; the kernel moves nothing else.
 // W = waves per workgroup: 8 (128 patches, two waves per SIMD) for throughput; 4 (64 patches) when the whole request
 // fits one round of workgroups anyway, so that it spreads over twice as many CUs with a SIMD to each wave.
+#ifdef LF_PHASE_TIMING   // timing-only build (tools/phase_timing.py): per-wave wall clock of the phases of a patch row,
+                         // left by workgroup 0 in out[wave * 128 + phase]
+#define LF_PT(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                      pt[i] += t_ - pt_prev; pt_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LF_PT(i) do { } while (0)
+#endif
+
 template <int ANGLE, int POOL, int W>
 __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ patches, long n_host,
                                                 const unsigned long long *__restrict__ n_dev,
@@ -560,6 +568,9 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
         issue_lut_row<W>(lut_rows, 0, s_mem, wave, lane);
     }
     unsigned par = 0;  // LUT row buffer holding the row about to be consumed
+#ifdef LF_PHASE_TIMING
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_prev = __builtin_readcyclecounter();
+#endif
 
     for (; batch < nbatch; batch += gridDim.x) {
         const long base = batch * (16 * W) + wave * 16;
@@ -576,10 +587,12 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
 #pragma unroll 1
         for (int g = 0; g < 32; ++g) {
             // LUT row g and ring row g+3 have landed (own DMA: vmcnt; everyone's: barrier); row g-1 is done
+            LF_PT(7);
 #ifndef LF_ABLATE_SYNC
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
 #endif
+            LF_PT(0);
             const unsigned char *brow = s_mem + par * kRowBytes + lane * 16;
             // row buffer par ^ 1 is free: next LUT row; during row 31 the f16 epilogue's first whitening step instead
             if (POOL == LF_POOL_F16X3 ? g < 31 : (g < 31 || more))
@@ -619,6 +632,7 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
                 for (int r = -2; r <= 3; ++r) issue_raw_row(src_next, r, ring, r + 2);  // next batch's first rows
             }
             s0 = s0 == kRingSlots - 1 ? 0 : s0 + 1;
+            LF_PT(1);
 
             f32x2 m[4], c1[4], s1[4];
 #pragma unroll
@@ -644,6 +658,7 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
             }
             cur_l = nxt_l;
             cur_r = nxt_r;
+            LF_PT(2);
 
             // m stream x (polar | cartesian) kernels: accumulator tiles 0-2
             BFrag babs[1] = {load_b<3>(brow)};
@@ -657,9 +672,11 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
 #pragma unroll
                 for (int t = 0; t < 3; ++t) mma_part<POOL, 2>(am, bm[t], acc[t]);
             }
+            LF_PT(3);
             // absolute angle x cartesian kernels: unique tiles 3-5, accumulators 15-17 (cos), 18-20 (sin)
             BFrag brel[2] = {load_b<6>(brow), load_b<7>(brow)};
             pool_family<POOL, 1, 3, 15, 18>(m, c1, s1, brow, babs, acc);
+            LF_PT(4);
             // angle + gradient_angle(px) (embedding.glsl:70-72) x polar kernels: unique tiles 6-11
             f32x2 d1[4], e1[4];
             {
@@ -673,6 +690,7 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
                 }
             }
             pool_family<POOL, 2, 6, 3, 9>(m, d1, e1, brow, brel, acc);
+            LF_PT(5);
         }
         // launder the (uniform) table pointers once per batch: otherwise hipcc hoists one 64-bit VGPR address per
         // whitening-fragment load out of the batch loop and spills 1.4 KB of them per lane
@@ -687,7 +705,13 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
         finish_descriptors<POOL, W>(acc, lane, wave, base + p < n, base + p, colmap, wf, bs, out, raw_out, s_mem, lut_rows,
                                     more);
 #endif
+        LF_PT(6);
     }
+#ifdef LF_PHASE_TIMING
+    __syncthreads();
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) out[wave * 128 + i] = (float)pt[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
