@@ -193,13 +193,17 @@ template <> struct AFrag<LF_POOL_F32> {
 template <> struct AFrag<LF_POOL_F16X3> {
     u32x4 hi, lo;
     __device__ __forceinline__ void set(const f32x2 (&a)[4]) {
+        // residual a - hi as ONE v_fma_mix_f32 (f32 x f32 - f16); the factor 1 is hidden from hipcc, which otherwise
+        // folds the fma into an unpack plus a subtract
+        float one = 1.f;
+        asm("" : "+v"(one));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const unsigned h = pack_rtz(a[e].x, a[e].y);
             const float h0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xffffu));
             const float h1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h >> 16));
             hi[e] = h;
-            lo[e] = pack_rtz(a[e].x - h0, a[e].y - h1);
+            lo[e] = pack_rtz(__builtin_fmaf(a[e].x, one, -h0), __builtin_fmaf(a[e].y, one, -h1));
         }
     }
     // stream value = m * t: hi from the packed product, lo = fma(m, t, -hi) so that each residual is ONE
@@ -317,14 +321,16 @@ __device__ __forceinline__ void blur_row(const unsigned char *ring_lane, int s0,
 template <int POOL, int NT, int U0, int C0, int S0>
 __device__ __forceinline__ void pool_family(const f32x2 (&m)[4], const f32x2 (&c1)[4], const f32x2 (&s1)[4],
                                             const unsigned char *brow, BFrag (&b)[NT], f32x4 (&acc)[kTiles]) {
-    f32x2 ck[4], sk[4];
+    // the recurrence runs on the products themselves: (pk, qk) = m (cos, sin)(k theta); one rotation by (c1, s1) per
+    // harmonic instead of a rotation of the unit vector plus two products
+    f32x2 pk[4], qk[4];
     AFrag<POOL> ac, as;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { ck[e] = c1[e]; sk[e] = s1[e]; }
+    for (int e = 0; e < 4; ++e) { pk[e] = m[e] * c1[e]; qk[e] = m[e] * s1[e]; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        ac.set_product(m, ck);
-        as.set_product(m, sk);
+        ac.set(pk);
+        as.set(qk);
         BFrag bcur[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) bcur[t] = b[t];
@@ -335,10 +341,10 @@ __device__ __forceinline__ void pool_family(const f32x2 (&m)[4], const f32x2 (&c
                 else b[t] = load_b<U0 + 2 * NT>(brow + t * 2048);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {  // angle addition: (ck, sk) <- (ck, sk) * (c1, s1)
-                const f32x2 c = pk_fma(ck[e], c1[e], -(sk[e] * s1[e]));
-                sk[e] = pk_fma(sk[e], c1[e], ck[e] * s1[e]);
-                ck[e] = c;
+            for (int e = 0; e < 4; ++e) {  // angle addition: (pk, qk) <- (pk, qk) * (c1, s1)
+                const f32x2 c = pk_fma(pk[e], c1[e], -(qk[e] * s1[e]));
+                qk[e] = pk_fma(qk[e], c1[e], pk[e] * s1[e]);
+                pk[e] = c;
             }
         }
         mma_pair<POOL, NT>(ac, as, bcur, &acc[C0 + NT * k], &acc[S0 + NT * k]);
