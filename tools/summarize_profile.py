@@ -65,6 +65,16 @@ if bench:
     lines += ["## bench.py line of the `--stats` run", "", "```json", json.dumps(bench), "```", ""]
     if kern_ms:
         lines.append(f"Kernel time agreement: rocprofv3 average {kern_ms:.4f} ms vs bench.py HIP events {bench['roofline']['kernel_ms']:.4f} ms.")
+        # the --stats average includes the warm-up launches (the first one runs cold); the trace has every dispatch
+        import csv, glob
+        traces = sorted(glob.glob(os.path.join(os.path.dirname(stats[-1]), "*kernel_trace.csv")), key=os.path.getmtime) if stats else []
+        if traces:
+            durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(traces[-1]))
+                    if variant.split("(")[0] in r["Kernel_Name"]]
+            k = bench["steps"]
+            if len(durs) >= k:
+                lines.append(f"Over the {k} timed launches alone (kernel trace, warm-up launches left out): rocprofv3 average "
+                             f"{sum(durs[-k:]) / k:.4f} ms.")
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 for f in stats:
