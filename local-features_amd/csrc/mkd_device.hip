@@ -321,12 +321,13 @@ __device__ __forceinline__ void blur_row(const unsigned char *ring_lane, int s0,
 template <int POOL, int NT, int U0, int C0, int S0>
 __device__ __forceinline__ void pool_family(const f32x2 (&m)[4], const f32x2 (&c1)[4], const f32x2 (&s1)[4],
                                             const unsigned char *brow, BFrag (&b)[NT], f32x4 (&acc)[kTiles]) {
-    // the recurrence runs on the products themselves: (pk, qk) = m (cos, sin)(k theta); one rotation by (c1, s1) per
-    // harmonic instead of a rotation of the unit vector plus two products
-    f32x2 pk[4], qk[4];
+    // The recurrence runs on the products themselves, (pk, qk) = m (cos, sin)(k theta), as a three-term (Chebyshev)
+    // recurrence x_{k+1} = 2 c1 x_k - x_{k-1} with x_0 = (m, 0): one instruction per stream and harmonic instead of a
+    // rotation of the unit vector (two) plus a product.
+    f32x2 pk[4], qk[4], pp[4], qp[4], tc[4];
     AFrag<POOL> ac, as;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { pk[e] = m[e] * c1[e]; qk[e] = m[e] * s1[e]; }
+    for (int e = 0; e < 4; ++e) { pk[e] = m[e] * c1[e]; qk[e] = m[e] * s1[e]; tc[e] = c1[e] + c1[e]; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         ac.set(pk);
@@ -341,10 +342,11 @@ __device__ __forceinline__ void pool_family(const f32x2 (&m)[4], const f32x2 (&c
                 else b[t] = load_b<U0 + 2 * NT>(brow + t * 2048);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {  // angle addition: (pk, qk) <- (pk, qk) * (c1, s1)
-                const f32x2 c = pk_fma(pk[e], c1[e], -(qk[e] * s1[e]));
-                qk[e] = pk_fma(qk[e], c1[e], pk[e] * s1[e]);
-                pk[e] = c;
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 pn = pk_fma(tc[e], pk[e], k == 0 ? -m[e] : -pp[e]);
+                const f32x2 qn = k == 0 ? tc[e] * qk[e] : pk_fma(tc[e], qk[e], -qp[e]);
+                pp[e] = pk[e]; qp[e] = qk[e];
+                pk[e] = pn; qk[e] = qn;
             }
         }
         mma_pair<POOL, NT>(ac, as, bcur, &acc[C0 + NT * k], &acc[S0 + NT * k]);
