@@ -391,21 +391,19 @@ __device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lan
     sp += __shfl_xor(sp, 16); sp += __shfl_xor(sp, 32);
     sc += __shfl_xor(sc, 16); sc += __shfl_xor(sc, 32);
     const float inv_p = 1.f / __builtin_amdgcn_sqrtf(sp), inv_c = 1.f / __builtin_amdgcn_sqrtf(sc);
-    float sa = 0.f;
+    // normalize.glsl then L2-normalises the concatenation of the two unit blocks.  Its squared norm follows from the
+    // block sums (sp inv_p^2 + sc inv_c^2, within 2 ulp of the shader's second pass over the 238 values), so the two
+    // scalings fold into one pass
+    const float sa = fmaf(sp * inv_p, inv_p, (sc * inv_c) * inv_c);
+    const float inv_a = 1.f / __builtin_amdgcn_sqrtf(sa);
+    const float k_p = inv_p * inv_a, k_c = inv_c * inv_a;
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool polar = t == 0 || (t >= 3 && t <= 14) || (t == 1 && t1_polar[i]);
-            acc[t][i] *= polar ? inv_p : inv_c;
-            sa = fmaf(acc[t][i], acc[t][i], sa);
+            acc[t][i] *= polar ? k_p : k_c;
         }
-    sa += __shfl_xor(sa, 16); sa += __shfl_xor(sa, 32);
-    const float inv_a = 1.f / __builtin_amdgcn_sqrtf(sa);
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t][i] *= inv_a;
     if (raw_out) {  // verification tap: the 238-D descriptor before whitening
 #pragma unroll
         for (int t = 0; t < kTiles; ++t)
