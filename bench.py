@@ -162,12 +162,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the describe path has no CPU fallback")
+    # LF_BENCH_REHEARSAL=1 (development only): ranks share the visible GPUs and meet over gloo, so that the N > 1 code
+    # path can be run on a one-GPU box; the figures of such a run mean nothing
+    rehearsal = os.environ.get("LF_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n = args.patches
     gen = torch.Generator(device="cuda").manual_seed(0x4D4B44 + rank)
@@ -200,7 +208,7 @@ def main():
     dt = time.perf_counter() - t0
     pool_ms, whiten_ms, launches = h.kernel_times()
     from local_features_python import sharding
-    dt = sharding.max_over_ranks(dt, "cuda")
+    dt = sharding.max_over_ranks(dt, "cpu" if rehearsal else "cuda")
 
     # secondary figure: the same workload with the exact gradient direction (plus the shader's angle 0 at gx == 0)
     # instead of the shader's polynomial atan2: LF_MKD_ANGLE_EXACT_ZERO, within 1e-4 of the shader reference on every
