@@ -546,7 +546,9 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
     // number of patches: given by the host, or (graph-captured pipelines) left on the device by the previous stage
     const long n = n_dev ? (long)*n_dev : n_host;
     float *s_phi = reinterpret_cast<float *>(s_mem + kPhiOff);
-    for (int i = threadIdx.x; i < 2048; i += 64 * W) s_phi[i] = phi_cs[i];
+    // (cos, sin) per pixel in the table; in LDS per pixel pair as (cos, cos, sin, sin), so that a 16-byte read lands as
+    // two aligned register pairs (interleaved, every pair cost three v_mov to take apart)
+    for (int i = threadIdx.x; i < 2048; i += 64 * W) s_phi[(i >> 2) * 4 + (i & 1) * 2 + ((i >> 1) & 1)] = phi_cs[i];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -689,8 +691,8 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
                 const f32x4 *pp = reinterpret_cast<const f32x4 *>(&s_phi[(g * 32 + 8 * q) * 2]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const f32x4 t4 = pp[e];   // cos, sin of phi for pixels 2e, 2e+1
-                    const f32x2 cp = {t4[0], t4[2]}, sp = {t4[1], t4[3]};
+                    const f32x4 t4 = pp[e];   // cos of phi for pixels 2e, 2e+1, then their sines
+                    const f32x2 cp = {t4[0], t4[1]}, sp = {t4[2], t4[3]};
                     d1[e] = pk_fma(c1[e], cp, -(s1[e] * sp));
                     e1[e] = pk_fma(s1[e], cp, c1[e] * sp);
                 }
