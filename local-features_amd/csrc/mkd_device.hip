@@ -97,6 +97,12 @@ __device__ __forceinline__ void issue_raw_row(const float *__restrict__ src_lane
     lds_dma16(src_lane + y * 32 + 16, ring + slot * 2048 + 1024);
 }
 
+// No implicit contraction in the describe kernel (down to the end of mkd_pool): every fused multiply-add in it is written
+// as one.  The 4-wave and 8-wave forms are separate instantiations, and left to itself hipcc may contract an
+// expression in one and not in the other -- a descriptor must not depend on the size of the request it was part of
+// (tests/test_gpu_parity.py::test_full_size_properties compares the two forms bit for bit).
+#pragma clang fp contract(off)
+
 // cos/sin of the gradient angle theta = -atan2(gy over gx), for a pair of pixels.
 template <int ANGLE>
 __device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 &ct, f32x2 &st) {
@@ -382,11 +388,16 @@ __device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lan
     for (int t = 0; t < kTiles; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float v2 = acc[t][i] * acc[t][i];
             const bool polar = t == 0 || (t >= 3 && t <= 14) || (t == 1 && t1_polar[i]);
-            if (t == 1) { sp += polar ? v2 : 0.f; sc += polar ? 0.f : v2; }
-            else if (polar) sp += v2;
-            else sc += v2;
+            if (t == 1) {
+                const float v2 = acc[t][i] * acc[t][i];
+                sp += polar ? v2 : 0.f;
+                sc += polar ? 0.f : v2;
+            } else if (polar) {
+                sp = fmaf(acc[t][i], acc[t][i], sp);
+            } else {
+                sc = fmaf(acc[t][i], acc[t][i], sc);
+            }
         }
     sp += __shfl_xor(sp, 16); sp += __shfl_xor(sp, 32);
     sc += __shfl_xor(sc, 16); sc += __shfl_xor(sc, 32);
@@ -650,7 +661,7 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
                 const f32x2 right = {cur[x + 1], x == 6 ? cur_r : cur[x + 2]};
                 const f32x2 gx = left - right;                                   // left - right
                 const f32x2 gy = f32x2{nxt[x], nxt[x + 1]} - f32x2{prv[x], prv[x + 1]};   // down - up
-                const f32x2 r2 = gx * gx + gy * gy + pk_set(1e-8f);
+                const f32x2 r2 = pk_fma(gy, gy, gx * gx) + pk_set(1e-8f);
                 m[e] = f32x2{__builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(r2.x)),
                              __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(r2.y))};
 #ifdef LF_ABLATE_FRONT
@@ -721,6 +732,8 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
         for (int i = 0; i < 8; ++i) out[wave * 128 + i] = (float)pt[i];
 #endif
 }
+
+#pragma clang fp contract(fast)   // hipcc's default, for what follows (the detector kernels set their own)
 
 // ---------------------------------------------------------------------------------------------
 // Keypoint mode: pyramid and sampling.  Sampler = linear filter, MirroredRepeat (mod.rs:940-943),
