@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mkd_device.h"
 
 namespace lfmkd {
@@ -105,9 +107,9 @@ __device__ __forceinline__ void issue_raw_row(const float *__restrict__ src_lane
 
 // cos/sin of the gradient angle theta = -atan2(gy over gx), for a pair of pixels.
 template <int ANGLE>
-__device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 &ct, f32x2 &st) {
+__device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 r2, f32x2 &ct, f32x2 &st) {
     if (ANGLE == LF_ANGLE_EXACT || ANGLE == LF_ANGLE_EXACT_ZERO) {
-        const f32x2 r2 = pk_fma(gx, gx, gy * gy);
+        // r2 = gx^2 + gy^2 comes from the caller (it is the magnitude's radicand before its epsilon)
         const f32x2 inv = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
         const f32x2 c = gx * inv, s = -gy * inv;
         // EXACT: angle 0 only for the null gradient (the CPU twin's atan2(0, 0)); EXACT_ZERO: wherever gx == 0, which is
@@ -603,8 +605,13 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
         float cur[8], prv[8], cur_l = 0.f, cur_r = 0.f;  // blurred rows g and g-1 (row -1 replicates row 0)
         int s0 = 1;                                      // ring slot of raw row g-1 (rows g-1..g+3 feed hb(g+1))
 
-#pragma unroll 1
-        for (int g = 0; g < 32; ++g) {
+        // The first and the last row of a batch differ from the 30 between them (two blurs and a later ring request /
+        // no blur and the next batch's first rows): they are separate copies of the row body, so that the loop over the
+        // middle rows carries none of their branches -- hipcc speculated the last row's "row 32 = row 31" copy into
+        // every row (ten v_mov).
+        auto patch_row = [&](auto kind, const int g) __attribute__((always_inline)) {
+            constexpr bool kFirst = decltype(kind)::value == 0, kLast = decltype(kind)::value == 2;
+
             // LUT row g and ring row g+3 have landed (own DMA: vmcnt; everyone's: barrier); row g-1 is done
             LF_PT(7);
 #ifndef LF_ABLATE_SYNC
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
             LF_PT(0);
             const unsigned char *brow = s_mem + par * kRowBytes + lane * 16;
             // row buffer par ^ 1 is free: next LUT row; during row 31 the f16 epilogue's first whitening step instead
-            if (POOL == LF_POOL_F16X3 ? g < 31 : (g < 31 || more))
+            if (POOL == LF_POOL_F16X3 ? !kLast : (!kLast || more))
                 issue_lut_row<W>(lut_rows, (g + 1) & 31, s_mem + (par ^ 1) * kRowBytes, wave, lane);
             else if (POOL == LF_POOL_F16X3)
                 issue_w_step<W>(wfrag, 0, s_mem, wave, lane);
@@ -627,14 +634,14 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
             // Raw row g+4 goes into the slot of row g-2, whose last reader was the blur of the previous iteration: for
             // g >= 1 it is requested here, a whole row before the vmcnt(0) that waits for it (counters: the waves spend
             // 29 % of their time in s_waitcnt and only 2 % of that on LDS), for g == 0 after the first blur below.
-            if (g >= 1 && g <= 29) issue_raw_row(src, g + 4, ring, s0 == 0 ? kRingSlots - 1 : s0 - 1);
-            if (g == 0) {  // first blurred row of the batch: rows -2..2 sit in slots 0..4
+            if (!kFirst && !kLast && g <= 29) issue_raw_row(src, g + 4, ring, s0 == 0 ? kRingSlots - 1 : s0 - 1);
+            if (kFirst) {  // first blurred row of the batch: rows -2..2 sit in slots 0..4
                 blur_row(ring_lane, 0, addr_l, addr_r, has_l, has_r, cur, cur_l, cur_r);
 #pragma unroll
                 for (int x = 0; x < 8; ++x) prv[x] = cur[x];
             }
             float nxt[8], nxt_l, nxt_r;
-            if (g < 31) {  // hb(g+1) from raw rows g-1..g+3 = slots s0..s0+4
+            if (!kLast) {  // hb(g+1) from raw rows g-1..g+3 = slots s0..s0+4
                 blur_row(ring_lane, s0, addr_l, addr_r, has_l, has_r, nxt, nxt_l, nxt_r);
             } else {  // row 32 replicates row 31
 #pragma unroll
@@ -644,9 +651,9 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
             }
             // the slot of raw row g-2 is free now (its last reader was the blur above when g == 0)
             asm volatile("" ::: "memory");
-            if (g == 0) {
+            if (kFirst) {
                 issue_raw_row(src, g + 4, ring, s0 == 0 ? kRingSlots - 1 : s0 - 1);
-            } else if (g == 31 && more) {
+            } else if (kLast && more) {
 #pragma unroll
                 for (int r = -2; r <= 3; ++r) issue_raw_row(src_next, r, ring, r + 2);  // next batch's first rows
             }
@@ -661,13 +668,14 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
                 const f32x2 right = {cur[x + 1], x == 6 ? cur_r : cur[x + 2]};
                 const f32x2 gx = left - right;                                   // left - right
                 const f32x2 gy = f32x2{nxt[x], nxt[x + 1]} - f32x2{prv[x], prv[x + 1]};   // down - up
-                const f32x2 r2 = pk_fma(gy, gy, gx * gx) + pk_set(1e-8f);
+                const f32x2 r2n = pk_fma(gy, gy, gx * gx);
+                const f32x2 r2 = r2n + pk_set(1e-8f);
                 m[e] = f32x2{__builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(r2.x)),
                              __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(r2.y))};
 #ifdef LF_ABLATE_FRONT
                 c1[e] = gx; s1[e] = gy;
 #else
-                gradient_direction<ANGLE>(gx, gy, c1[e], s1[e]);
+                gradient_direction<ANGLE>(gx, gy, r2n, c1[e], s1[e]);
 #endif
             }
 #pragma unroll
@@ -710,7 +718,11 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
             }
             pool_family<POOL, 2, 6, 3, 9>(m, d1, e1, brow, brel, acc);
             LF_PT(5);
-        }
+        };
+        patch_row(std::integral_constant<int, 0>(), 0);
+#pragma unroll 1
+        for (int g = 1; g < 31; ++g) patch_row(std::integral_constant<int, 1>(), g);
+        patch_row(std::integral_constant<int, 2>(), 31);
         // launder the (uniform) table pointers once per batch: otherwise hipcc hoists one 64-bit VGPR address per
         // whitening-fragment load out of the batch loop and spills 1.4 KB of them per lane
         const unsigned char *wf = wfrag;
