@@ -119,14 +119,16 @@ __device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 r2,
         ct = f32x2{z0 ? 1.f : c.x, z1 ? 1.f : c.y};
         st = f32x2{z0 ? 0.f : s.x, z1 ? 0.f : s.y};
     } else {
-        // atan2.glsl:19-46 called as atan2(x = gx, y = gy).  With p = poly(a), |a| <= 1, the
-        // branches of the shader are quadrant symmetries of (cos p, sin p):
-        //   swap:  res = sign(a) pi/2 - p  -> (cos, sin) = sign(a) (sin p, cos p); a == 0 -> res = 0
-        //   x < 0: res += +-pi              -> both negated
-        const bool sw0 = fabsf(gx.x) < fabsf(gy.x), sw1 = fabsf(gx.y) < fabsf(gy.y);
-        const f32x2 num = {sw0 ? gx.x : gy.x, sw1 ? gx.y : gy.y};
-        const f32x2 den = {sw0 ? gy.x : gx.x, sw1 ? gy.y : gx.y};
-        const f32x2 a = num * f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        // atan2.glsl:19-46 called as atan2(x = gx, y = gy): a = (smaller / larger component), p = poly(a), then
+        //   swap (|x| < |y|):  res = sign(a) pi/2 - p;   x < 0: res += +-pi.
+        // poly is odd, so with a' = |a| and p' = poly(a') = |p| these branches are the octant symmetries
+        //   (|cos res|, |sin res|) = swap ? (sin p', cos p') : (cos p', sin p'),  sign(cos res) = sign(x),  sign(sin res) = sign(y)
+        // (case by case from the three lines above), and the first octant needs no signs and no select of num / den:
+        const float ax0 = fabsf(gx.x), ay0 = fabsf(gy.x), ax1 = fabsf(gx.y), ay1 = fabsf(gy.y);
+        const bool sw0 = ax0 < ay0, sw1 = ax1 < ay1;
+        const f32x2 mn = {__builtin_fminf(ax0, ay0), __builtin_fminf(ax1, ay1)};
+        const f32x2 mx = {__builtin_fmaxf(ax0, ay0), __builtin_fmaxf(ax1, ay1)};
+        const f32x2 a = mn * f32x2{__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
         const f32x2 s = a * a;
         f32x2 p = pk_fma(s, pk_set(-0.0117212f), pk_set(0.05265332f));
         p = pk_fma(s, p, pk_set(-0.11643287f));
@@ -134,8 +136,8 @@ __device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 r2,
         p = pk_fma(s, p, pk_set(-0.33262347f));
         p = pk_fma(s, p, pk_set(0.99997726f));
         p = a * p;
-        // |p| <= 0.7854: minimax fits in p^2 (Remez on [0, (pi/4)^2], float64, rounded to f32) -- 2.4e-9 / 2.8e-8 before
-        // rounding, one term shorter than the Taylor series of the same accuracy
+        // 0 <= p <= 0.7854: minimax fits in p^2 (Remez on [0, (pi/4)^2], float64, rounded to f32) -- 2.4e-9 / 2.8e-8
+        // before rounding, one term shorter than the Taylor series of the same accuracy
         const f32x2 p2 = p * p;
         f32x2 sn = pk_fma(p2, pk_set(-0.000195038549f), pk_set(0.0083320355f));
         sn = pk_fma(p2, sn, pk_set(-0.166666508f));
@@ -144,19 +146,12 @@ __device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 r2,
         f32x2 cs = pk_fma(p2, pk_set(-0.00135857589f), pk_set(0.0416550152f));
         cs = pk_fma(p2, cs, pk_set(-0.499998569f));
         cs = pk_fma(p2, cs, pk_set(1.f));
-        // sign(a) (sin p, cos p) for the swapped octants: flip the sign bits where a < 0.  (a == 0 needs no care: it
-        // only matters together with swap, i.e. gx == 0, which the last line overrides.)
-        const unsigned na0 = __float_as_uint(a.x) & 0x80000000u, na1 = __float_as_uint(a.y) & 0x80000000u;
-        float cr0 = sw0 ? __uint_as_float(__float_as_uint(sn.x) ^ na0) : cs.x;
-        float sr0 = sw0 ? __uint_as_float(__float_as_uint(cs.x) ^ na0) : sn.x;
-        float cr1 = sw1 ? __uint_as_float(__float_as_uint(sn.y) ^ na1) : cs.y;
-        float sr1 = sw1 ? __uint_as_float(__float_as_uint(cs.y) ^ na1) : sn.y;
-        // x < 0: res +- pi negates both; theta = -res negates the sine once more
-        const unsigned nx0 = __float_as_uint(gx.x) & 0x80000000u, nx1 = __float_as_uint(gx.y) & 0x80000000u;
-        cr0 = __uint_as_float(__float_as_uint(cr0) ^ nx0);
-        cr1 = __uint_as_float(__float_as_uint(cr1) ^ nx1);
-        sr0 = __uint_as_float(__float_as_uint(sr0) ^ nx0 ^ 0x80000000u);
-        sr1 = __uint_as_float(__float_as_uint(sr1) ^ nx1 ^ 0x80000000u);
+        // cos theta = cos res: sign of gx; sin theta = -sin res: opposite sign of gy (sn, cs >= 0: OR the sign bit in)
+        const unsigned sgn = 0x80000000u;
+        float cr0 = __uint_as_float(__float_as_uint(sw0 ? sn.x : cs.x) | (__float_as_uint(gx.x) & sgn));
+        float cr1 = __uint_as_float(__float_as_uint(sw1 ? sn.y : cs.y) | (__float_as_uint(gx.y) & sgn));
+        float sr0 = __uint_as_float(__float_as_uint(sw0 ? cs.x : sn.x) | (~__float_as_uint(gy.x) & sgn));
+        float sr1 = __uint_as_float(__float_as_uint(sw1 ? cs.y : sn.y) | (~__float_as_uint(gy.y) & sgn));
         // gx == 0: the shader returns 0 both for atan2(0, 0) and (its quirk) for atan2(0, y != 0)
         if (gx.x == 0.f) { cr0 = 1.f; sr0 = 0.f; }
         if (gx.y == 0.f) { cr1 = 1.f; sr1 = 0.f; }
