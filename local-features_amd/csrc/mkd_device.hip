@@ -188,16 +188,17 @@ template <> struct AFrag<LF_POOL_F32> {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] = a[e].x; v[2 * e + 1] = a[e].y; }
     }
-    __device__ __forceinline__ void set_product(const f32x2 (&m)[4], const f32x2 (&t)[4]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const f32x2 p = m[e] * t[e]; v[2 * e] = p.x; v[2 * e + 1] = p.y; }
-    }
 };
 template <> struct AFrag<LF_POOL_F16X3> {
     u32x4 hi, lo;
     __device__ __forceinline__ void set(const f32x2 (&a)[4]) {
         // residual a - hi as ONE v_fma_mix_f32 (f32 x f32 - f16); the factor 1 is hidden from hipcc, which otherwise
         // folds the fma into an unpack plus a subtract
+#ifdef LF_ABLATE_SPLIT  // timing-only build: no hi-lo split
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = __float_as_uint(a[e].x); lo[e] = __float_as_uint(a[e].y); }
+        return;
+#endif
         float one = 1.f;
         asm("" : "+v"(one));
 #pragma unroll
@@ -207,24 +208,6 @@ template <> struct AFrag<LF_POOL_F16X3> {
             const float h1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h >> 16));
             hi[e] = h;
             lo[e] = pack_rtz(__builtin_fmaf(a[e].x, one, -h0), __builtin_fmaf(a[e].y, one, -h1));
-        }
-    }
-    // stream value = m * t: hi from the packed product, lo = fma(m, t, -hi) so that each residual is ONE
-    // v_fma_mix_f32 (f32 x f32 - f16) instead of an unpack plus a subtract
-    __device__ __forceinline__ void set_product(const f32x2 (&m)[4], const f32x2 (&t)[4]) {
-#ifdef LF_ABLATE_SPLIT  // timing-only build: no product / hi-lo split
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { hi[e] = __float_as_uint(m[e].x); lo[e] = __float_as_uint(t[e].y); }
-        return;
-#endif
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const f32x2 p = m[e] * t[e];
-            const unsigned h = pack_rtz(p.x, p.y);
-            const float h0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xffffu));
-            const float h1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h >> 16));
-            hi[e] = h;
-            lo[e] = pack_rtz(__builtin_fmaf(m[e].x, t[e].x, -h0), __builtin_fmaf(m[e].y, t[e].y, -h1));
         }
     }
 };
