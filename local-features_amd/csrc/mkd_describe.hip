@@ -1,0 +1,761 @@
+// MKD descriptor path, the describe kernel: device code for gfx950 (CDNA4, wave64).
+//
+//   mkd_pool   mkd/patch_gradients.glsl:72-104 + mkd/embedding.glsl:53-121 (both variants)
+//              + mkd/normalize.glsl:22-142 + mkd/whitening.glsl:22-77 + mkd/normalize_final.glsl
+// (paths under local_features/src/vulkan/shaders/; the other stages live in mkd_pyramid.hip -- pyramid and patch
+//  sampling --, mkd_orient.hip, mkd_detect.hip and mkd_match.hip)
+//
+// Pooling is a GEMM with M = patches, K = pixels, N = (stream, spatial kernel) columns.  One wave
+// owns 16 patches; lane l = (patch p = l & 15, segment q = l >> 4) holds the 8 pixels
+// x in [8q, 8q+8) of the current patch row, which is exactly the A-operand lane map of the
+// 16x16 MFMAs (row = l & 15, k-group = l >> 4).  So blur, gradients and the von-Mises
+// embedding are computed in the registers that feed the matrix cores; nothing but the final
+// sums leaves the wave.  Horizontal neighbours come from lanes l -/+ 16 via ds_bpermute; vertical
+// neighbours from a ring of raw patch rows that LDS-DMA keeps filled.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "mkd_device.h"
+
+namespace lfmkd {
+
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Two adjacent pixels per register pair: arithmetic on f32x2 compiles to v_pk_{mul,add,fma}_f32, which issue
+// in the time of one scalar-f32 VALU instruction (tools/micro/valu_rate.hip) -- the kernel is VALU-issue-bound.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_set(float v) { return f32x2{v, v}; }
+
+constexpr int kTiles = 21;   // accumulator tiles (16 packed columns each), see mkd_consts.hpp
+// Accumulator tile numbering: m 0-2 | rel cos k 3+2(k-1).. | rel sin k 9+2(k-1).. | abs cos k 14+k | abs sin k 17+k.
+// The cos and sin streams of one harmonic meet the same LUT columns, so a LUT row holds 12 unique tiles:
+//   0-2 m | 3-5 abs k=1..3 | 6-11 rel k=1..3 (two tiles each).
+constexpr int kUniqueTiles = 12;
+
+// 5-tap sigma=0.7 kernel, patch_gradients.glsl:22-28
+constexpr float kB0 = 0.0096f, kB1 = 0.2054f, kB2 = 0.5699f;
+
+// LDS map of the pooling kernel (bytes)
+constexpr int kRowBytes = kUniqueTiles * 2 * 1024;   // 24576: one LUT row image, 2 x 1 KiB pieces per tile
+constexpr int kPhiOff = 2 * kRowBytes;               // cos/sin(phi) table, 8 KiB
+constexpr int kRingOff = kPhiOff + 8192;             // raw patch rows: [wave 8][slot 6][2 KiB]
+constexpr int kRingSlots = 6;
+// total: kRingOff + waves * kRingSlots * 2048 = 155648 B for 8 waves, 106496 B for 4
+
+__device__ __forceinline__ float lane_fetch(int byte_addr, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+
+__device__ __forceinline__ void lds_dma16(const void *gsrc, void *ldst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+}
+
+// one LUT row (24 pieces) into an LDS row buffer, 24 / W pieces per wave
+template <int W>
+__device__ __forceinline__ void issue_lut_row(const unsigned char *__restrict__ lut_rows, int row,
+                                              unsigned char *lds_row, int wave, int lane) {
+    const unsigned char *g = lut_rows + (size_t)row * kRowBytes + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 24 / W; ++j) lds_dma16(g + (wave + W * j) * 1024, lds_row + (wave + W * j) * 1024);
+}
+
+// Whitening fragments are staged through the two LUT row buffers (idle during the epilogue) one 16 KiB step at a
+// time, shared by the workgroup's waves: three slots, placed so that step 0 lies in row buffer 0 (it is requested during
+// patch row 31, when only that buffer is free) and the last step in row buffer 1 (so that LUT row 0 of the next batch
+// can be requested into buffer 0 while the last step is still being consumed).
+constexpr int kWStepBytes = 16384;
+__device__ __forceinline__ constexpr int wstage_slot(int step) { return step % 3 == 0 ? 0 : (step % 3 == 1 ? 32768 : 16384); }
+static_assert(wstage_slot(0) + kWStepBytes <= kRowBytes && wstage_slot(10) >= kRowBytes && 3 * kWStepBytes <= 2 * kRowBytes, "");
+
+template <int W>
+__device__ __forceinline__ void issue_w_step(const unsigned char *__restrict__ wfrag, int step, unsigned char *lds,
+                                             int wave, int lane) {
+    const unsigned char *g = wfrag + (size_t)step * kWStepBytes + lane * 16;
+    unsigned char *d = lds + wstage_slot(step);
+#pragma unroll
+    for (int j = 0; j < 16 / W; ++j) lds_dma16(g + (wave + W * j) * 1024, d + (wave + W * j) * 1024);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// one raw patch row (16 patches x 128 B) of this wave into ring slot `slot`; rows outside [0,31] replicate
+__device__ __forceinline__ void issue_raw_row(const float *__restrict__ src_lane, int row, unsigned char *ring,
+                                              int slot) {
+    const int y = row < 0 ? 0 : (row > 31 ? 31 : row);
+    lds_dma16(src_lane + y * 32, ring + slot * 2048);
+    lds_dma16(src_lane + y * 32 + 16, ring + slot * 2048 + 1024);
+}
+
+// No implicit contraction in the describe kernel (down to the end of mkd_pool): every fused multiply-add in it is written
+// as one.  The 4-wave and 8-wave forms are separate instantiations, and left to itself hipcc may contract an
+// expression in one and not in the other -- a descriptor must not depend on the size of the request it was part of
+// (tests/test_gpu_parity.py::test_full_size_properties compares the two forms bit for bit).
+#pragma clang fp contract(off)
+
+// cos/sin of the gradient angle theta = -atan2(gy over gx), for a pair of pixels.
+template <int ANGLE>
+__device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 r2, f32x2 &ct, f32x2 &st) {
+    if (ANGLE == LF_ANGLE_EXACT || ANGLE == LF_ANGLE_EXACT_ZERO) {
+        // r2 = gx^2 + gy^2 comes from the caller (it is the magnitude's radicand before its epsilon)
+        const f32x2 inv = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+        const f32x2 c = gx * inv, s = -gy * inv;
+        // EXACT: angle 0 only for the null gradient (the CPU twin's atan2(0, 0)); EXACT_ZERO: wherever gx == 0, which is
+        // the shader's convention (atan2.glsl:33-38) -- the one place where the two angle definitions are far apart
+        const bool z0 = ANGLE == LF_ANGLE_EXACT ? r2.x == 0.f : gx.x == 0.f;
+        const bool z1 = ANGLE == LF_ANGLE_EXACT ? r2.y == 0.f : gx.y == 0.f;
+        ct = f32x2{z0 ? 1.f : c.x, z1 ? 1.f : c.y};
+        st = f32x2{z0 ? 0.f : s.x, z1 ? 0.f : s.y};
+    } else {
+        // atan2.glsl:19-46 called as atan2(x = gx, y = gy): a = (smaller / larger component), p = poly(a), then
+        //   swap (|x| < |y|):  res = sign(a) pi/2 - p;   x < 0: res += +-pi.
+        // poly is odd, so with a' = |a| and p' = poly(a') = |p| these branches are the octant symmetries
+        //   (|cos res|, |sin res|) = swap ? (sin p', cos p') : (cos p', sin p'),  sign(cos res) = sign(x),  sign(sin res) = sign(y)
+        // (case by case from the three lines above), and the first octant needs no signs and no select of num / den:
+        const float ax0 = fabsf(gx.x), ay0 = fabsf(gy.x), ax1 = fabsf(gx.y), ay1 = fabsf(gy.y);
+        const bool sw0 = ax0 < ay0, sw1 = ax1 < ay1;
+        const f32x2 mn = {__builtin_fminf(ax0, ay0), __builtin_fminf(ax1, ay1)};
+        const f32x2 mx = {__builtin_fmaxf(ax0, ay0), __builtin_fmaxf(ax1, ay1)};
+        const f32x2 a = mn * f32x2{__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
+        const f32x2 s = a * a;
+        f32x2 p = pk_fma(s, pk_set(-0.0117212f), pk_set(0.05265332f));
+        p = pk_fma(s, p, pk_set(-0.11643287f));
+        p = pk_fma(s, p, pk_set(0.19354346f));
+        p = pk_fma(s, p, pk_set(-0.33262347f));
+        p = pk_fma(s, p, pk_set(0.99997726f));
+        p = a * p;
+        // 0 <= p <= 0.7854: minimax fits in p^2 (Remez on [0, (pi/4)^2], float64, rounded to f32) -- 2.4e-9 / 2.8e-8
+        // before rounding, one term shorter than the Taylor series of the same accuracy
+        const f32x2 p2 = p * p;
+        f32x2 sn = pk_fma(p2, pk_set(-0.000195038549f), pk_set(0.0083320355f));
+        sn = pk_fma(p2, sn, pk_set(-0.166666508f));
+        sn = pk_fma(p2, sn, pk_set(1.f));
+        sn = p * sn;
+        f32x2 cs = pk_fma(p2, pk_set(-0.00135857589f), pk_set(0.0416550152f));
+        cs = pk_fma(p2, cs, pk_set(-0.499998569f));
+        cs = pk_fma(p2, cs, pk_set(1.f));
+        // cos theta = cos res: sign of gx; sin theta = -sin res: opposite sign of gy (sn, cs >= 0: OR the sign bit in)
+        const unsigned sgn = 0x80000000u;
+        float cr0 = __uint_as_float(__float_as_uint(sw0 ? sn.x : cs.x) | (__float_as_uint(gx.x) & sgn));
+        float cr1 = __uint_as_float(__float_as_uint(sw1 ? sn.y : cs.y) | (__float_as_uint(gx.y) & sgn));
+        float sr0 = __uint_as_float(__float_as_uint(sw0 ? cs.x : sn.x) | (~__float_as_uint(gy.x) & sgn));
+        float sr1 = __uint_as_float(__float_as_uint(sw1 ? cs.y : sn.y) | (~__float_as_uint(gy.y) & sgn));
+        // gx == 0: the shader returns 0 both for atan2(0, 0) and (its quirk) for atan2(0, y != 0)
+        if (gx.x == 0.f) { cr0 = 1.f; sr0 = 0.f; }
+        if (gx.y == 0.f) { cr1 = 1.f; sr1 = 0.f; }
+        ct = f32x2{cr0, cr1};
+        st = f32x2{sr0, sr1};
+    }
+}
+
+// ---- B fragments (LUT) and A fragments (streams) -------------------------------------------------
+// One unique LUT tile = two 1 KiB pieces: f32: pixels 0-3 / 4-7 of the lane's segment (K = 4 MFMAs);
+// f16: hi / lo halves of all 8 pixels (K = 32 MFMAs).  16 B per lane either way.
+struct BFrag { u32x4 p0, p1; };
+
+template <int UT>
+__device__ __forceinline__ BFrag load_b(const unsigned char *brow) {
+    BFrag b;
+#ifdef LF_ABLATE_BLOAD  // timing-only build: no LUT fragment reads
+    b.p0 = u32x4{(unsigned)UT, 1u, 2u, 3u}; b.p1 = b.p0; return b;
+#endif
+    b.p0 = *reinterpret_cast<const u32x4 *>(brow + (UT * 2 + 0) * 1024);
+    b.p1 = *reinterpret_cast<const u32x4 *>(brow + (UT * 2 + 1) * 1024);
+    return b;
+}
+
+__device__ __forceinline__ unsigned pack_rtz(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+
+// A operand of one stream: f32: the 8 values themselves; f16: hi = f16 truncation, lo = f16(a - hi)
+template <int POOL> struct AFrag;
+template <> struct AFrag<LF_POOL_F32> {
+    float v[8];
+    __device__ __forceinline__ void set(const f32x2 (&a)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = a[e].x; v[2 * e + 1] = a[e].y; }
+    }
+};
+template <> struct AFrag<LF_POOL_F16X3> {
+    u32x4 hi, lo;
+    __device__ __forceinline__ void set(const f32x2 (&a)[4]) {
+        // residual a - hi as ONE v_fma_mix_f32 (f32 x f32 - f16); the factor 1 is hidden from hipcc, which otherwise
+        // folds the fma into an unpack plus a subtract
+#ifdef LF_ABLATE_SPLIT  // timing-only build: no hi-lo split
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = __float_as_uint(a[e].x); lo[e] = __float_as_uint(a[e].y); }
+        return;
+#endif
+        float one = 1.f;
+        asm("" : "+v"(one));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned h = pack_rtz(a[e].x, a[e].y);
+            const float h0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xffffu));
+            const float h1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h >> 16));
+            hi[e] = h;
+            lo[e] = pack_rtz(__builtin_fmaf(a[e].x, one, -h0), __builtin_fmaf(a[e].y, one, -h1));
+        }
+    }
+};
+
+// acc += LUT^T x stream for one (stream, tile): the LUT fragment is the MFMA's A operand (rows = packed
+// columns), the stream its B operand (columns = patches), so a lane ends up holding packed columns
+// 16t + 4(lane >> 4) + i of ITS OWN patch (lane & 15) -- which is what the fused epilogue needs.
+// `part` selects one third of the f16 split so callers can interleave independent accumulators between the
+// dependent MFMAs of one tile.
+template <int POOL, int PART>
+__device__ __forceinline__ void mma_part(const AFrag<POOL> &a, const BFrag &b, f32x4 &acc) {
+#ifdef LF_ABLATE_MMA   // timing-only build: no matrix instructions, operands kept alive
+    if constexpr (POOL == LF_POOL_F16X3) { asm volatile("" ::"v"(a.hi), "v"(a.lo), "v"(b.p0), "v"(b.p1)); return; }
+#endif
+    if constexpr (POOL == LF_POOL_F32) {
+        const f32x4 b0 = __builtin_bit_cast(f32x4, b.p0), b1 = __builtin_bit_cast(f32x4, b.p1);
+        if (PART == 0) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[e], a.v[e], acc, 0, 0, 0);
+        } else if (PART == 1) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[3], a.v[3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[0], a.v[4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[1], a.v[5], acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[2], a.v[6], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[3], a.v[7], acc, 0, 0, 0);
+        }
+    } else {
+        const f16x8 bh = __builtin_bit_cast(f16x8, b.p0), bl = __builtin_bit_cast(f16x8, b.p1);
+        const f16x8 ah = __builtin_bit_cast(f16x8, a.hi), al = __builtin_bit_cast(f16x8, a.lo);
+        if (PART == 0) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acc, 0, 0, 0);
+        else if (PART == 1) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc, 0, 0, 0);
+    }
+}
+
+// cos and sin streams of one harmonic against the NT tiles they share
+template <int POOL, int NT>
+__device__ __forceinline__ void mma_pair(const AFrag<POOL> &ac, const AFrag<POOL> &as, const BFrag (&b)[NT],
+                                         f32x4 *acc_c, f32x4 *acc_s) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { mma_part<POOL, 0>(ac, b[t], acc_c[t]); mma_part<POOL, 0>(as, b[t], acc_s[t]); }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { mma_part<POOL, 1>(ac, b[t], acc_c[t]); mma_part<POOL, 1>(as, b[t], acc_s[t]); }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { mma_part<POOL, 2>(ac, b[t], acc_c[t]); mma_part<POOL, 2>(as, b[t], acc_s[t]); }
+}
+
+// Blurred row of this lane's segment from the raw-row ring (patch_gradients.glsl:72-92): vertical 5 taps over
+// ring slots s0..s0+4, then horizontal 5 taps with the neighbours fetched from lanes -/+16.
+// Returns the row plus its x-1 / x+8 neighbours.
+__device__ __forceinline__ void blur_row(const unsigned char *ring_lane, int s0, int addr_l, int addr_r, bool has_l,
+                                         bool has_r, float (&out)[8], float &out_l, float &out_r) {
+    float vb[8];
+    {
+        const float kk[5] = {kB0, kB1, kB2, kB1, kB0};
+        f32x2 v2[4];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            int sl = s0 + i;
+            sl = sl >= kRingSlots ? sl - kRingSlots : sl;
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(ring_lane + sl * 2048);
+            const f32x4 hi = *reinterpret_cast<const f32x4 *>(ring_lane + sl * 2048 + 256);
+            const f32x2 r[4] = {{lo[0], lo[1]}, {lo[2], lo[3]}, {hi[0], hi[1]}, {hi[2], hi[3]}};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v2[e] = i == 0 ? pk_set(kk[0]) * r[e] : pk_fma(pk_set(kk[i]), r[e], v2[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vb[2 * e] = v2[e].x; vb[2 * e + 1] = v2[e].y; }
+    }
+    float ext[12];
+    const float l0 = lane_fetch(addr_l, vb[6]), l1 = lane_fetch(addr_l, vb[7]);
+    const float r0 = lane_fetch(addr_r, vb[0]), r1 = lane_fetch(addr_r, vb[1]);
+    ext[0] = has_l ? l0 : vb[0];
+    ext[1] = has_l ? l1 : vb[0];
+    ext[10] = has_r ? r0 : vb[7];
+    ext[11] = has_r ? r1 : vb[7];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) ext[2 + x] = vb[x];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        float s = kB0 * ext[x];
+        s = fmaf(kB1, ext[x + 1], s);
+        s = fmaf(kB2, ext[x + 2], s);
+        s = fmaf(kB1, ext[x + 3], s);
+        s = fmaf(kB0, ext[x + 4], s);
+        out[x] = s;
+    }
+    const float hl = lane_fetch(addr_l, out[7]), hr = lane_fetch(addr_r, out[0]);
+    out_l = has_l ? hl : out[0];
+    out_r = has_r ? hr : out[7];
+}
+
+// One orientation family (absolute or relative angle): harmonics k = 1..3 by angle addition; harmonic k
+// uses unique LUT tiles [U0 + NT*(k-1), +NT) and accumulator tiles C0 + NT*(k-1).. (cos), S0 + NT*(k-1).. (sin).
+// `bnext` holds the fragments of harmonic 1 on entry (prefetched by the caller).
+template <int POOL, int NT, int U0, int C0, int S0>
+__device__ __forceinline__ void pool_family(const f32x2 (&m)[4], const f32x2 (&c1)[4], const f32x2 (&s1)[4],
+                                            const unsigned char *brow, BFrag (&b)[NT], f32x4 (&acc)[kTiles]) {
+    // The recurrence runs on the products themselves, (pk, qk) = m (cos, sin)(k theta), as a three-term (Chebyshev)
+    // recurrence x_{k+1} = 2 c1 x_k - x_{k-1} with x_0 = (m, 0): one instruction per stream and harmonic instead of a
+    // rotation of the unit vector (two) plus a product.
+    f32x2 pk[4], qk[4], pp[4], qp[4], tc[4];
+    AFrag<POOL> ac, as;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pk[e] = m[e] * c1[e]; qk[e] = m[e] * s1[e]; tc[e] = c1[e] + c1[e]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        ac.set(pk);
+        as.set(qk);
+        BFrag bcur[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bcur[t] = b[t];
+        if (k < 2) {  // fragments of the next harmonic: in flight behind this harmonic's matrix work
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (k == 0) b[t] = load_b<U0 + NT>(brow + t * 2048);
+                else b[t] = load_b<U0 + 2 * NT>(brow + t * 2048);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 pn = pk_fma(tc[e], pk[e], k == 0 ? -m[e] : -pp[e]);
+                const f32x2 qn = k == 0 ? tc[e] * qk[e] : pk_fma(tc[e], qk[e], -qp[e]);
+                pp[e] = pk[e]; qp[e] = qk[e];
+                pk[e] = pn; qk[e] = qn;
+            }
+        }
+        mma_pair<POOL, NT>(ac, as, bcur, &acc[C0 + NT * k], &acc[S0 + NT * k]);
+    }
+}
+
+// Epilogue, per wave and batch: acc[t][i] holds the pooled sum of packed column 16t + 4q + i for the lane's
+// own patch.  normalize.glsl:22-142 (polar | cartesian | all), whitening.glsl:22-77 as an MFMA with the
+// accumulators as B operand (out^T = W_T x raw, the mean folded into a bias), normalize_final.glsl.
+// Whitening fragments (host: mkd_consts.cpp): f16: [step 11][row tile 8][hi|lo][lane][8], step s covers
+// accumulator tiles 2s, 2s+1; f32: [tile 21][i 4][row tile 8][lane].
+// f16 path: on entry step 0 of the fragments is on its way into its slot (requested by the caller during patch row 31);
+// on exit LUT row 0 of the next batch is on its way into row buffer 0 if `more`.  Every wave of the workgroup must call.
+template <int POOL, int W>
+__device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lane, int wave, bool valid, long patch,
+                                                   const short *__restrict__ colmap,
+                                                   const unsigned char *__restrict__ wfrag,
+                                                   const float *__restrict__ bias, float *__restrict__ out,
+                                                   float *__restrict__ raw_out, unsigned char *s_mem,
+                                                   const unsigned char *__restrict__ lut_rows, bool more) {
+    const int q = lane >> 4;
+    if constexpr (POOL == LF_POOL_F16X3) {
+        __syncthreads();   // every wave has left patch row 31: row buffer 1 is free too
+        issue_w_step<W>(wfrag, 1, s_mem, wave, lane);
+        issue_w_step<W>(wfrag, 2, s_mem, wave, lane);
+    }
+    // tile 1 mixes polar (packed columns 0-8 of the tile) and cartesian (9-15) kernels of the m stream
+    bool t1_polar[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t1_polar[i] = 4 * q + i < 9;
+    float sp = 0.f, sc = 0.f;
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool polar = t == 0 || (t >= 3 && t <= 14) || (t == 1 && t1_polar[i]);
+            if (t == 1) {
+                const float v2 = acc[t][i] * acc[t][i];
+                sp += polar ? v2 : 0.f;
+                sc += polar ? 0.f : v2;
+            } else if (polar) {
+                sp = fmaf(acc[t][i], acc[t][i], sp);
+            } else {
+                sc = fmaf(acc[t][i], acc[t][i], sc);
+            }
+        }
+    sp += __shfl_xor(sp, 16); sp += __shfl_xor(sp, 32);
+    sc += __shfl_xor(sc, 16); sc += __shfl_xor(sc, 32);
+    const float inv_p = 1.f / __builtin_amdgcn_sqrtf(sp), inv_c = 1.f / __builtin_amdgcn_sqrtf(sc);
+    // normalize.glsl then L2-normalises the concatenation of the two unit blocks.  Its squared norm follows from the
+    // block sums (sp inv_p^2 + sc inv_c^2, within 2 ulp of the shader's second pass over the 238 values), so the two
+    // scalings fold into one pass
+    const float sa = fmaf(sp * inv_p, inv_p, (sc * inv_c) * inv_c);
+    const float inv_a = 1.f / __builtin_amdgcn_sqrtf(sa);
+    const float k_p = inv_p * inv_a, k_c = inv_c * inv_a;
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool polar = t == 0 || (t >= 3 && t <= 14) || (t == 1 && t1_polar[i]);
+            acc[t][i] *= polar ? k_p : k_c;
+        }
+    if (raw_out) {  // verification tap: the 238-D descriptor before whitening
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = colmap[t * 16 + 4 * q + i];
+                if (valid && d >= 0) raw_out[patch * 238 + d] = acc[t][i];
+            }
+    }
+    f32x4 o[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (POOL == LF_POOL_F16X3) {
+        // The whitening is bound by operand delivery (each wave needs all 176 KiB of fragments per batch): from LDS, where
+        // the 8 waves share one copy, they arrive at twice the rate the vector L1 gives each wave its own.
+        constexpr int kDma = 16 / W;   // DMA instructions per lane and step
+        if (raw_out) wait_vmcnt<0>();  // stores and loads retire out of order with respect to each other
+        // Within a wave the LDS reads run one unit (4 row tiles, hi + lo = 8 KiB) ahead of the MFMAs, in two register
+        // buffers: the waves of a workgroup move in lock step here, so without that the LDS and the matrix pipe would
+        // take turns idling.
+        u32x4 wbuf[2][8];   // [buffer][row tile rr][hi|lo]
+        auto read_unit = [&](int u, u32x4 (&dst)[8]) {
+            const u32x4 *w = reinterpret_cast<const u32x4 *>(s_mem + wstage_slot(u >> 1)) + (u & 1) * 8 * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[j] = w[j * 64];
+        };
+        f16x8 yh, yl;
+        auto mma_unit = [&](int u, const u32x4 (&src)[8]) {
+            const int r0 = (u & 1) * 4;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                o[r0 + rr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, src[2 * rr + 1]), yh, o[r0 + rr], 0, 0, 0);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                o[r0 + rr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, src[2 * rr]), yl, o[r0 + rr], 0, 0, 0);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                o[r0 + rr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, src[2 * rr]), yh, o[r0 + rr], 0, 0, 0);
+        };
+#pragma unroll
+        for (int s = 0; s < 11; ++s) {
+            // own share of step s has landed (steps s+1, and s+2 for s = 0, may still be in flight) and own reads of
+            // step s-1 have returned; after the barrier that holds for every wave, so the slot of step s-1 can take
+            // step s+2
+            if (s == 0) wait_vmcnt<2 * kDma>();
+            else if (s < 10) wait_vmcnt<kDma>();
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (s >= 1 && s + 2 < 11) issue_w_step<W>(wfrag, s + 2, s_mem, wave, lane);
+            if (s == 10 && more) issue_lut_row<W>(lut_rows, 0, s_mem, wave, lane);
+            read_unit(2 * s, wbuf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s > 0) mma_unit(2 * s - 1, wbuf[1]);
+            {
+                const f32x4 y0 = acc[2 * s];
+                const f32x4 y1 = 2 * s + 1 < kTiles ? acc[(2 * s + 1 < kTiles) ? 2 * s + 1 : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x2 y[4] = {{y0[0], y0[1]}, {y0[2], y0[3]}, {y1[0], y1[1]}, {y1[2], y1[3]}};
+                AFrag<LF_POOL_F16X3> yb;
+                yb.set(y);
+                yh = __builtin_bit_cast(f16x8, yb.hi);
+                yl = __builtin_bit_cast(f16x8, yb.lo);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            read_unit(2 * s + 1, wbuf[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_unit(2 * s, wbuf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mma_unit(21, wbuf[1]);
+    } else {
+        const float *w = reinterpret_cast<const float *>(wfrag);
+        float wbuf[2][16];  // unit = two (tile, i) steps x 8 row tiles
+        auto load_unit = [&](int u, float (&dst)[16]) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) dst[k * 8 + r] = w[((2 * u + k) * 8 + r) * 64 + lane];
+        };
+        load_unit(0, wbuf[0]);
+#pragma unroll
+        for (int u = 0; u < 42; ++u) {
+            if (u + 1 < 42) load_unit(u + 1, wbuf[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int ti = 2 * u + k;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    o[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wbuf[u & 1][k * 8 + r], acc[ti >> 2][ti & 3], o[r], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // lane holds outputs 16r + 4q + i of its patch: add the bias (-W mean), L2-normalise, store
+    float ss = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + 16 * r + 4 * q);
+        o[r] += b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ss = fmaf(o[r][i], o[r][i], ss);
+    }
+    ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+    const float inv = 1.f / __builtin_amdgcn_sqrtf(ss);   // one division, 32 multiplications: 1 ulp from 32 divisions
+    if (valid) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) *reinterpret_cast<f32x4 *>(out + patch * 128 + 16 * r + 4 * q) = o[r] * inv;
+    }
+}
+
+}  // namespace
+
+// grid = min(#batches, #CUs) persistent workgroups of 8 waves; a batch is 128 patches (16 per wave).
+// Per patch row g (32 per batch): one barrier, after which the LUT row g is in LDS (issued a whole row
+// earlier, double-buffered) and every wave has left row g-1.  Raw patch rows arrive by LDS-DMA into a
+// 6-slot ring private to each wave, one row per step, so the main loop holds no patch data in VGPRs beyond
+// the three blurred rows of the gradient stencil.
+// Algorithmic HBM bytes per patch: 4096 read + 512 written; the kernel moves nothing else.
+// W = waves per workgroup: 8 (128 patches, two waves per SIMD) for throughput; 4 (64 patches) when the whole request
+// fits one round of workgroups anyway, so that it spreads over twice as many CUs with a SIMD to each wave.
+#ifdef LF_PHASE_TIMING   // timing-only build (tools/phase_timing.py): per-wave wall clock of the phases of a patch row,
+                         // left by workgroup 0 in out[wave * 128 + phase]
+#define LF_PT(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                      pt[i] += t_ - pt_prev; pt_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LF_PT(i) do { } while (0)
+#endif
+
+template <int ANGLE, int POOL, int W>
+__global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ patches, long n_host,
+                                                const unsigned long long *__restrict__ n_dev,
+                                                const unsigned char *__restrict__ lut_rows,
+                                                const float *__restrict__ phi_cs,
+                                                const short *__restrict__ colmap,
+                                                const unsigned char *__restrict__ wfrag,
+                                                const float *__restrict__ bias,
+                                                float *__restrict__ out, float *__restrict__ raw_out) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kRingOff + W * kRingSlots * 2048];
+    // number of patches: given by the host, or (graph-captured pipelines) left on the device by the previous stage
+    const long n = n_dev ? (long)*n_dev : n_host;
+    float *s_phi = reinterpret_cast<float *>(s_mem + kPhiOff);
+    // (cos, sin) per pixel in the table; in LDS per pixel pair as (cos, cos, sin, sin), so that a 16-byte read lands as
+    // two aligned register pairs (interleaved, every pair cost three v_mov to take apart)
+    for (int i = threadIdx.x; i < 2048; i += 64 * W) s_phi[(i >> 2) * 4 + (i & 1) * 2 + ((i >> 1) & 1)] = phi_cs[i];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 15, q = lane >> 4;
+    const int addr_l = ((lane - 16) & 63) * 4, addr_r = ((lane + 16) & 63) * 4;
+    const bool has_l = q > 0, has_r = q < 3;
+    const long nbatch = (n + 16 * W - 1) / (16 * W);
+    unsigned char *ring = s_mem + kRingOff + wave * (kRingSlots * 2048);
+    // DMA writes are lane-linear (lane l -> bytes [16l, 16l+16) of a 1 KiB piece): lane (p, q) moves the 16-B
+    // chunk q of its patch's half-row; the reader (p, q) needs chunks 2(q&1), 2(q&1)+1 of half q>>1.
+    const unsigned char *ring_lane = ring + (q >> 1) * 1024 + ((2 * (q & 1)) * 16 + p) * 16;
+
+    auto lane_src = [&](long batch) {
+        const long b0 = batch * (16 * W) + wave * 16;
+        const long pidx = (b0 + p < n) ? b0 + p : n - 1;  // tail lanes recompute the last patch
+        return patches + pidx * 1024 + 4 * q;
+    };
+
+    long batch = blockIdx.x;
+    if (batch >= nbatch) return;
+    {
+        const float *src = lane_src(batch);
+#pragma unroll
+        for (int r = -2; r <= 3; ++r) issue_raw_row(src, r, ring, r + 2);
+        issue_lut_row<W>(lut_rows, 0, s_mem, wave, lane);
+    }
+    unsigned par = 0;  // LUT row buffer holding the row about to be consumed
+#ifdef LF_PHASE_TIMING
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_prev = __builtin_readcyclecounter();
+#endif
+
+    for (; batch < nbatch; batch += gridDim.x) {
+        const long base = batch * (16 * W) + wave * 16;
+        const float *src = lane_src(batch);
+        const bool more = batch + gridDim.x < nbatch;
+        const float *src_next = more ? lane_src(batch + gridDim.x) : src;
+
+        f32x4 acc[kTiles];
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float cur[8], prv[8], cur_l = 0.f, cur_r = 0.f;  // blurred rows g and g-1 (row -1 replicates row 0)
+        int s0 = 1;                                      // ring slot of raw row g-1 (rows g-1..g+3 feed hb(g+1))
+
+        // The first and the last row of a batch differ from the 30 between them (two blurs and a later ring request /
+        // no blur and the next batch's first rows): they are separate copies of the row body, so that the loop over the
+        // middle rows carries none of their branches -- hipcc speculated the last row's "row 32 = row 31" copy into
+        // every row (ten v_mov).
+        auto patch_row = [&](auto kind, const int g) __attribute__((always_inline)) {
+            constexpr bool kFirst = decltype(kind)::value == 0, kLast = decltype(kind)::value == 2;
+
+            // LUT row g and ring row g+3 have landed (own DMA: vmcnt; everyone's: barrier); row g-1 is done
+            LF_PT(7);
+#ifndef LF_ABLATE_SYNC
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#endif
+            LF_PT(0);
+            const unsigned char *brow = s_mem + par * kRowBytes + lane * 16;
+            // row buffer par ^ 1 is free: next LUT row; during row 31 the f16 epilogue's first whitening step instead
+            if (POOL == LF_POOL_F16X3 ? !kLast : (!kLast || more))
+                issue_lut_row<W>(lut_rows, (g + 1) & 31, s_mem + (par ^ 1) * kRowBytes, wave, lane);
+            else if (POOL == LF_POOL_F16X3)
+                issue_w_step<W>(wfrag, 0, s_mem, wave, lane);
+            par ^= 1;
+            BFrag bm[3] = {load_b<0>(brow), load_b<1>(brow), load_b<2>(brow)};   // m-stream fragments
+
+#ifdef LF_ABLATE_FRONT  // timing-only build: no blur, no gradient direction
+#define blur_row(rl, s, al, ar, hl, hr, o, ol, or_) do { const f32x4 a_ = *reinterpret_cast<const f32x4 *>(rl + (s) * 2048); const f32x4 b_ = *reinterpret_cast<const f32x4 *>(rl + (s) * 2048 + 256); for (int x_ = 0; x_ < 4; ++x_) { o[x_] = a_[x_]; o[4 + x_] = b_[x_]; } ol = o[0]; or_ = o[7]; } while (0)
+#endif
+            // Raw row g+4 goes into the slot of row g-2, whose last reader was the blur of the previous iteration: for
+            // g >= 1 it is requested here, a whole row before the vmcnt(0) that waits for it (counters: the waves spend
+            // 29 % of their time in s_waitcnt and only 2 % of that on LDS), for g == 0 after the first blur below.
+            if (!kFirst && !kLast && g <= 29) issue_raw_row(src, g + 4, ring, s0 == 0 ? kRingSlots - 1 : s0 - 1);
+            if (kFirst) {  // first blurred row of the batch: rows -2..2 sit in slots 0..4
+                blur_row(ring_lane, 0, addr_l, addr_r, has_l, has_r, cur, cur_l, cur_r);
+#pragma unroll
+                for (int x = 0; x < 8; ++x) prv[x] = cur[x];
+            }
+            float nxt[8], nxt_l, nxt_r;
+            if (!kLast) {  // hb(g+1) from raw rows g-1..g+3 = slots s0..s0+4
+                blur_row(ring_lane, s0, addr_l, addr_r, has_l, has_r, nxt, nxt_l, nxt_r);
+            } else {  // row 32 replicates row 31
+#pragma unroll
+                for (int x = 0; x < 8; ++x) nxt[x] = cur[x];
+                nxt_l = cur_l;
+                nxt_r = cur_r;
+            }
+            // the slot of raw row g-2 is free now (its last reader was the blur above when g == 0)
+            asm volatile("" ::: "memory");
+            if (kFirst) {
+                issue_raw_row(src, g + 4, ring, s0 == 0 ? kRingSlots - 1 : s0 - 1);
+            } else if (kLast && more) {
+#pragma unroll
+                for (int r = -2; r <= 3; ++r) issue_raw_row(src_next, r, ring, r + 2);  // next batch's first rows
+            }
+            s0 = s0 == kRingSlots - 1 ? 0 : s0 + 1;
+            LF_PT(1);
+
+            f32x2 m[4], c1[4], s1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {  // patch_gradients.glsl:94-100, two pixels at a time
+                const int x = 2 * e;
+                const f32x2 left = {x == 0 ? cur_l : cur[x - 1], cur[x]};
+                const f32x2 right = {cur[x + 1], x == 6 ? cur_r : cur[x + 2]};
+                const f32x2 gx = left - right;                                   // left - right
+                const f32x2 gy = f32x2{nxt[x], nxt[x + 1]} - f32x2{prv[x], prv[x + 1]};   // down - up
+                const f32x2 r2n = pk_fma(gy, gy, gx * gx);
+                const f32x2 r2 = r2n + pk_set(1e-8f);
+                m[e] = f32x2{__builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(r2.x)),
+                             __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(r2.y))};
+#ifdef LF_ABLATE_FRONT
+                c1[e] = gx; s1[e] = gy;
+#else
+                gradient_direction<ANGLE>(gx, gy, r2n, c1[e], s1[e]);
+#endif
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                prv[x] = cur[x];
+                cur[x] = nxt[x];
+            }
+            cur_l = nxt_l;
+            cur_r = nxt_r;
+            LF_PT(2);
+
+            // m stream x (polar | cartesian) kernels: accumulator tiles 0-2
+            BFrag babs[1] = {load_b<3>(brow)};
+            {
+                AFrag<POOL> am;
+                am.set(m);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) mma_part<POOL, 0>(am, bm[t], acc[t]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) mma_part<POOL, 1>(am, bm[t], acc[t]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) mma_part<POOL, 2>(am, bm[t], acc[t]);
+            }
+            LF_PT(3);
+            // absolute angle x cartesian kernels: unique tiles 3-5, accumulators 15-17 (cos), 18-20 (sin)
+            BFrag brel[2] = {load_b<6>(brow), load_b<7>(brow)};
+            pool_family<POOL, 1, 3, 15, 18>(m, c1, s1, brow, babs, acc);
+            LF_PT(4);
+            // angle + gradient_angle(px) (embedding.glsl:70-72) x polar kernels: unique tiles 6-11
+            f32x2 d1[4], e1[4];
+            {
+                const f32x4 *pp = reinterpret_cast<const f32x4 *>(&s_phi[(g * 32 + 8 * q) * 2]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 t4 = pp[e];   // cos of phi for pixels 2e, 2e+1, then their sines
+                    const f32x2 cp = {t4[0], t4[1]}, sp = {t4[2], t4[3]};
+                    d1[e] = pk_fma(c1[e], cp, -(s1[e] * sp));
+                    e1[e] = pk_fma(s1[e], cp, c1[e] * sp);
+                }
+            }
+            pool_family<POOL, 2, 6, 3, 9>(m, d1, e1, brow, brel, acc);
+            LF_PT(5);
+        };
+        patch_row(std::integral_constant<int, 0>(), 0);
+#pragma unroll 1
+        for (int g = 1; g < 31; ++g) patch_row(std::integral_constant<int, 1>(), g);
+        patch_row(std::integral_constant<int, 2>(), 31);
+        // launder the (uniform) table pointers once per batch: otherwise hipcc hoists one 64-bit VGPR address per
+        // whitening-fragment load out of the batch loop and spills 1.4 KB of them per lane
+        const unsigned char *wf = wfrag;
+        const float *bs = bias;
+        asm volatile("" : "+s"(wf), "+s"(bs));
+#ifdef LF_ABLATE_EPILOGUE  // timing-only build
+        { f32x4 sum = acc[0]; for (int t = 1; t < kTiles; ++t) sum += acc[t];
+          if (base + p < n) *reinterpret_cast<f32x4 *>(out + (base + p) * 128 + 4 * q) = sum;
+          if (POOL == LF_POOL_F16X3) { __syncthreads(); if (more) issue_lut_row<W>(lut_rows, 0, s_mem, wave, lane); } }
+#else
+        finish_descriptors<POOL, W>(acc, lane, wave, base + p < n, base + p, colmap, wf, bs, out, raw_out, s_mem, lut_rows,
+                                    more);
+#endif
+        LF_PT(6);
+    }
+#ifdef LF_PHASE_TIMING
+    __syncthreads();
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) out[wave * 128 + i] = (float)pt[i];
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+// n_dev != nullptr: the patch count is read on the device (<= n, which then only sizes the grid)
+void launch_describe(const float *patches, long n, const unsigned long long *n_dev, const DeviceConsts &dc,
+                     int angle_mode, int pool_mode, float *out, float *raw_out, int num_cus, hipStream_t stream) {
+    if (n <= 0) return;
+    // one 100-152 KiB-LDS workgroup per CU; requests of at most one round of 64-patch workgroups take the 4-wave form
+#ifdef LF_ABLATE_FORCE_W4   // timing-only build: the 4-wave form at every size
+    const bool small = true;
+#else
+    const bool small = n <= 64L * num_cus;
+#endif
+    const long nbatch = small ? (n + 63) / 64 : (n + 127) / 128;
+    const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);
+    const bool f16 = pool_mode == LF_POOL_F16X3;
+    const unsigned char *lut = f16 ? reinterpret_cast<const unsigned char *>(dc.pool_b_f16)
+                                   : reinterpret_cast<const unsigned char *>(dc.pool_b_f32);
+    const unsigned char *wf = f16 ? reinterpret_cast<const unsigned char *>(dc.white_a_f16)
+                                  : reinterpret_cast<const unsigned char *>(dc.white_a_f32);
+#define LF_LAUNCH_W(A, P, WV)                                                                                          \
+    hipLaunchKernelGGL((mkd_pool<A, P, WV>), dim3(grid), dim3(64 * WV), 0, stream, patches, n, n_dev, lut, dc.phi_cs, \
+                       dc.colmap, wf, dc.white_bias, out, raw_out)
+#define LF_LAUNCH(A, P)            \
+    do {                           \
+        if (small) LF_LAUNCH_W(A, P, 4); \
+        else LF_LAUNCH_W(A, P, 8); \
+    } while (0)
+    if (f16) {
+        if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH(LF_ANGLE_EXACT, LF_POOL_F16X3);
+        else if (angle_mode == LF_ANGLE_EXACT_ZERO) LF_LAUNCH(LF_ANGLE_EXACT_ZERO, LF_POOL_F16X3);
+        else LF_LAUNCH(LF_ANGLE_SHADER, LF_POOL_F16X3);
+    } else {
+        if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH(LF_ANGLE_EXACT, LF_POOL_F32);
+        else if (angle_mode == LF_ANGLE_EXACT_ZERO) LF_LAUNCH(LF_ANGLE_EXACT_ZERO, LF_POOL_F32);
+        else LF_LAUNCH(LF_ANGLE_SHADER, LF_POOL_F32);
+    }
+#undef LF_LAUNCH_W
+#undef LF_LAUNCH
+}
+
+}  // namespace lfmkd

@@ -1,0 +1,593 @@
+// MKD descriptor path: scale-space detector and blob filter for gfx950.
+//
+//   scan_extrema      swt_sub.glsl:17-30 + scan_extrema.glsl:36-241; cubes_* = its ordered compaction
+//   topk_*            the host blob filter of detect_top_n (vulkan/mod.rs:1753-1786) on the device; segments_* batch it
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mkd_device.h"
+
+namespace lfmkd {
+
+// ---------------------------------------------------------------------------------------------
+// Detector: DoG + 3-D extremum scan + quadratic refinement + edge test (swt_sub.glsl:17-30,
+// scan_extrema.glsl:36-241).  The reference works in 4x4x4 cubes with at most 8 candidates each; a cube is
+// exactly one wavefront here (lane = x + 4 y + 16 z), so "which 8" and the order of the survivors are settled
+// by ballots in lane order instead of atomics.  The DoG is never written to HBM: a workgroup differences the
+// a-trous layers into an LDS tile (the subtraction is the same single f32 operation either way).
+// Output per cube: count + up to 8 slots {x, y, size, contrast}; cubes_compact_* turn that into the ordered list.
+// ---------------------------------------------------------------------------------------------
+// Workgroup = a 32 x 8 pixel tile (8 x 2 cubes per cube layer): the tile's DoG volume (plus a one-texel rim) is
+// differenced into LDS once with row-contiguous loads, then each of the 4 waves walks its share of the cubes.
+constexpr int kScanTX = 32, kScanTY = 8, kScanMaxFine = 8;
+constexpr int kScanRowLen = kScanTX + 2, kScanPlane = (kScanTY + 2) * kScanRowLen;
+
+__global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ layer0, long layer0_stride,
+                                                    const float *__restrict__ coarse, long coarse_stride,
+                                                    long layer_stride, int n_fine, int w, int h, int border,
+                                                    int skip_layers, float contrast_threshold, int gx, int gy, int gz,
+                                                    float *__restrict__ slots /*[frames*cubes][8][4]*/,
+                                                    unsigned *__restrict__ counts /*[frames*cubes]*/) {
+#pragma clang fp contract(off)
+    __shared__ float s_dog[kScanMaxFine * kScanPlane];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned f = blockIdx.z;
+    const int tx0 = blockIdx.x * kScanTX + border, ty0 = blockIdx.y * kScanTY + border;   // first candidate texel
+    const float *l0 = layer0 + f * layer0_stride, *cs = coarse + f * coarse_stride;
+    // fine[z] = coarse[z] - coarse[z+1] (swt_sub.glsl:24-29) for the tile and its rim; outside the frame: 0
+    for (int i = threadIdx.x; i < kScanPlane; i += 256) {
+        const int yy = i / kScanRowLen, xx = i - yy * kScanRowLen;
+        const int x = tx0 - 1 + xx, y = ty0 - 1 + yy;
+        const bool in = x >= 0 && x < w && y >= 0 && y < h;
+        const size_t o = in ? (size_t)y * w + x : 0;
+        float c[kScanMaxFine + 1];   // all layers of this texel requested at once
+        c[0] = in ? l0[o] : 0.f;
+#pragma unroll
+        for (int z = 0; z < kScanMaxFine; ++z) c[z + 1] = (in && z < n_fine) ? cs[(size_t)z * layer_stride + o] : 0.f;
+#pragma unroll
+        for (int z = 0; z < kScanMaxFine; ++z)
+            if (z < n_fine) s_dog[z * kScanPlane + i] = c[z] - c[z + 1];
+    }
+    __syncthreads();
+    const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
+    const int b1 = border > 1 ? border : 1;
+    const int ncubes = gx * gy * gz;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int q = wave; q < 16 * gz; q += 4) {   // cube q of this tile: (cube layer, cube row, cube column)
+        const int qz = q >> 4, qy = (q >> 3) & 1, qx = q & 7;
+        const int cx = blockIdx.x * 8 + qx, cy = blockIdx.y * 2 + qy;
+        if (cx >= gx || cy >= gy) continue;      // uniform per wave
+        const int x = tx0 + qx * 4 + lx, y = ty0 + qy * 4 + ly, z = qz * 4 + lz + 1 + skip_layers;
+        const bool inside = !(x < b1 || x >= w - b1 || y < b1 || y >= h - b1 || z <= 0 || z >= n_fine - 1);
+        // LDS index of this voxel; out-of-range lanes are parked on a valid interior voxel and never become candidates
+        const int c = (inside ? z : 1) * kScanPlane + (qy * 4 + ly + 1) * kScanRowLen + (qx * 4 + lx + 1);
+        auto at = [&](int dz, int dy, int dx) { return s_dog[c + dz * kScanPlane + dy * kScanRowLen + dx]; };
+        const float val = s_dog[c];
+        // sign(val) val >= sign(val) neighbour for all 26 neighbours (lines 97-124)  <=>  val >= their maximum when
+        // val > 0, val <= their minimum when val < 0 (multiplying by +-1 is exact): 13 max3 + 13 min3 instead of 26
+        // multiply-compare-and chains, and no divergence
+        float nmax = -INFINITY, nmin = INFINITY;
+#pragma unroll
+        for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx)
+                    if (dz || dy || dx) {
+                        const float v = at(dz, dy, dx);
+                        nmax = fmaxf(nmax, v);
+                        nmin = fminf(nmin, v);
+                    }
+        const bool cand = inside && fabsf(val) > contrast_threshold && (val > 0.f ? val >= nmax : val <= nmin);
+        const unsigned long long cm = __ballot(cand);
+        bool emit = false;
+        float ox = 0.f, oy = 0.f, size = 0.f, contrast = 0.f;
+        if (cand && __popcll(cm & below) < 8) {   // max_wg_extrema = 8 (scan_extrema.glsl:28)
+            const float dds = (at(1, 0, 0) - at(-1, 0, 0)) / 2.0f;
+            const float ddy = (at(0, 1, 0) - at(0, -1, 0)) / 2.0f;
+            const float ddx = (at(0, 0, 1) - at(0, 0, -1)) / 2.0f;
+            const float value2x = val * 2.0f;
+            const float h11 = at(1, 0, 0) + at(-1, 0, 0) - value2x;
+            const float h22 = at(0, 1, 0) + at(0, -1, 0) - value2x;
+            const float h33 = at(0, 0, 1) + at(0, 0, -1) - value2x;
+            const float h12 = (at(1, 1, 0) - at(-1, 1, 0) - at(1, -1, 0) + at(-1, -1, 0)) / 4.0f;
+            const float h13 = (at(1, 0, 1) - at(-1, 0, 1) - at(1, 0, -1) + at(-1, 0, -1)) / 4.0f;
+            const float h23 = (at(0, 1, 1) - at(0, 1, -1) - at(0, -1, 1) + at(0, -1, -1)) / 4.0f;
+            const float det =
+                h11 * h22 * h33 - h11 * h23 * h23 - h12 * h12 * h33 + 2.f * h12 * h13 * h23 - h13 * h13 * h22;
+            const float hinv11 = (h22 * h33 - h23 * h23) / det;
+            const float hinv12 = (h13 * h23 - h12 * h33) / det;
+            const float hinv13 = (h12 * h23 - h13 * h22) / det;
+            const float hinv22 = (h11 * h33 - h13 * h13) / det;
+            const float hinv23 = (h12 * h13 - h11 * h23) / det;
+            const float hinv33 = (h11 * h22 - h12 * h12) / det;
+            const float os = -(hinv11 * dds + hinv12 * ddy + hinv13 * ddx);
+            oy = -(hinv12 * dds + hinv22 * ddy + hinv23 * ddx);
+            ox = -(hinv13 * dds + hinv23 * ddy + hinv33 * ddx);
+            // |offset| > 0.5 in any direction: the shader moves x, y, z and emits nothing (lines 200-203).
+            // A singular hessian gives NaN offsets; the shader would emit NaN coordinates, here it is dropped.
+            const bool within = fabsf(ox) <= 0.5f && fabsf(oy) <= 0.5f && fabsf(os) <= 0.5f;
+            const float interp = os * dds + oy * ddy + ox * ddx;
+            contrast = fabsf(val + interp / 2.0f);
+            const float denom = (h22 + h33) * (h22 + h33);
+            const float cmv = 1.f - 4.f * (h22 * h33 - h23 * h23) / denom;
+            emit = within && denom != 0.f && !(0.7f <= cmv && cmv <= 1.5f);
+            size = 0.82f * 1.41421356237f * exp2f((float)z + os);
+        }
+        const unsigned long long em = __ballot(emit);
+        const size_t g = (size_t)f * ncubes + ((size_t)qz * gy + cy) * gx + cx;
+        if (emit) {
+            float *o = slots + (g * 8 + __popcll(em & below)) * 4;
+            o[0] = (float)x + ox;
+            o[1] = (float)y + oy;
+            o[2] = size;
+            o[3] = contrast;
+        }
+        if (lane == 0) counts[g] = (unsigned)__popcll(em);
+    }
+}
+
+// Ordered compaction of per-cube slots, three small launches: (1) sums of 1024 counts, (2) one workgroup scans the
+// sums, (3) every workgroup rescans its 1024 counts from its base and copies the slots.  Item i belongs to frame
+// i / items_per_frame; frame_start[f] (optional) receives the offset of the frame's first extremum.
+__global__ __launch_bounds__(1024) void cubes_block_sums(const unsigned *__restrict__ counts, long n,
+                                                         unsigned *__restrict__ sums) {
+    __shared__ unsigned ws[16];
+    const long i = (long)blockIdx.x * 1024 + threadIdx.x;
+    unsigned v = i < n ? counts[i] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int k = 0; k < 16; ++k) t += ws[k];
+        sums[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void cubes_scan_sums(unsigned *__restrict__ sums, long nb, unsigned long long max_out,
+                                                        unsigned long long *__restrict__ totals) {
+    __shared__ unsigned ws[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long base = 0;
+    for (long chunk = 0; chunk < nb; chunk += 1024) {
+        const long i = chunk + threadIdx.x;
+        const unsigned c = i < nb ? sums[i] : 0u;
+        unsigned incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        unsigned before = 0, all = 0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const unsigned t = ws[v];
+            before += v < wave ? t : 0u;
+            all += t;
+        }
+        if (i < nb) sums[i] = (unsigned)(base + before + incl - c);   // exclusive offset of the block
+        base += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[0] = base < max_out ? base : max_out;
+        totals[1] = base < max_out ? 0ull : base - max_out;
+    }
+}
+
+__global__ __launch_bounds__(1024) void cubes_scatter(const unsigned *__restrict__ counts,
+                                                      const float *__restrict__ slots,
+                                                      const unsigned *__restrict__ block_offsets, long n,
+                                                      long items_per_frame, float *__restrict__ out /*[max_out][4]*/,
+                                                      unsigned *__restrict__ frame_of, unsigned *__restrict__ frame_start,
+                                                      unsigned long long max_out) {
+    __shared__ unsigned ws[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 1024 + threadIdx.x;
+    const unsigned c = i < n ? counts[i] : 0u;
+    unsigned incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    unsigned before = 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) before += v < wave ? ws[v] : 0u;
+    const unsigned long long first = (unsigned long long)block_offsets[blockIdx.x] + before + incl - c;
+    if (i >= n) return;
+    const unsigned f = (unsigned)(i / items_per_frame);
+    if (frame_start && i == (long)f * items_per_frame) frame_start[f] = (unsigned)(first < max_out ? first : max_out);
+    for (unsigned j = 0; j < c; ++j) {
+        const unsigned long long o = first + j;
+        if (o < max_out) {
+            *reinterpret_cast<f32x4 *>(out + o * 4) = *reinterpret_cast<const f32x4 *>(slots + ((size_t)i * 8 + j) * 4);
+            if (frame_of) frame_of[o] = f;
+        }
+    }
+}
+
+// TopKContrastFilter::filter (vulkan/mod.rs:1753-1786) for one frame's extrema [n][4], one workgroup per frame:
+// keep blobs with size >= min_size; if more than n_keep remain, find the (n_keep+1)-th largest contrast (radix
+// select on the float bits, contrast >= 0) and keep, in index order, the first n_keep blobs that reach it.
+// seg_start[f], seg_start[f+1] delimit frame f (seg_start == nullptr: one segment [0, *n_in)).
+// out: gathered extrema from out_base(f) = f * n_keep; out_count[f].
+__global__ __launch_bounds__(1024) void topk_filter(const float *__restrict__ extrema, const unsigned *__restrict__ seg_start,
+                                                    const unsigned long long *__restrict__ n_in,
+                                                    unsigned long long n_host, unsigned n_frames, unsigned seg_cap,
+                                                    unsigned n_keep, float min_size, float *__restrict__ out,
+                                                    unsigned *__restrict__ out_index, unsigned *__restrict__ out_count,
+                                                    unsigned long long *__restrict__ out_count64) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned ws[16];
+    __shared__ unsigned sh_prefix, sh_rank, sh_m;
+    const unsigned f = blockIdx.x;
+    const unsigned total = (unsigned)(n_in ? n_in[0] : n_host);   // count on the device, or given by the host
+    unsigned lo = seg_start ? seg_start[f] : 0u;
+    unsigned hi = seg_start ? (f + 1 < n_frames ? seg_start[f + 1] : total) : total;
+    lo = lo < total ? lo : total;
+    hi = hi < total ? hi : total;
+    hi = hi - lo > seg_cap ? lo + seg_cap : hi;   // a frame's extrema beyond max_extrema are dropped (mod.rs:627)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // One sweep over the segment, four extrema per thread and step so that their loads are in flight together (the
+    // segment is a few thousand to a few ten thousand entries: the sweeps are latency-, not bandwidth-bound).
+    // fn(index, passes min_size, key = float bits of |contrast|)
+    auto sweep = [&](auto fn) {
+        for (unsigned i0 = lo + threadIdx.x; i0 < hi; i0 += 4096) {
+            float sz[4], ct[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned i = i0 + 1024u * j;
+                const bool in = i < hi;
+                sz[j] = in ? extrema[(size_t)i * 4 + 2] : 0.f;
+                ct[j] = in ? extrema[(size_t)i * 4 + 3] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned i = i0 + 1024u * j;
+                if (i < hi) fn(i, sz[j] >= min_size, __float_as_uint(fabsf(ct[j])));
+            }
+        }
+    };
+    // how many pass min_size
+    if (threadIdx.x == 0) sh_m = 0;
+    __syncthreads();
+    unsigned mine = 0;
+    sweep([&](unsigned, bool pass, unsigned) { mine += pass ? 1u : 0u; });
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0) atomicAdd(&sh_m, mine);
+    __syncthreads();
+    const unsigned m = sh_m;
+    unsigned cutoff = 0;   // key threshold; 0 keeps everything that passes
+    if (m > n_keep) {
+        // radix select, most significant byte first: rank n_keep (0-based) in descending key order
+        unsigned prefix = 0, rank = n_keep;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int b = threadIdx.x; b < 256; b += 1024) hist[b] = 0;
+            __syncthreads();
+            const unsigned mask = shift == 24 ? 0u : 0xFFFFFFFFu << (shift + 8);
+            sweep([&](unsigned, bool pass, unsigned k) {
+                if (pass && (k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+            });
+            __syncthreads();
+            // the bin holding the wanted rank, walking down from byte value 255: threads 0..255 take bins 255..0,
+            // prefix sums over them locate it in parallel
+            {
+                const unsigned c = threadIdx.x < 256 ? hist[255 - threadIdx.x] : 0u;   // waves 4..15 carry zeros
+                unsigned incl = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned t = __shfl_up(incl, o);
+                    if (lane >= o) incl += t;
+                }
+                if (lane == 63) ws[wave] = incl;
+                __syncthreads();
+                unsigned before = 0;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) before += v < wave ? ws[v] : 0u;
+                const unsigned excl = before + incl - c;
+                if (c != 0 && rank >= excl && rank < excl + c) {
+                    sh_prefix = prefix | ((255u - threadIdx.x) << shift);
+                    sh_rank = rank - excl;
+                }
+            }
+            __syncthreads();
+            prefix = sh_prefix;
+            rank = sh_rank;
+            __syncthreads();
+        }
+        cutoff = prefix;
+    }
+    // ordered compaction of {passes && key >= cutoff}, first n_keep
+    unsigned base = 0;
+    for (unsigned chunk = lo; chunk < hi && base < n_keep; chunk += 1024) {
+        const unsigned i = chunk + threadIdx.x;
+        const bool take = i < hi && extrema[(size_t)i * 4 + 2] >= min_size &&
+                          __float_as_uint(fabsf(extrema[(size_t)i * 4 + 3])) >= cutoff;
+        const unsigned long long bm = __ballot(take);
+        if (lane == 0) ws[wave] = (unsigned)__popcll(bm);
+        __syncthreads();
+        unsigned before = 0, all = 0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const unsigned t = ws[v];
+            before += v < wave ? t : 0u;
+            all += t;
+        }
+        const unsigned o = base + before + (unsigned)__popcll(bm & ((1ull << lane) - 1ull));
+        if (take && o < n_keep) {
+            const size_t dst = (size_t)f * n_keep + o;
+            *reinterpret_cast<f32x4 *>(out + dst * 4) = *reinterpret_cast<const f32x4 *>(extrema + (size_t)i * 4);
+            if (out_index) out_index[dst] = i - lo;
+        }
+        base += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out_count[f] = base < n_keep ? base : n_keep;
+        if (out_count64 && f == 0) out_count64[0] = base < n_keep ? base : n_keep;
+    }
+}
+
+// The same selection for ONE long list (a 4K frame yields tens of thousands of extrema), spread over the chip: per
+// radix byte one histogram launch over all workgroups and one 256-thread launch that picks the bin, then the ordered
+// compaction in the three-launch form.  work (u32): [0,256) histogram, [256] prefix, [257] rank, [258] done,
+// [259] cutoff key, [264,268) two u64 totals, [272...) sums of the compaction.
+constexpr int kTopkState = 256, kTopkTotals = 264, kTopkSums = 272;
+
+__global__ void topk_init(unsigned *__restrict__ work, unsigned n_keep) {
+    work[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        work[kTopkState + 0] = 0;        // prefix
+        work[kTopkState + 1] = n_keep;   // rank wanted (0-based, descending)
+        work[kTopkState + 2] = 0;        // done: every blob that passes min_size is kept
+        work[kTopkState + 3] = 0;        // cutoff key
+    }
+}
+
+__global__ __launch_bounds__(1024) void topk_hist(const float *__restrict__ extrema, const unsigned long long *__restrict__ n_in,
+                                                  unsigned long long n_host, float min_size, int shift,
+                                                  unsigned *__restrict__ work) {
+    __shared__ unsigned lh[16][256];   // one histogram per wave: lanes of different waves never collide
+    if (work[kTopkState + 2]) return;
+    const unsigned n = (unsigned)(n_in ? n_in[0] : n_host);
+    const unsigned prefix = work[kTopkState + 0];
+    const unsigned mask = shift == 24 ? 0u : 0xFFFFFFFFu << (shift + 8);
+    const int wave = threadIdx.x >> 6;
+    for (int b = threadIdx.x; b < 16 * 256; b += 1024) (&lh[0][0])[b] = 0;
+    __syncthreads();
+    float sz[4], ct[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned i = blockIdx.x * 4096u + threadIdx.x + 1024u * j;
+        sz[j] = i < n ? extrema[(size_t)i * 4 + 2] : 0.f;
+        ct[j] = i < n ? extrema[(size_t)i * 4 + 3] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned i = blockIdx.x * 4096u + threadIdx.x + 1024u * j;
+        const unsigned k = __float_as_uint(fabsf(ct[j]));
+        if (i < n && sz[j] >= min_size && (k & mask) == prefix) atomicAdd(&lh[wave][(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        unsigned t = 0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) t += lh[v][threadIdx.x];
+        if (t) atomicAdd(&work[threadIdx.x], t);
+    }
+}
+
+__global__ __launch_bounds__(256) void topk_pick(unsigned *__restrict__ work, unsigned n_keep, int shift) {
+    __shared__ unsigned ws[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool done = work[kTopkState + 2] != 0;
+    const unsigned prefix = work[kTopkState + 0], rank = work[kTopkState + 1];
+    const unsigned c = work[255 - threadIdx.x];   // thread t takes bin 255 - t: prefix sums walk down from the top
+    unsigned incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    unsigned before = 0, all = 0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        before += v < wave ? ws[v] : 0u;
+        all += ws[v];
+    }
+    const unsigned excl = before + incl - c;
+    work[threadIdx.x] = 0;   // histogram ready for the next byte
+    if (done) return;
+    if (shift == 24 && all <= n_keep) {   // the first histogram counts everything that passes min_size
+        if (threadIdx.x == 0) { work[kTopkState + 2] = 1; work[kTopkState + 3] = 0; }
+        return;
+    }
+    if (c != 0 && rank >= excl && rank < excl + c) {
+        const unsigned np = prefix | ((255u - threadIdx.x) << shift);
+        work[kTopkState + 0] = np;
+        work[kTopkState + 1] = rank - excl;
+        if (shift == 0) work[kTopkState + 3] = np;
+    }
+}
+
+// take flags of the compaction: passes min_size and reaches the cutoff key
+__device__ __forceinline__ bool topk_take(const float *__restrict__ extrema, unsigned i, unsigned n, float min_size,
+                                          unsigned cutoff) {
+    return i < n && extrema[(size_t)i * 4 + 2] >= min_size && __float_as_uint(fabsf(extrema[(size_t)i * 4 + 3])) >= cutoff;
+}
+
+__global__ __launch_bounds__(1024) void topk_sums(const float *__restrict__ extrema, const unsigned long long *__restrict__ n_in,
+                                                  unsigned long long n_host, float min_size, unsigned *__restrict__ work) {
+    __shared__ unsigned ws[16];
+    const unsigned n = (unsigned)(n_in ? n_in[0] : n_host);
+    const bool take = topk_take(extrema, blockIdx.x * 1024u + threadIdx.x, n, min_size, work[kTopkState + 3]);
+    const unsigned long long bm = __ballot(take);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = (unsigned)__popcll(bm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int v = 0; v < 16; ++v) t += ws[v];
+        work[kTopkSums + blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void topk_scatter(const float *__restrict__ extrema, const unsigned long long *__restrict__ n_in,
+                                                     unsigned long long n_host, float min_size, unsigned n_keep,
+                                                     const unsigned *__restrict__ work, float *__restrict__ out,
+                                                     unsigned *__restrict__ out_index, unsigned *__restrict__ out_count,
+                                                     unsigned long long *__restrict__ out_count64) {
+    __shared__ unsigned ws[16];
+    const unsigned n = (unsigned)(n_in ? n_in[0] : n_host);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned i = blockIdx.x * 1024u + threadIdx.x;
+    const bool take = topk_take(extrema, i, n, min_size, work[kTopkState + 3]);
+    const unsigned long long bm = __ballot(take);
+    if (lane == 0) ws[wave] = (unsigned)__popcll(bm);
+    __syncthreads();
+    unsigned before = 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) before += v < wave ? ws[v] : 0u;
+    const unsigned o = work[kTopkSums + blockIdx.x] + before + (unsigned)__popcll(bm & ((1ull << lane) - 1ull));
+    if (take && o < n_keep) {
+        *reinterpret_cast<f32x4 *>(out + (size_t)o * 4) = *reinterpret_cast<const f32x4 *>(extrema + (size_t)i * 4);
+        if (out_index) out_index[o] = i;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long kept = *reinterpret_cast<const unsigned long long *>(work + kTopkTotals);
+        out_count[0] = (unsigned)kept;
+        if (out_count64) out_count64[0] = kept;
+    }
+}
+
+void scan_grid(int w, int h, int n_fine, int border, int skip_layers, int &gx, int &gy, int &gz) {
+    gx = w - 2 * border > 0 ? (w - 2 * border + 3) / 4 : 0;
+    gy = h - 2 * border > 0 ? (h - 2 * border + 3) / 4 : 0;
+    gz = n_fine - 2 - skip_layers > 0 ? (n_fine - 2 - skip_layers + 3) / 4 : 0;
+}
+
+// a-trous stack -> ordered extrema of `frames` frames.  slots/counts/sums are scratch sized for frames x cubes.
+void launch_detect_extrema(const float *layer0, long layer0_stride, const float *coarse, long coarse_stride,
+                           long layer_stride, int n_layers, int w, int h, int frames, int border, int skip_layers,
+                           float contrast_threshold, float *slots, unsigned *counts, unsigned *sums, float *extrema,
+                           unsigned *frame_of, unsigned *frame_start, unsigned long long max_out,
+                           unsigned long long *totals, hipStream_t stream) {
+    int gx, gy, gz;
+    scan_grid(w, h, n_layers - 1, border, skip_layers, gx, gy, gz);
+    const long ncubes = (long)gx * gy * gz, n = ncubes * frames;
+    const long nb = (n + 1023) / 1024;
+    if (ncubes > 0) {
+        hipLaunchKernelGGL(scan_extrema, dim3((gx + 7) / 8, (gy + 1) / 2, frames), dim3(256), 0, stream, layer0,
+                           layer0_stride, coarse, coarse_stride, layer_stride, n_layers - 1, w, h, border, skip_layers,
+                           contrast_threshold, gx, gy, gz, slots, counts);
+        hipLaunchKernelGGL(cubes_block_sums, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts, n, sums);
+    }
+    hipLaunchKernelGGL(cubes_scan_sums, dim3(1), dim3(1024), 0, stream, sums, nb, max_out, totals);
+    if (ncubes > 0)
+        hipLaunchKernelGGL(cubes_scatter, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts,
+                           (const float *)slots, (const unsigned *)sums, n, ncubes, extrema, frame_of, frame_start,
+                           max_out);
+}
+
+void launch_topk_filter(const float *extrema, const unsigned *seg_start, const unsigned long long *n_in,
+                        unsigned long long n_host, unsigned n_frames, unsigned seg_cap, unsigned n_keep, float min_size,
+                        float *out, unsigned *out_index, unsigned *out_count, unsigned long long *out_count64,
+                        unsigned long long n_cap, unsigned *work, hipStream_t stream) {
+    // one frame with a long list and scratch to work in: the multi-workgroup form; otherwise one workgroup per frame
+    if (n_frames == 1 && !seg_start && work && n_cap > 8192 && seg_cap >= n_cap) {
+        const unsigned nb4 = (unsigned)((n_cap + 4095) / 4096), nb1 = (unsigned)((n_cap + 1023) / 1024);
+        hipLaunchKernelGGL(topk_init, dim3(1), dim3(256), 0, stream, work, n_keep);
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hipLaunchKernelGGL(topk_hist, dim3(nb4), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, shift, work);
+            hipLaunchKernelGGL(topk_pick, dim3(1), dim3(256), 0, stream, work, n_keep, shift);
+        }
+        hipLaunchKernelGGL(topk_sums, dim3(nb1), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, work);
+        hipLaunchKernelGGL(cubes_scan_sums, dim3(1), dim3(1024), 0, stream, work + kTopkSums, (long)nb1,
+                           (unsigned long long)n_keep, reinterpret_cast<unsigned long long *>(work + kTopkTotals));
+        hipLaunchKernelGGL(topk_scatter, dim3(nb1), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, n_keep,
+                           (const unsigned *)work, out, out_index, out_count, out_count64);
+        return;
+    }
+    hipLaunchKernelGGL(topk_filter, dim3(n_frames), dim3(1024), 0, stream, extrema, seg_start, n_in, n_host, n_frames,
+                       seg_cap, n_keep, min_size, out, out_index, out_count, out_count64);
+}
+
+size_t topk_work_words(unsigned long long n_cap) { return kTopkSums + (size_t)((n_cap + 1023) / 1024) + 2; }
+
+// [frames][n_keep] padded per-frame selections + counts -> one contiguous list with the frame of every entry.
+// totals[0] = entries, totals[1] = extrema the per-frame cap dropped (dropped_blobs summed over the frames).
+__global__ __launch_bounds__(1024) void segments_offsets(const unsigned *__restrict__ counts, unsigned n_frames,
+                                                         const unsigned *__restrict__ seg_start,
+                                                         const unsigned long long *__restrict__ n_total, unsigned seg_cap,
+                                                         unsigned *__restrict__ offsets,
+                                                         unsigned long long *__restrict__ totals) {
+    __shared__ unsigned ws[16];
+    __shared__ unsigned long long dropped;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) dropped = 0;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (unsigned chunk = 0; chunk < n_frames; chunk += 1024) {
+        const unsigned f = chunk + threadIdx.x;
+        const unsigned c = f < n_frames ? counts[f] : 0u;
+        if (f < n_frames) {
+            const unsigned total = (unsigned)n_total[0];
+            const unsigned lo = seg_start[f], hi = f + 1 < n_frames ? seg_start[f + 1] : total;
+            if (hi - lo > seg_cap) atomicAdd(&dropped, (unsigned long long)(hi - lo - seg_cap));
+        }
+        unsigned incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        unsigned before = 0, all = 0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const unsigned t = ws[v];
+            before += v < wave ? t : 0u;
+            all += t;
+        }
+        if (f < n_frames) offsets[f] = (unsigned)(base + before + incl - c);
+        base += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[0] = base;
+        totals[1] = dropped;
+    }
+}
+
+__global__ __launch_bounds__(256) void segments_gather(const float *__restrict__ padded, const unsigned *__restrict__ counts,
+                                                       const unsigned *__restrict__ offsets, unsigned n_keep,
+                                                       float *__restrict__ out, unsigned *__restrict__ frame_of) {
+    const unsigned f = blockIdx.x, c = counts[f], o = offsets[f];
+    for (unsigned i = threadIdx.x; i < c; i += 256) {
+        *reinterpret_cast<f32x4 *>(out + (size_t)(o + i) * 4) =
+            *reinterpret_cast<const f32x4 *>(padded + ((size_t)f * n_keep + i) * 4);
+        frame_of[o + i] = f;
+    }
+}
+
+void launch_segments_compact(const float *padded, const unsigned *counts, const unsigned *seg_start,
+                             const unsigned long long *n_total, unsigned n_frames, unsigned seg_cap, unsigned n_keep,
+                             unsigned *offsets, float *out, unsigned *frame_of, unsigned long long *totals,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(segments_offsets, dim3(1), dim3(1024), 0, stream, counts, n_frames, seg_start, n_total, seg_cap,
+                       offsets, totals);
+    hipLaunchKernelGGL(segments_gather, dim3(n_frames), dim3(256), 0, stream, padded, counts, (const unsigned *)offsets,
+                       n_keep, out, frame_of);
+}
+
+}  // namespace lfmkd

@@ -1,4 +1,5 @@
-// Launch interface between the C ABI (lf_mkd.cpp) and the gfx950 kernels (mkd_device.hip).
+// Launch interface between the C ABI (lf_mkd.cpp) and the gfx950 kernels (mkd_describe.hip, mkd_pyramid.hip,
+// mkd_orient.hip, mkd_detect.hip, mkd_match.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -10,6 +11,8 @@
 #define LF_POOL_F16X3 1
 
 namespace lfmkd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxPyrLevels = 16;
 

@@ -19,7 +19,7 @@ def pytest_configure(config):
     # that a fresh checkout can run the suite without a separate build step (hipcc cross-compiles without a GPU)
     import subprocess
     for target in (os.path.join(ROOT, "local-features_amd"), os.path.join(ROOT, "oracle")):
-        subprocess.check_call(["make", "-s", "-C", target])
+        subprocess.check_call(["make", "-s", "-j8", "-C", target])
 
 
 def rel_l2(a, b):
