@@ -144,6 +144,24 @@ def pipeline_extras(lfp, torch, device):
         ms = e0.elapsed_time(e1) / 3
         out["matcher_65536x65536"] = {"ms": ms, "similarities_per_s": n * n / (ms * 1e-3),
                                       "f16_mfma_pflops": n * n * 128 * 2 * 3 / (ms * 1e-3) / 1e15}
+        del hnd, a, b, mt
+        # patch mode at the keypoint counts of configs[1] and configs[2]: the same describe call, smaller n
+        for n in (10000, 512000):
+            g = torch.Generator(device="cuda").manual_seed(10)
+            p = torch.rand((n, 32, 32), device="cuda", generator=g)
+            o = torch.empty((n, 128), device="cuda")
+            hnd = lfp.MkdHandle(max_features=n, pool_mode=lfp.POOL_F16X3, device=device)
+            for _ in range(3):
+                hnd.describe_patches_device(p.data_ptr(), n, o.data_ptr(), s)
+            side.synchronize()
+            e0.record(side)
+            for _ in range(10):
+                hnd.describe_patches_device(p.data_ptr(), n, o.data_ptr(), s)
+            e1.record(side)
+            side.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            out[f"patch_mode_n{n}"] = {"ms": ms, "descriptors_per_s": n / (ms * 1e-3)}
+            del hnd, p, o
     return out
 
 
