@@ -53,9 +53,10 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
     const int b1 = border > 1 ? border : 1;
     const int ncubes = gx * gy * gz;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int q = wave; q < 16 * gz; q += 4) {   // cube q of this tile: (cube layer, cube row, cube column)
-        const int qz = q >> 4, qy = (q >> 3) & 1, qx = q & 7;
-        const int cx = blockIdx.x * 8 + qx, cy = blockIdx.y * 2 + qy;
+    constexpr int kCX = kScanTX / 4, kCY = kScanTY / 4;   // cubes of a tile per cube layer
+    for (int q = wave; q < kCX * kCY * gz; q += 4) {   // cube q of this tile: (cube layer, cube row, cube column)
+        const int qz = q / (kCX * kCY), qy = (q / kCX) % kCY, qx = q % kCX;
+        const int cx = blockIdx.x * kCX + qx, cy = blockIdx.y * kCY + qy;
         if (cx >= gx || cy >= gy) continue;      // uniform per wave
         const int x = tx0 + qx * 4 + lx, y = ty0 + qy * 4 + ly, z = qz * 4 + lz + 1 + skip_layers;
         const bool inside = !(x < b1 || x >= w - b1 || y < b1 || y >= h - b1 || z <= 0 || z >= n_fine - 1);
@@ -486,7 +487,8 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, const float 
     const long ncubes = (long)gx * gy * gz, n = ncubes * frames;
     const long nb = (n + 1023) / 1024;
     if (ncubes > 0) {
-        hipLaunchKernelGGL(scan_extrema, dim3((gx + 7) / 8, (gy + 1) / 2, frames), dim3(256), 0, stream, layer0,
+        hipLaunchKernelGGL(scan_extrema, dim3((gx + kScanTX / 4 - 1) / (kScanTX / 4), (gy + kScanTY / 4 - 1) / (kScanTY / 4), frames),
+                           dim3(256), 0, stream, layer0,
                            layer0_stride, coarse, coarse_stride, layer_stride, n_layers - 1, w, h, border, skip_layers,
                            contrast_threshold, gx, gy, gz, slots, counts);
         hipLaunchKernelGGL(cubes_block_sums, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts, n, sums);
