@@ -64,6 +64,13 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
         const int c = (inside ? z : 1) * kScanPlane + (qy * 4 + ly + 1) * kScanRowLen + (qx * 4 + lx + 1);
         auto at = [&](int dz, int dy, int dx) { return s_dog[c + dz * kScanPlane + dy * kScanRowLen + dx]; };
         const float val = s_dog[c];
+        // a candidate needs |val| above the contrast threshold (line 95): a cube without such a voxel -- most cubes of a
+        // natural image -- is done after this one read per lane
+        const bool hot = inside && fabsf(val) > contrast_threshold;
+        if (__ballot(hot) == 0ull) {   // uniform
+            if (lane == 0) counts[(size_t)f * ncubes + ((size_t)qz * gy + cy) * gx + cx] = 0u;
+            continue;
+        }
         // sign(val) val >= sign(val) neighbour for all 26 neighbours (lines 97-124)  <=>  val >= their maximum when
         // val > 0, val <= their minimum when val < 0 (multiplying by +-1 is exact): 13 max3 + 13 min3 instead of 26
         // multiply-compare-and chains, and no divergence
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
                         nmax = fmaxf(nmax, v);
                         nmin = fminf(nmin, v);
                     }
-        const bool cand = inside && fabsf(val) > contrast_threshold && (val > 0.f ? val >= nmax : val <= nmin);
+        const bool cand = hot && (val > 0.f ? val >= nmax : val <= nmin);
         const unsigned long long cm = __ballot(cand);
         bool emit = false;
         float ox = 0.f, oy = 0.f, size = 0.f, contrast = 0.f;
