@@ -3,9 +3,15 @@
 
 A "step" is one pass of the describe path (lf_mkd_describe_patches_device through the C ABI) over one
 batch of synthetic 32x32 f32 patches already resident in HBM.  Default workload: 2^20 patches per GPU
-(the per-GPU share of BASELINE.json configs[3]; SURVEY.md 8(d) headline "patch mode").  For N > 1 the
-driver launches one process per GPU (torch.distributed, backend nccl = RCCL); patches shard by rank
-with no data-path collective, so scaling is "weak".
+(the per-GPU share of BASELINE.json configs[3]; SURVEY.md 8(d) headline "patch mode").  For N > 1 there is one
+process per GPU (torch.distributed, backend nccl = RCCL): either the driver starts them (torch.distributed.run sets
+WORLD_SIZE) or, when `--gpus N` is given without that environment, this script starts them itself before it touches
+the GPU.  Patches shard by rank with no data-path collective, so scaling is "weak".
+
+After the timed describe steps every rank runs the rest of configs[3] once on the descriptors it just produced, and
+rank 0 reports it under "match_stage": the all-gather of the descriptor shards (the path's one collective; both the
+point-to-point form and RCCL's ring) and the cross-image brute-force match of the rank's own descriptors against the
+gathered set.
 
 Extra objects on the line:
   roofline      the describe kernel (mkd_pool: blur .. whitening .. L2 fused in one launch) vs the
@@ -165,6 +171,84 @@ def pipeline_extras(lfp, torch, device):
     return out
 
 
+def launch_ranks(n):
+    """`bench.py --gpus N` without a launcher's environment: start the N ranks here, as children of a parent that never
+    touches the GPU (a process that has initialised HIP must not be replaced or forked), and pass on their exit code."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehearsal, gathered, out, n):
+    """configs[3] after the describe: descriptor shards -> all-gather -> cross-image brute-force match, once, timed.
+    Every rank's `out` is already its own view of `gathered` (the describe wrote there), so the gather copies nothing
+    locally.  Images: --kpts-per-image descriptors each, in storage order; a query never matches its own image."""
+    per_img = max(2, min(args.kpts_per_image, n))
+    sizes = [per_img] * (n // per_img) + ([n % per_img] if n % per_img else [])
+    counts = [n] * world
+    res = {"ranks_seen": world, "descriptors_per_rank": n, "keypoints_per_image": per_img,
+           "gathered_bytes": world * n * 512, "received_bytes_per_rank": (world - 1) * n * 512}
+
+    def timed(fn):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return sharding.max_over_ranks(time.perf_counter() - t0, "cpu" if rehearsal else "cuda") * 1e3
+
+    if world > 1:
+        for mode in ("direct", "ring"):
+            run = lambda: sharding.all_gather_descriptors(out, mode=mode, out=gathered, counts=counts)
+            run()                                                       # first call sets up the communicator's channels
+            res[f"allgather_{mode}_ms"] = min(timed(run) for _ in range(3))
+            res[f"allgather_{mode}_gbs_per_rank"] = res["received_bytes_per_rank"] / res[f"allgather_{mode}_ms"] / 1e6
+        res["allgather_ms"] = min(res["allgather_direct_ms"], res["allgather_ring_ms"])
+        # every shard must have arrived: row norms of the whole gathered set are 1
+        nrm = gathered.norm(dim=1)
+        if not bool(((nrm - 1).abs() < 1e-4).all().item()):
+            raise SystemExit("bench.py: gathered descriptors are not all unit norm (a shard did not arrive)")
+    else:
+        res["allgather_ms"] = 0.0
+    hm = lfp.MkdHandle(max_features=64, device=local_rank)
+    lo, hi = sharding.exclusion_ranges(sizes, rank * n, "cuda")
+    m = torch.empty((n,), dtype=torch.int32, device="cuda")
+    best = torch.empty((n,), device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    run = lambda: hm.match_device(out.data_ptr(), n, gathered.data_ptr(), world * n, m.data_ptr(), 0.8, lo.data_ptr(),
+                                  hi.data_ptr(), best.data_ptr(), None, s)
+    if n * world <= 1 << 18:
+        run()                                                           # warm (small problems only: the big one is seconds)
+    res["match_ms"] = timed(run)
+    res["similarities_per_s"] = float(n) * n * world * world / (res["match_ms"] * 1e-3)
+    # accepted matches point outside the query's own image, and every best similarity is a valid cosine
+    acc = m >= 0
+    bad = acc & (m >= lo) & (m < hi)
+    if bool(bad.any().item()) or not bool((best.abs() <= 1.0 + 1e-4).all().item()):
+        raise SystemExit("bench.py: cross-image match returned a candidate inside the query's own image")
+    res["accepted_fraction"] = float(acc.float().mean().item())
+    res["what"] = ("each rank: its descriptors x the gathered set, own image excluded, ratio 0.8 "
+                   "(examples/match_images/src/main.rs:8-27); ms = slowest rank")
+    return res
+
+
+def source_stamp():
+    """What the traffic counters in profiles/traffic_latest.json were measured on: sha256 of the describe kernel's source."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in ("mkd_describe.hip", "mkd_device.h"):
+        hsh.update(open(os.path.join(ROOT, "local-features_amd", "csrc", f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,7 +259,13 @@ def main():
     ap.add_argument("--pool", choices=["f32", "f16x3"], default=os.environ.get("LF_MKD_POOL", "f16x3"))
     ap.add_argument("--cpu-sample", type=int, default=-1, help="patches for the CPU baseline (0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary pipeline figures")
+    ap.add_argument("--no-match", action="store_true", help="skip the all-gather + cross-image match stage")
+    ap.add_argument("--kpts-per-image", type=int, default=8192, help="descriptors per image in the match stage "
+                    "(configs[3]: 8M keypoints over 1024 frames)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))       # nothing has touched the GPU yet in this process
 
     import torch
     import local_features_python as lfp
@@ -183,7 +273,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(args.gpus, 1) and world > 1:
+    if world != max(args.gpus, 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the describe path has no CPU fallback")
@@ -205,7 +295,9 @@ def main():
     n = args.patches
     gen = torch.Generator(device="cuda").manual_seed(0x4D4B44 + rank)
     patches = torch.rand((n, 32, 32), device="cuda", generator=gen)
-    out = torch.empty((n, 128), device="cuda")
+    from local_features_python import sharding
+    # the descriptors are written straight into this rank's rows of the buffer the match stage gathers into
+    gathered, out = sharding.gathered_buffer([n] * world, rank)
     h = lfp.MkdHandle(pca="liberty", max_features=n, device=local_rank,
                       angle_mode={"shader": lfp.ANGLE_SHADER, "exact": lfp.ANGLE_EXACT,
                                   "exact_zero": lfp.ANGLE_EXACT_ZERO}[args.angle],
@@ -232,16 +324,13 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     pool_ms, whiten_ms, launches = h.kernel_times()
-    from local_features_python import sharding
     dt = sharding.max_over_ranks(dt, "cpu" if rehearsal else "cuda")
 
     # secondary figure: the same workload with the exact gradient direction (plus the shader's angle 0 at gx == 0)
     # instead of the shader's polynomial atan2: LF_MKD_ANGLE_EXACT_ZERO, within 1e-4 of the shader reference on every
     # patch (tests/test_gpu_parity.py) -- the headline stays on the most faithful mode
-    alt = None
-    if world == 1 and args.angle == "shader":
-        h2 = lfp.MkdHandle(pca="liberty", max_features=n, device=local_rank, angle_mode=lfp.ANGLE_EXACT_ZERO,
-                           pool_mode=lfp.POOL_F32 if args.pool == "f32" else lfp.POOL_F16X3)
+    def side_figure(angle_mode, pool_mode):
+        h2 = lfp.MkdHandle(pca="liberty", max_features=n, device=local_rank, angle_mode=angle_mode, pool_mode=pool_mode)
         out2 = torch.empty_like(out)
         for _ in range(2):
             h2.describe_patches_device(patches.data_ptr(), n, out2.data_ptr(), stream)
@@ -250,8 +339,13 @@ def main():
         for _ in range(args.steps):
             h2.describe_patches_device(patches.data_ptr(), n, out2.data_ptr(), stream)
         torch.cuda.synchronize()
-        alt = n * args.steps / (time.perf_counter() - t1)
-        del out2
+        return n * args.steps / (time.perf_counter() - t1)
+
+    alt = alt_f32 = None
+    if world == 1 and args.angle == "shader" and args.pool == "f16x3":
+        alt = side_figure(lfp.ANGLE_EXACT_ZERO, lfp.POOL_F16X3)
+        # the same workload with the pooling contraction in exact f32 arithmetic (LF_MKD_POOL_F32, the verification mode)
+        alt_f32 = side_figure(lfp.ANGLE_SHADER, lfp.POOL_F32)
 
     # sanity on the timed output: finite, unit norm (a wrong-but-fast kernel must not pass silently)
     nrm = out.norm(dim=1)
@@ -259,16 +353,29 @@ def main():
     if not ok:
         raise SystemExit("bench.py: descriptors are not finite / unit norm")
 
+    # configs[3]'s second half on the descriptors just produced: every rank takes part (the all-gather is collective)
+    stage = None
+    if not args.no_match:
+        try:
+            stage = match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehearsal, gathered, out, n)
+        except SystemExit:
+            raise
+        except Exception as e:           # reported, not fatal: the headline is the describe figure
+            stage = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         total = n * world * args.steps
         kern_s = pool_ms / 1e3 / max(launches, 1)
         achieved = BYTES_PER_DESC * n / kern_s / 1e9 if kern_s > 0 else 0.0
+        # HBM traffic of the kernel comes from rocprofv3 PMC passes (tools/profile_round.sh), which cannot run inside
+        # this process: the committed figure is quoted only if it was measured on this very kernel source and workload
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("patches") == n and tj.get("pool") == args.pool:
+                if (tj.get("patches") == n and tj.get("pool") == args.pool and tj.get("angle") == args.angle
+                        and tj.get("source_sha256") == source_stamp()):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -281,15 +388,17 @@ def main():
             "config": {"workload": f"patch mode: {n} uniform-random 32x32 f32 patches per GPU resident in HBM "
                                    "(per-GPU share of BASELINE configs[3]; SURVEY 8(d) headline), PCA=liberty",
                        "patches_per_gpu": n, "angle_mode": args.angle, "pool_mode": args.pool,
-                       "parallelism": f"shard-by-rank x{world}, no collective"},
+                       "parallelism": f"shard-by-rank x{world}, no collective in the describe path"},
             "exact_zero_angle_mode_value": alt,
+            "f32_pool_mode_value": alt_f32,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mkd_pool", "kernel_ms": kern_s * 1e3,
                          "algorithmic_bytes_per_launch": BYTES_PER_DESC * n},
+            "match_stage": stage,
         }
         if world == 1 and not args.no_extras:
-            del patches, out
+            del patches, out, gathered
             torch.cuda.empty_cache()
             try:
                 line["pipelines"] = pipeline_extras(lfp, torch, local_rank)

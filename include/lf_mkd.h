@@ -50,10 +50,13 @@ typedef enum { LF_MKD_PCA_LIBERTY = 0, LF_MKD_PCA_NOTREDAME = 1, LF_MKD_PCA_YOSE
 typedef enum { LF_MKD_ANGLE_SHADER = 0, LF_MKD_ANGLE_EXACT = 1, LF_MKD_ANGLE_EXACT_ZERO = 2 } lf_mkd_angle_mode;
 
 /* Arithmetic of the pooling contraction (1024 px x 7 in-dims x 34 kernels per patch).
- * F32     : v_mfma_f32_16x16x4_f32, bit-for-bit an f32 fma chain.
  * F16X3   : operands split into f16 hi+lo, three f16 MFMAs per product (hi*hi, hi*lo, lo*hi),
- *           f32 accumulate; ~2^-21 relative per product. */
-typedef enum { LF_MKD_POOL_F32 = 0, LF_MKD_POOL_F16X3 = 1 } lf_mkd_pool_mode;
+ *           f32 accumulate; ~2^-21 relative per product -- descriptors within 1e-5 relative L2 of the f32
+ *           formulation (gate 1e-4).  THE DEFAULT (a zero-initialised lf_mkd_params selects it): ~250 M
+ *           descriptors/s per MI355X in patch mode.
+ * F32     : v_mfma_f32_16x16x4_f32, bit-for-bit an f32 fma chain; the verification mode, bound by the f32 MFMA
+ *           rate at ~117 M descriptors/s (2.1x slower). */
+typedef enum { LF_MKD_POOL_DEFAULT = 0, LF_MKD_POOL_F16X3 = 1, LF_MKD_POOL_F32 = 2 } lf_mkd_pool_mode;
 
 /* lf_mkd_params.flags */
 #define LF_MKD_FLAG_KERNEL_TIMING 1u /* bracket every kernel launch with HIP events on its stream;
@@ -70,7 +73,7 @@ typedef struct {
     float patch_scale_factor;   /* FeatureDetectParams.patch_scale_factor (default 24)         */
     int32_t device;             /* HIP device ordinal                                          */
     int32_t angle_mode;         /* lf_mkd_angle_mode                                           */
-    int32_t pool_mode;          /* lf_mkd_pool_mode                                            */
+    int32_t pool_mode;          /* lf_mkd_pool_mode (0 = LF_MKD_POOL_F16X3)                    */
     uint32_t flags;             /* LF_MKD_FLAG_*                                               */
     uint32_t max_frames;        /* frames of max_image_* size the pyramid store holds for the
                                    multi-frame entry points (default 1)                         */
@@ -228,7 +231,9 @@ int lf_mkd_detect_frames_device(lf_mkd *h, const float *d_images, uint32_t n_fra
  * [0] extrema found (capped at max_blobs), [1] dropped_blobs, [2] extrema after the top_n filter,
  * [3] keypoints written (valid rows of the two outputs), [4] dropped_features.
  * lf_mkd_stream_frame launches the graph on `stream` (NULL: the handle's stream), asynchronously.
- * One stream pipeline per handle; creating another replaces it. */
+ * One stream pipeline per handle; creating another replaces it.  Creating one also discards the frame loaded by
+ * lf_mkd_set_image*: until the first lf_mkd_stream_frame the keypoint, orientation and verification entry points return
+ * LF_MKD_ERR_NO_IMAGE; after it they see the frame the pipeline last processed (on the stream it was launched on). */
 int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t top_n, float min_size,
                          uint64_t max_out, const float *d_image, lf_mkd_keypoint *d_keypoints,
                          float *d_descriptors, uint64_t *d_counts);

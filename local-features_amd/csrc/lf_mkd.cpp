@@ -54,6 +54,7 @@ struct lf_mkd {
     // graph-captured per-frame pipeline (lf_mkd_stream_*)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    PyramidDesc graph_pd{};     // frame geometry the recorded pipeline was captured for
     float *d_stream_patches = nullptr;
     uint64_t stream_patch_cap = 0;
     // matcher scratch
@@ -126,6 +127,17 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     if (!h) return LF_MKD_ERR_BAD_ARG;
     h->params = *params;
     if (h->params.patch_scale_factor == 0.f) h->params.patch_scale_factor = 24.f;  // lib.rs:46
+    if (h->params.pool_mode == LF_MKD_POOL_DEFAULT) h->params.pool_mode = LF_MKD_POOL_F16X3;
+    if (h->params.pool_mode != LF_MKD_POOL_F16X3 && h->params.pool_mode != LF_MKD_POOL_F32) {
+        g_create_error = "pool_mode must be LF_MKD_POOL_DEFAULT, LF_MKD_POOL_F16X3 or LF_MKD_POOL_F32";
+        delete h;
+        return LF_MKD_ERR_BAD_ARG;
+    }
+    if (h->params.angle_mode < LF_MKD_ANGLE_SHADER || h->params.angle_mode > LF_MKD_ANGLE_EXACT_ZERO) {
+        g_create_error = "angle_mode must be one of lf_mkd_angle_mode";
+        delete h;
+        return LF_MKD_ERR_BAD_ARG;
+    }
     const uint64_t mf = params->max_features ? params->max_features : 2000;        // lib.rs:69
     h->n_layers = int(params->n_scales ? params->n_scales : 4) + 3;                // lib.rs:70, mod.rs:1093
     if (h->n_layers - 1 > 8) {   // the extremum scan keeps at most 8 DoG layers of a tile in LDS
@@ -772,12 +784,14 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
         return fail(h, LF_MKD_ERR_BAD_ARG, "stream_create: frame exceeds max_image_width/height given at creation");
     LF_HIP(h, hipSetDevice(h->params.device));
     LF_HIP(h, hipStreamSynchronize(h->stream));
-    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    retire_graph(h);   // an earlier recording may still be running on a caller's stream
     // every allocation happens before the capture starts
     describe_pyramid(width, height, h->pd);
     h->n_frames = 1;
-    h->have_image = true;
+    // no frame has gone through the recorded pipeline yet: until lf_mkd_stream_frame runs, the pyramid and the a-trous
+    // stack hold nothing the keypoint / orientation / verification entry points could use
+    h->have_image = false;
+    h->coarse_valid = h->coarse_l1_valid = false;
     if (!h->d_coarse) {
         h->layer_stride = long(h->params.max_image_width) * h->params.max_image_height;
         h->coarse_stride = h->layer_stride * (h->n_layers - 1);
@@ -826,8 +840,7 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
         return LF_MKD_ERR_HIP;
     }
     LF_HIP(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
-    h->coarse_valid = true;      // every launch rebuilds the stack of the frame in d_image
-    h->coarse_l1_valid = true;
+    h->graph_pd = h->pd;
     return LF_MKD_OK;
 }
 
@@ -838,6 +851,11 @@ int lf_mkd_stream_frame(lf_mkd *h, void *stream) {
                                            "grew the handle's scratch buffers retires an earlier recording)");
     LF_HIP(h, hipSetDevice(h->params.device));
     LF_HIP(h, hipGraphLaunch(h->graph_exec, stream ? static_cast<hipStream_t>(stream) : h->stream));
+    // every launch rebuilds the pyramid and the a-trous stack of the frame in d_image: work enqueued behind it on the same
+    // stream (describe_keypoints, orientation, the verification taps) sees that frame
+    h->pd = h->graph_pd;
+    h->n_frames = 1;
+    h->have_image = h->coarse_valid = h->coarse_l1_valid = true;
     return LF_MKD_OK;
 }
 

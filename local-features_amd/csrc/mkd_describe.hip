@@ -56,14 +56,30 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, void *ldst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
                                      (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
 }
+// (uniform base) + (32-bit lane offset).  The base goes through an opaque SGPR constraint so that hipcc cannot
+// re-associate it with the lane offset into a per-lane 64-bit base plus a uniform offset (which it then hoists).
+__device__ __forceinline__ void lds_dma16_sv(const unsigned char *uniform_base, unsigned lane_off, void *ldst) {
+    asm("" : "+s"(uniform_base));
+    // volatile: keeps the 32-bit offset's zero-extension in the basic block of its use, where instruction selection can
+    // fold it into the addressing mode (hoisted out of the row loop it becomes a 64-bit VGPR pair and an add per request)
+    asm volatile("" : "+v"(lane_off));
+    lds_dma16(uniform_base + lane_off, ldst);
+}
 
+// Global addresses of the DMA requests are formed as (wave-uniform 64-bit base) + (32-bit lane offset), in that order:
+// hipcc then selects the SGPR-base form `global_load_lds_dwordx4 v_off, s[base:base+1]`, which costs no 64-bit VALU add and
+// no VGPR pair per request (written as per-lane pointer + uniform offset, every request carried its own v_lshl_add_u64
+// and the hoisted address pairs were spilled).
 // one LUT row (24 pieces) into an LDS row buffer, 24 / W pieces per wave
 template <int W>
 __device__ __forceinline__ void issue_lut_row(const unsigned char *__restrict__ lut_rows, int row,
                                               unsigned char *lds_row, int wave, int lane) {
-    const unsigned char *g = lut_rows + (size_t)row * kRowBytes + lane * 16;
+    const unsigned lane16 = (unsigned)lane * 16u;
 #pragma unroll
-    for (int j = 0; j < 24 / W; ++j) lds_dma16(g + (wave + W * j) * 1024, lds_row + (wave + W * j) * 1024);
+    for (int j = 0; j < 24 / W; ++j) {
+        const unsigned char *g = lut_rows + ((size_t)row * kRowBytes + (size_t)(wave + W * j) * 1024);   // uniform
+        lds_dma16_sv(g, lane16, lds_row + (wave + W * j) * 1024);
+    }
 }
 
 // Whitening fragments are staged through the two LUT row buffers (idle during the epilogue) one 16 KiB step at a
@@ -77,20 +93,30 @@ static_assert(wstage_slot(0) + kWStepBytes <= kRowBytes && wstage_slot(10) >= kR
 template <int W>
 __device__ __forceinline__ void issue_w_step(const unsigned char *__restrict__ wfrag, int step, unsigned char *lds,
                                              int wave, int lane) {
-    const unsigned char *g = wfrag + (size_t)step * kWStepBytes + lane * 16;
+    const unsigned lane16 = (unsigned)lane * 16u;
     unsigned char *d = lds + wstage_slot(step);
 #pragma unroll
-    for (int j = 0; j < 16 / W; ++j) lds_dma16(g + (wave + W * j) * 1024, d + (wave + W * j) * 1024);
+    for (int j = 0; j < 16 / W; ++j) {
+        const unsigned char *g = wfrag + ((size_t)step * kWStepBytes + (size_t)(wave + W * j) * 1024);   // uniform
+        lds_dma16_sv(g, lane16, d + (wave + W * j) * 1024);
+    }
 }
 
+// Counted wait on the vector-memory counter.  INVARIANT: between the DMA requests this counts and the wait itself, the
+// wave must issue no other vector-memory instruction -- in particular no scratch spill: spill stores share vmcnt and retire
+// out of order with respect to loads, so one in flight lets the wait pass before the counted DMA has landed.  hipcc
+// inserts spills on its own when registers run out; the Makefile therefore rejects an f16 build of this kernel whose
+// ScratchSize is not 0 (tools/check_scratch.py), and the raw_out verification tap, which stores, waits with vmcnt(0).
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// one raw patch row (16 patches x 128 B) of this wave into ring slot `slot`; rows outside [0,31] replicate
-__device__ __forceinline__ void issue_raw_row(const float *__restrict__ src_lane, int row, unsigned char *ring,
-                                              int slot) {
+// one raw patch row (16 patches x 128 B) of this wave into ring slot `slot`; rows outside [0,31] replicate.
+// src = the wave's (uniform) first patch, lane_off = byte offset of the lane's patch and 16-byte chunk from it.
+struct RawSrc { const unsigned char *base; unsigned lane_off; };
+__device__ __forceinline__ void issue_raw_row(const RawSrc &src, int row, unsigned char *ring, int slot) {
     const int y = row < 0 ? 0 : (row > 31 ? 31 : row);
-    lds_dma16(src_lane + y * 32, ring + slot * 2048);
-    lds_dma16(src_lane + y * 32 + 16, ring + slot * 2048 + 1024);
+    const unsigned char *g = src.base + y * 128;   // uniform
+    lds_dma16_sv(g, src.lane_off, ring + slot * 2048);
+    lds_dma16_sv(g + 64, src.lane_off, ring + slot * 2048 + 1024);
 }
 
 // No implicit contraction in the describe kernel (down to the end of mkd_pool): every fused multiply-add in it is written
@@ -546,16 +572,17 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
     // chunk q of its patch's half-row; the reader (p, q) needs chunks 2(q&1), 2(q&1)+1 of half q>>1.
     const unsigned char *ring_lane = ring + (q >> 1) * 1024 + ((2 * (q & 1)) * 16 + p) * 16;
 
-    auto lane_src = [&](long batch) {
-        const long b0 = batch * (16 * W) + wave * 16;
-        const long pidx = (b0 + p < n) ? b0 + p : n - 1;  // tail lanes recompute the last patch
-        return patches + pidx * 1024 + 4 * q;
-    };
-
     long batch = blockIdx.x;
     if (batch >= nbatch) return;
+    // lanes beyond the last patch recompute it: the wave's base is clamped the same way, so lane offsets stay >= 0
+    auto raw_src = [&](const float *pt, long b) {
+        const long b0 = b * (16 * W) + wave * 16;
+        const long wave0 = b0 < n ? b0 : n - 1;                 // uniform
+        const long pidx = b0 + p < n ? b0 + p : n - 1;
+        return RawSrc{reinterpret_cast<const unsigned char *>(pt + wave0 * 1024), (unsigned)(pidx - wave0) * 4096u + 16u * q};
+    };
     {
-        const float *src = lane_src(batch);
+        const RawSrc src = raw_src(patches, batch);
 #pragma unroll
         for (int r = -2; r <= 3; ++r) issue_raw_row(src, r, ring, r + 2);
         issue_lut_row<W>(lut_rows, 0, s_mem, wave, lane);
@@ -566,10 +593,21 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
 #endif
 
     for (; batch < nbatch; batch += gridDim.x) {
+        // Launder the (uniform) table and buffer pointers once per batch.  Otherwise hipcc hoists one 64-bit per-lane VGPR
+        // address per DMA / fragment load / store out of the batch loop and spills them (1.4 KB per lane for the
+        // whitening fragments alone).  Spills matter beyond their cost here: scratch loads and stores count on vmcnt
+        // like the LDS-DMA requests, stores retire out of order with respect to loads, and the f16 epilogue waits for its
+        // DMA steps with COUNTED waits (wait_vmcnt<kDma>) -- a scratch store in flight there would let a wait pass
+        // before its DMA has landed.  The Makefile fails the build if an f16 instantiation of this kernel uses scratch.
+        const unsigned char *wf = wfrag, *lr = lut_rows;
+        const float *bs = bias, *pt = patches;
+        float *o = out, *ro = raw_out;
+        const short *cm = colmap;
+        asm volatile("" : "+s"(wf), "+s"(bs), "+s"(lr), "+s"(o), "+s"(ro), "+s"(cm), "+s"(pt));
         const long base = batch * (16 * W) + wave * 16;
-        const float *src = lane_src(batch);
+        const RawSrc src = raw_src(pt, batch);
         const bool more = batch + gridDim.x < nbatch;
-        const float *src_next = more ? lane_src(batch + gridDim.x) : src;
+        const RawSrc src_next = more ? raw_src(pt, batch + gridDim.x) : src;
 
         f32x4 acc[kTiles];
 #pragma unroll
@@ -594,9 +632,9 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
             const unsigned char *brow = s_mem + par * kRowBytes + lane * 16;
             // row buffer par ^ 1 is free: next LUT row; during row 31 the f16 epilogue's first whitening step instead
             if (POOL == LF_POOL_F16X3 ? !kLast : (!kLast || more))
-                issue_lut_row<W>(lut_rows, (g + 1) & 31, s_mem + (par ^ 1) * kRowBytes, wave, lane);
+                issue_lut_row<W>(lr, (g + 1) & 31, s_mem + (par ^ 1) * kRowBytes, wave, lane);
             else if (POOL == LF_POOL_F16X3)
-                issue_w_step<W>(wfrag, 0, s_mem, wave, lane);
+                issue_w_step<W>(wf, 0, s_mem, wave, lane);
             par ^= 1;
             BFrag bm[3] = {load_b<0>(brow), load_b<1>(brow), load_b<2>(brow)};   // m-stream fragments
 
@@ -695,18 +733,12 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
 #pragma unroll 1
         for (int g = 1; g < 31; ++g) patch_row(std::integral_constant<int, 1>(), g);
         patch_row(std::integral_constant<int, 2>(), 31);
-        // launder the (uniform) table pointers once per batch: otherwise hipcc hoists one 64-bit VGPR address per
-        // whitening-fragment load out of the batch loop and spills 1.4 KB of them per lane
-        const unsigned char *wf = wfrag;
-        const float *bs = bias;
-        asm volatile("" : "+s"(wf), "+s"(bs));
 #ifdef LF_ABLATE_EPILOGUE  // timing-only build
         { f32x4 sum = acc[0]; for (int t = 1; t < kTiles; ++t) sum += acc[t];
           if (base + p < n) *reinterpret_cast<f32x4 *>(out + (base + p) * 128 + 4 * q) = sum;
-          if (POOL == LF_POOL_F16X3) { __syncthreads(); if (more) issue_lut_row<W>(lut_rows, 0, s_mem, wave, lane); } }
+          if (POOL == LF_POOL_F16X3) { __syncthreads(); if (more) issue_lut_row<W>(lr, 0, s_mem, wave, lane); } }
 #else
-        finish_descriptors<POOL, W>(acc, lane, wave, base + p < n, base + p, colmap, wf, bs, out, raw_out, s_mem, lut_rows,
-                                    more);
+        finish_descriptors<POOL, W>(acc, lane, wave, base + p < n, base + p, cm, wf, bs, o, ro, s_mem, lr, more);
 #endif
         LF_PT(6);
     }

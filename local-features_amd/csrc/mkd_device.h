@@ -7,8 +7,8 @@
 #define LF_ANGLE_SHADER 0
 #define LF_ANGLE_EXACT 1
 #define LF_ANGLE_EXACT_ZERO 2   // exact direction, but angle 0 where gx == 0 like the shader
-#define LF_POOL_F32 0
-#define LF_POOL_F16X3 1
+#define LF_POOL_F16X3 1         // = LF_MKD_POOL_F16X3 (lf_mkd.h); the ABI's 0 ("default") is mapped to it at creation
+#define LF_POOL_F32 2           // = LF_MKD_POOL_F32
 
 namespace lfmkd {
 

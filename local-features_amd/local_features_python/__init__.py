@@ -14,9 +14,9 @@ import threading
 import numpy as np
 
 from ._lib import (ANGLE_EXACT, ANGLE_EXACT_ZERO, ANGLE_SHADER, FLAG_KERNEL_TIMING, KEYPOINT_DTYPE, LIB_PATH, MODEL_DIR, PCA_NAMES,
-                   POOL_F16X3, POOL_F32, SYMBOLS, MkdHandle, load_library, model_path)
+                   POOL_DEFAULT, POOL_F16X3, POOL_F32, SYMBOLS, MkdHandle, load_library, model_path)
 
-__all__ = ["Keypoint", "LocalFeatures", "MkdHandle", "ANGLE_SHADER", "ANGLE_EXACT", "ANGLE_EXACT_ZERO", "POOL_F32",
+__all__ = ["Keypoint", "LocalFeatures", "MkdHandle", "ANGLE_SHADER", "ANGLE_EXACT", "ANGLE_EXACT_ZERO", "POOL_DEFAULT", "POOL_F32",
            "POOL_F16X3", "FLAG_KERNEL_TIMING", "KEYPOINT_DTYPE", "PCA_NAMES", "SYMBOLS", "LIB_PATH", "MODEL_DIR",
            "load_library", "model_path"]
 
@@ -54,7 +54,7 @@ class LocalFeatures:
     `dropped_blobs` / `dropped_features`."""
 
     def __init__(self, max_image_width, max_image_height, max_features, max_blobs=8000, n_scales=4,
-                 pca="liberty", device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_F32, max_frames=1):
+                 pca="liberty", device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_DEFAULT, max_frames=1):
         if pca not in PCA_NAMES:
             raise RuntimeError("Invalid PCA argument")
         try:
@@ -66,7 +66,7 @@ class LocalFeatures:
             raise RuntimeError("Failed to initialize local features", str(e)) from e
         self._lock = threading.Lock()   # Mutex<LocalFeaturesVulkan>, python/src/lib.rs:38
         self.max_blobs, self.n_scales, self.max_frames = max_blobs, n_scales, max_frames
-        self.max_features = max_features
+        self.max_features, self.device = max_features, device
         self.dropped_blobs = self.dropped_features = 0
 
     def describe(self, img, keypoints):
@@ -139,29 +139,36 @@ class LocalFeatures:
     def detect_top_n_batch(self, imgs, n, min_size=0.0):
         """detect_top_n over a batch of equally sized frames ([f, h, w] float32, f <= max_frames) with every stage
         launched once for all frames (lf_mkd_detect_frames_device).  Returns one (list[Keypoint], ndarray[k,128]) per
-        frame, each equal to what detect_top_n gives for that frame alone; max_features is the budget per frame."""
+        frame.  The library's keypoint budget is one number for the whole batch (lf_mkd.h): max_features * f here, with
+        every frame then cut to its first max_features keypoints -- so each frame's result equals what detect_top_n gives
+        for that frame alone as long as the batch total fits the budget (keypoints beyond it are lost to the LAST frames
+        and counted, like the per-frame cuts, in dropped_features)."""
         import torch
         arr = np.ascontiguousarray(imgs, np.float32)
         if arr.ndim != 3:
             raise RuntimeError("Failed to extract features", "images must be [frames, height, width]")
         f, h, w = arr.shape
         cap = self.max_features * f
+        dev = torch.device("cuda", self.device)      # the handle's device, not torch's current one
         with self._lock:
             try:
-                d_img = torch.from_numpy(arr).cuda()
-                d_k = torch.empty((cap, 5), device="cuda")
-                d_f = torch.empty((cap,), dtype=torch.int32, device="cuda")
-                d_d = torch.empty((cap, 128), device="cuda")
-                m, self.dropped_blobs, self.dropped_features = self._inner.detect_frames_device(
-                    d_img.data_ptr(), f, w, h, int(n), float(min_size), d_k.data_ptr(), d_f.data_ptr(), d_d.data_ptr(),
-                    cap, torch.cuda.current_stream().cuda_stream)
-                torch.cuda.synchronize()
+                with torch.cuda.device(dev):
+                    d_img = torch.from_numpy(arr).to(dev)
+                    d_k = torch.empty((cap, 5), device=dev)
+                    d_f = torch.empty((cap,), dtype=torch.int32, device=dev)
+                    d_d = torch.empty((cap, 128), device=dev)
+                    m, self.dropped_blobs, self.dropped_features = self._inner.detect_frames_device(
+                        d_img.data_ptr(), f, w, h, int(n), float(min_size), d_k.data_ptr(), d_f.data_ptr(), d_d.data_ptr(),
+                        cap, torch.cuda.current_stream(dev).cuda_stream)
+                    torch.cuda.synchronize(dev)
             except RuntimeError as e:
                 raise RuntimeError("Failed to extract features", str(e)) from e
         kps, fid, desc = d_k[:m].cpu().numpy(), d_f[:m].cpu().numpy(), d_d[:m].cpu().numpy()
         out = []
         for i in range(f):
-            sel = fid == i
+            sel = np.flatnonzero(fid == i)
+            self.dropped_features += max(0, len(sel) - self.max_features)
+            sel = sel[:self.max_features]
             out.append(([Keypoint(*row) for row in kps[sel]], desc[sel]))
         return out
 

@@ -12,7 +12,7 @@ MODEL_DIR = os.path.join(_ROOT, "models", "mkd")
 
 FLAG_KERNEL_TIMING = 1
 ANGLE_SHADER, ANGLE_EXACT, ANGLE_EXACT_ZERO = 0, 1, 2
-POOL_F32, POOL_F16X3 = 0, 1
+POOL_DEFAULT, POOL_F16X3, POOL_F32 = 0, 1, 2   # lf_mkd_pool_mode; the default is the f16x3 split
 PCA_NAMES = ("liberty", "notredame", "yosemite")   # enum MKDPCA, lib.rs:26-32
 
 # every symbol include/lf_mkd.h declares
@@ -116,7 +116,7 @@ class MkdHandle:
     pointers (ints), e.g. torch.Tensor.data_ptr()."""
 
     def __init__(self, pca="liberty", max_features=2000, max_image_width=0, max_image_height=0,
-                 patch_scale_factor=24.0, device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_F32, flags=0,
+                 patch_scale_factor=24.0, device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_DEFAULT, flags=0,
                  max_frames=1, n_scales=4, max_blobs=8000):
         self._h = None
         self.n_scales = n_scales

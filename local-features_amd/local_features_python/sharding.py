@@ -17,25 +17,83 @@ def patch_slice_of_rank(n_total, rank, world):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def all_gather_descriptors(desc_local, group=None):
-    """[n_i,128] per rank -> ([sum n_i,128] on every rank, counts).  Shard sizes differ, so shards are
-    padded to the largest one for a single all_gather_into_tensor (one bucket per rank, direct over xGMI
-    with RCCL) and compacted afterwards."""
+def shard_counts(n_local, device, group=None):
+    """Rows held by every rank (a tiny all-gather of one integer each)."""
     world = dist.get_world_size(group)
-    n_local = torch.tensor([desc_local.shape[0]], device=desc_local.device, dtype=torch.int64)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
-    cap = max(max(counts), 1)
-    padded = torch.zeros((cap, desc_local.shape[1]), device=desc_local.device, dtype=desc_local.dtype)
-    padded[:desc_local.shape[0]] = desc_local
-    gathered = torch.empty((world * cap, desc_local.shape[1]), device=desc_local.device, dtype=desc_local.dtype)
-    dist.all_gather_into_tensor(gathered, padded, group=group)
-    parts = [gathered[r * cap:r * cap + counts[r]] for r in range(world)]
-    return torch.cat(parts, dim=0), counts
+    mine = torch.tensor([int(n_local)], device=device, dtype=torch.int64)
+    counts = torch.zeros((world,), device=device, dtype=torch.int64)
+    dist.all_gather_into_tensor(counts, mine, group=group)
+    return [int(c) for c in counts.tolist()]
 
 
-def cross_image_match(desc_local, image_sizes_local, match_fn, ratio=0.8, group=None):
+def gathered_buffer(counts, rank, width=128, device="cuda", dtype=torch.float32):
+    """The final gathered set [sum counts, width] and this rank's own rows in it (a view).  A producer that writes its
+    descriptors straight into the view (bench.py does) makes the all-gather copy-free on the sending side too."""
+    total = sum(counts)
+    buf = torch.empty((total, width), device=device, dtype=dtype)
+    lo = sum(counts[:rank])
+    return buf, buf[lo:lo + counts[rank]]
+
+
+def all_gather_descriptors(desc_local, group=None, mode="direct", out=None, counts=None):
+    """[n_i,128] per rank -> ([sum n_i,128] on every rank, counts).  Every shard lands at its final place (rank order)
+    in ONE buffer: no padding to the largest shard, no second copy.
+
+    mode "direct": every rank sends its shard to each peer and receives each peer's shard in one group of point-to-point
+                   transfers (ncclGroupStart .. End under batch_isend_irecv).  xGMI is a full point-to-point mesh, so the
+                   7 sends of a rank leave on 7 different links at once; shard sizes may differ.
+    mode "ring":   one all_gather_into_tensor (RCCL's ring: every byte crosses world-1 links in turn); needs equal
+                   shards, falls back to "direct" otherwise.
+    out / counts:  a buffer from gathered_buffer() whose own-rank view already holds desc_local (then nothing is copied
+                   locally); counts may be passed when the caller already knows them."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if counts is None:
+        counts = shard_counts(desc_local.shape[0], desc_local.device, group)
+    if counts[rank] != desc_local.shape[0]:
+        raise ValueError("counts[rank] must be the number of local descriptors")
+    offs = [sum(counts[:r]) for r in range(world + 1)]
+    if out is None:
+        out = torch.empty((offs[-1], desc_local.shape[1]), device=desc_local.device, dtype=desc_local.dtype)
+    elif out.shape[0] != offs[-1] or out.shape[1] != desc_local.shape[1] or not out.is_contiguous():
+        raise ValueError("out must be a contiguous [sum(counts), width] buffer")
+    mine = out[offs[rank]:offs[rank + 1]]
+    if mine.data_ptr() != desc_local.data_ptr() and counts[rank]:
+        mine.copy_(desc_local)
+    # gloo moves host memory only: a CUDA shard on a gloo group (the one-GPU rehearsal of bench.py) goes through the host
+    via_host = out.is_cuda and dist.get_backend(group) == "gloo"
+    buf = out.cpu() if via_host else out
+    if mode == "ring" and len(set(counts)) == 1 and counts[0] > 0:
+        dist.all_gather_into_tensor(buf, buf[offs[rank]:offs[rank + 1]], group=group)
+    elif mode in ("direct", "ring"):
+        ops = []
+        for step in range(1, world):       # peer order staggered by rank: at any step the pairs are disjoint
+            dst, src = (rank + step) % world, (rank - step) % world
+            if counts[rank]:
+                ops.append(dist.P2POp(dist.isend, buf[offs[rank]:offs[rank + 1]], dst, group))
+            if counts[src]:
+                ops.append(dist.P2POp(dist.irecv, buf[offs[src]:offs[src + 1]], src, group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+    else:
+        raise ValueError(f"unknown all-gather mode {mode!r}")
+    if via_host:
+        out.copy_(buf)
+    return out, counts
+
+
+def exclusion_ranges(image_sizes_local, base, device):
+    """Per local descriptor, the rows [lo, hi) of the gathered set that belong to its own image (which a cross-image
+    match must not consider); `base` = global row of this rank's first descriptor."""
+    sizes = torch.as_tensor(list(image_sizes_local), dtype=torch.int64)
+    starts = base + torch.cumsum(sizes, 0) - sizes                       # global row of each local image's first row
+    lo = torch.repeat_interleave(starts, sizes).to(torch.int32)
+    hi = torch.repeat_interleave(starts + sizes, sizes).to(torch.int32)
+    return lo.to(device), hi.to(device)
+
+
+def cross_image_match(desc_local, image_sizes_local, match_fn, ratio=0.8, group=None, mode="direct", out=None):
     """The match stage of BASELINE configs[3]: every rank holds the descriptors of its own images
     (desc_local [n_i,128], image_sizes_local = descriptors per image, in storage order); descriptor shards are
     all-gathered (the path's one collective), and each rank matches ITS descriptors against ALL descriptors
@@ -47,18 +105,15 @@ def cross_image_match(desc_local, image_sizes_local, match_fn, ratio=0.8, group=
     Returns (match [n_i] int64 GLOBAL row indices into the gathered set or -1, gathered descriptors,
     global offset of this rank's first row)."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    sizes = torch.as_tensor(list(image_sizes_local), dtype=torch.int64)
-    if int(sizes.sum()) != desc_local.shape[0]:
+    if sum(int(s) for s in image_sizes_local) != desc_local.shape[0]:
         raise ValueError("image_sizes_local must add up to the number of local descriptors")
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        gathered, counts = all_gather_descriptors(desc_local, group)
+        gathered, counts = all_gather_descriptors(desc_local, group, mode=mode, out=out)
     else:
         gathered, counts = desc_local, [desc_local.shape[0]]
     base = sum(counts[:rank])
-    starts = base + torch.cumsum(sizes, 0) - sizes                       # global row of each local image's first row
-    lo = torch.repeat_interleave(starts, sizes).to(torch.int32)
-    hi = torch.repeat_interleave(starts + sizes, sizes).to(torch.int32)
-    match = match_fn(desc_local, gathered, lo.to(desc_local.device), hi.to(desc_local.device), ratio)
+    lo, hi = exclusion_ranges(image_sizes_local, base, desc_local.device)
+    match = match_fn(desc_local, gathered, lo, hi, ratio)
     return match.to(torch.int64), gathered, base
 
 

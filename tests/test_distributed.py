@@ -4,6 +4,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -31,11 +32,22 @@ def _worker(rank, world, port, q):
     rng = np.random.default_rng(1234)
     all_desc = [rng.random((k, 128)).astype(np.float32) for k in kp_per_frame]   # same on every rank
     local = torch.from_numpy(np.concatenate([all_desc[f] for f in mine] or [np.zeros((0, 128), np.float32)]))
-    gathered, counts = sharding.all_gather_descriptors(local)
+    gathered, counts = sharding.all_gather_descriptors(local)           # "direct": point-to-point, uneven shards
     expect = np.concatenate([np.concatenate([all_desc[f] for f in sharding.frames_of_rank(7, r, world)])
                              for r in range(world)])
     ok = gathered.shape == (sum(kp_per_frame), 128) and np.array_equal(gathered.numpy(), expect)
     ok = ok and counts == [sum(kp_per_frame[f] for f in sharding.frames_of_rank(7, r, world)) for r in range(world)]
+    # the same set into a caller-owned final buffer whose own-rank view already holds the shard (nothing copied locally)
+    buf, mine_view = sharding.gathered_buffer(counts, rank, device="cpu")
+    mine_view.copy_(local)
+    g2, _ = sharding.all_gather_descriptors(mine_view, out=buf, counts=counts)
+    ok = ok and g2.data_ptr() == buf.data_ptr() and np.array_equal(buf.numpy(), expect)
+    # "ring" (one all_gather_into_tensor) on equal shards, and its fall-back to point-to-point on uneven ones
+    eq = torch.full((4, 128), float(rank + 1))
+    g3, c3 = sharding.all_gather_descriptors(eq, mode="ring")
+    ok = ok and c3 == [4] * world and all(bool((g3[4 * r:4 * r + 4] == r + 1).all()) for r in range(world))
+    g4, _ = sharding.all_gather_descriptors(local, mode="ring")
+    ok = ok and np.array_equal(g4.numpy(), expect)
     tmax = sharding.max_over_ranks(1.0 + rank, "cpu")
     ok = ok and tmax == float(world)
     # match stage of configs[3]: local queries against the gathered set, own image excluded; the engine is injected
@@ -74,8 +86,8 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_shard_and_all_gather():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_shard_and_all_gather(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -87,7 +99,7 @@ def test_two_ranks_shard_and_all_gather():
         p.join(60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _, _ in res)
-    assert [(a, b) for _, _, a, b in res] == [(0, 501), (501, 1001)]
+    assert [(a, b) for _, _, a, b in res] == {2: [(0, 501), (501, 1001)], 3: [(0, 334), (334, 668), (668, 1001)]}[world]
 
 
 def test_slices_cover_everything():

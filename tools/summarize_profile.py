@@ -16,7 +16,7 @@ kern_ms = None
 # the timed kernel variant: mkd_pool<ANGLE, POOL>; bench.py also runs the exact-angle variant once as a
 # secondary figure, which must not be mixed into the headline kernel's numbers
 variant = "mkd_pool<%d, %d, 8>" % (0 if (not bench or bench["config"]["angle_mode"] == "shader") else 1,
-                                   1 if (not bench or bench["config"]["pool_mode"] == "f16x3") else 0)
+                                   1 if (not bench or bench["config"]["pool_mode"] == "f16x3") else 2)
 if stats:
     lines += ["## `--kernel-trace --stats` (kernel_stats.csv)", "", "| kernel | calls | avg ms | min ms | max ms | % |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(stats[0])):
