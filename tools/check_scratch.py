@@ -5,8 +5,8 @@ Reads hipcc's -Rpass-analysis=kernel-resource-usage remarks of mkd_describe.hip 
 instantiation of mkd_pool uses scratch memory.  Why: the f16 epilogue waits for its LDS-DMA steps with COUNTED
 s_waitcnt vmcnt(N); scratch spill stores count on vmcnt too and retire out of order with respect to loads, so a spill
 in flight there would let a wait pass before its DMA has landed -- silently wrong descriptors, now and then.  The f32
-(POOL = 2) instantiations only ever wait with vmcnt(0) and may spill.  Everything that is not a resource remark
-(warnings, errors) is passed through to stderr."""
+(POOL = 2) instantiations only ever wait with vmcnt(0) and may spill.  Warnings and errors in the same file are passed
+through to stderr."""
 import re
 import sys
 
@@ -14,7 +14,7 @@ text = open(sys.argv[1], errors="replace").read().splitlines()
 name, bad, seen = None, [], 0
 for line in text:
     if "kernel-resource-usage" not in line:
-        if line.strip():
+        if re.search(r"\b(warning|error|note):", line):
             print(line, file=sys.stderr)
         continue
     m = re.search(r"Function Name: (\S+)", line)
