@@ -116,6 +116,29 @@ class LocalFeatures:
             m = self._inner.match(desc_a, desc_b, ratio)
         return [(int(i), int(j)) for i, j in enumerate(m) if j >= 0]
 
+    def match_ip_distance(self, desc_a, desc_b, factor=0.75):
+        """The webcam example's acceptance rule (examples/webcam/src/main.rs:97-104,261-265): nearest and second-nearest
+        neighbour of desc_a[i] in desc_b under the inner-product distance d = 1 - <a, b> (usearch MetricKind::IP), accepted
+        if d0 < factor * d1.  Built on the same matcher: lf_mkd_match_device with ratio <= 0 returns the best index plus
+        the best and second-best similarity, the rule is applied to those.  Returns a list of (i, j)."""
+        import torch
+        a = np.ascontiguousarray(desc_a, np.float32).reshape(-1, 128)
+        b = np.ascontiguousarray(desc_b, np.float32).reshape(-1, 128)
+        if len(a) == 0:
+            return []
+        dev = torch.device("cuda", self.device)
+        with self._lock, torch.cuda.device(dev):
+            d_a, d_b = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+            d_m = torch.empty((len(a),), dtype=torch.int32, device=dev)
+            d_1, d_2 = torch.empty((len(a),), device=dev), torch.empty((len(a),), device=dev)
+            s = torch.cuda.current_stream(dev)
+            self._inner.match_device(d_a.data_ptr(), len(a), d_b.data_ptr(), len(b), d_m.data_ptr(), 0.0, None, None,
+                                     d_1.data_ptr(), d_2.data_ptr(), s.cuda_stream)
+            s.synchronize()
+            keep = (1.0 - d_1) < (1.0 - d_2) * factor
+            m, keep = d_m.cpu().numpy(), keep.cpu().numpy()
+        return [(int(i), int(m[i])) for i in np.flatnonzero(keep)]
+
     def describe_patches(self, patches):
         """patches: [n,32,32] float32 -> ndarray[n,128] (the CPU twin's Mkd::patch, mkd_ref.rs:57-77)."""
         with self._lock:

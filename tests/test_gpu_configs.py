@@ -1,0 +1,110 @@
+"""BASELINE.json's configurations at their own sizes, against the oracle (GPU).
+
+configs[1]: 10 000 keypoints on one 1920x1080 frame      configs[3]: the per-GPU share, 2^20 patches
+(configs[2] and configs[4] live in test_gpu_detector.py / test_gpu_parity.py next to the pipelines they exercise;
+ configs[0] -- the reference's match_images on its own two photographs -- is below.)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GATE, GOLDEN, ROOT, assert_keypoint_parity, assert_patch_parity, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lfp():
+    import local_features_python as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "these tests need the MI355X"
+    return t
+
+
+def test_configs3_per_gpu_share_of_2pow20_patches(lfp, torch, oracle):
+    """2^20 patches (4 GiB in, 512 MiB out) in ONE call, as bench.py times it: size-independent properties over all of
+    them, and 4096 rows drawn across the whole range against the oracle."""
+    from oracle import ATAN_SHADER
+    n = 1 << 20
+    gen = torch.Generator(device="cuda").manual_seed(0x4D4B44)
+    p = torch.rand((n, 32, 32), device="cuda", generator=gen)
+    out = torch.empty((n, 128), device="cuda")
+    h = lfp.MkdHandle(max_features=n)
+    s = torch.cuda.current_stream().cuda_stream
+    h.describe_patches_device(p.data_ptr(), n, out.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+    assert float((out.norm(dim=1) - 1).abs().max()) < 1e-5
+    # a descriptor depends on its own patch only: the same rows through a small request (the 4-wave form of the kernel)
+    idx = torch.randint(0, n, (4096,), device="cuda", generator=gen)
+    idx[:3] = torch.tensor([0, n - 1, n // 2], device="cuda")
+    sub = p[idx].contiguous()
+    out2 = torch.empty((4096, 128), device="cuda")
+    h.describe_patches_device(sub.data_ptr(), 4096, out2.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out[idx])
+    # and it is the descriptor the oracle computes
+    worst = assert_patch_parity(oracle, sub.cpu().numpy(), out[idx].cpu().numpy(), ATAN_SHADER, what="2^20")
+    print(f"2^20 patches: worst relative L2 of 4096 sampled descriptors vs the oracle = {worst:.2e}")
+    # a second run gives the same bits (no race in the LDS pipeline at full occupancy)
+    out3 = torch.empty_like(out)
+    h.describe_patches_device(p.data_ptr(), n, out3.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out3)
+
+
+def test_configs1_10k_keypoints_on_a_1080p_frame(lfp, torch, oracle):
+    """10 000 keypoints on one 1920x1080 frame: unit norm and batch-independence over all of them, a 1000-row sample
+    against the oracle end to end (pyramid -> sampling -> describe)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gen_golden import random_keypoints, smooth_image
+    w, hgt, n = 1920, 1080, 10000
+    img = np.ascontiguousarray(smooth_image(hgt, w, 11), np.float32)
+    k5 = np.concatenate([random_keypoints(n, w, hgt, 12, margin=64.0), np.zeros((n, 1), np.float32)], axis=1)
+    k5 = np.ascontiguousarray(k5, np.float32)
+    h = lfp.MkdHandle(max_features=n, max_image_width=w, max_image_height=hgt)
+    h.set_image(img)
+    d = h.describe_keypoints(k5)
+    assert d.shape == (n, 128) and np.isfinite(d).all()
+    assert np.abs(np.linalg.norm(d, axis=1) - 1).max() < 1e-5
+    rng = np.random.default_rng(13)
+    pick = np.sort(rng.choice(n, 1000, replace=False))
+    # the same keypoints in a request of their own give the same bits
+    assert np.array_equal(h.describe_keypoints(k5[pick]), d[pick])
+    assert_keypoint_parity(oracle, h, img, k5[pick], d[pick], what="configs[1]")
+
+
+def test_configs0_match_images_on_the_reference_photographs(lfp, oracle):
+    """BASELINE configs[0]: `match_images bird.jpg houses.jpg` (examples/match_images/src/main.rs:36-159):
+    detect_top_n(2000, 0) with max_features 3000, max_blobs 8000, n_scales 5 on both photographs, match both ways.
+    houses.jpg is the reference's 4096 x 3072 benchmark input (benches/bench.rs:41-74).  The two pictures show
+    different scenes, so what is checked is every stage against the oracle on the real 12-megapixel input."""
+    sys.path.insert(0, os.path.join(ROOT, "local-features_amd", "examples"))
+    import match_images as ex
+    img1 = ex.load_gray(os.path.join(GOLDEN, "bird.jpg"))
+    img2 = ex.load_gray(os.path.join(GOLDEN, "houses.jpg"))
+    assert img2.shape == (3072, 4096)
+    kp1, kp2, d1, d2, m12, m21 = ex.match_images(img1, img2)
+    assert len(kp2) > 2000 and d2.shape == (len(kp2), 128)
+    # keypoints of the large photograph = the oracle's detect (same extrema, same top-2000, same orientations)
+    want_k, _ = oracle.detect(img2, n_scales=5, top_n=2000, max_blobs=8000, max_features=3000)
+    got = np.array([(k.x, k.y, k.size, k.angle, k.response) for k in kp2], np.float32)
+    assert got.shape == want_k.shape
+    assert np.abs(got[:, :2] - want_k[:, :2]).max() < 2e-3 and np.abs(got[:, 2] / want_k[:, 2] - 1).max() < 1e-4
+    da = np.abs(got[:, 3] - want_k[:, 3])
+    assert (np.minimum(da, 360 - da) < 1e-3).mean() > 0.995
+    # descriptors of a 512-keypoint sample against the oracle on the photograph
+    hgt, w = img2.shape
+    h = lfp.MkdHandle(max_features=3000, max_image_width=w, max_image_height=hgt, n_scales=5)
+    h.set_image(img2)
+    pick = np.arange(0, len(got), max(1, len(got) // 512))[:512]
+    assert_keypoint_parity(oracle, h, img2, got[pick], d2[pick], what="houses", patch_tol=1e-4)
+    # the match lists are the oracle's on the same descriptors
+    assert m12 == [(i, int(j)) for i, j in enumerate(oracle.match(d1, d2)[0]) if j >= 0]
+    assert m21 == [(i, int(j)) for i, j in enumerate(oracle.match(d2, d1)[0]) if j >= 0]

@@ -301,6 +301,32 @@ def test_4k_frame_at_baseline_size(lfp, torch, oracle):
     assert n == len(rk) > 6000 and int(d_c[0].item()) == total and int(d_c[2].item()) == 6000
     assert np.array_equal(d_k[:n].cpu().numpy(), rk) and np.array_equal(d_d[:n].cpu().numpy(), rd)
     assert np.allclose(np.linalg.norm(rd, axis=1), 1.0, atol=1e-5)
+    # ... and what the oracle gives: 512 of the recorded pipeline's descriptors, end to end on the 4K frame (after a
+    # launch the handle holds that frame's pyramid, so its sampler can be compared too)
+    pick = np.arange(0, n, max(1, n // 512))[:512]
+    assert_keypoint_parity(oracle, h, img, rk[pick], d_d[:n].cpu().numpy()[pick], what="4K hipGraph", patch_tol=1e-4)
+
+
+def test_stream_create_discards_the_loaded_frame(lfp, torch):
+    """lf_mkd_stream_create re-plans the pyramid store: until the first recorded frame has run, the keypoint entry
+    points must say LF_MKD_ERR_NO_IMAGE rather than read a stale or uninitialised pyramid."""
+    w, hgt, cap = 256, 192, 1024
+    img = blob_image(w, hgt, 3, 80)
+    h = lfp.MkdHandle(max_features=cap, max_image_width=w, max_image_height=hgt, max_blobs=512)
+    h.set_image(img)
+    kp = np.array([[100, 90, 4.0, 30.0, 0.0]], np.float32)
+    before = h.describe_keypoints(kp)
+    d_img = torch.from_numpy(img).cuda()
+    d_k, d_d = torch.zeros((cap, 5), device="cuda"), torch.zeros((cap, 128), device="cuda")
+    d_c = torch.zeros((8,), dtype=torch.int64, device="cuda")
+    h.stream_create(w, hgt, 100, 0.0, cap, d_img.data_ptr(), d_k.data_ptr(), d_d.data_ptr(), d_c.data_ptr())
+    with pytest.raises(RuntimeError, match="set_image"):
+        h.describe_keypoints(kp)
+    with pytest.raises(RuntimeError, match="set_image"):
+        h.coarse_layer(1, w, hgt)
+    h.stream_frame()
+    h.synchronize()
+    assert np.array_equal(h.describe_keypoints(kp), before)      # the frame the pipeline just processed
 
 
 def test_python_class_batch_call(lfp):

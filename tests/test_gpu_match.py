@@ -85,6 +85,25 @@ def test_match_ties_and_errors(lfp, oracle):
     assert len(h.match(np.zeros((0, 128), np.float32), b)) == 0
 
 
+def test_webcam_acceptance_rule(lfp, oracle):
+    """examples/webcam/src/main.rs:261-265: two nearest neighbours under the inner-product distance 1 - <a, b>
+    (usearch MetricKind::IP, main.rs:97-104), accepted if d0 < 0.75 d1 -- restated on the oracle's best / second."""
+    a, b = descriptor_sets(1500, 4000, 77)
+    idx, s1, s2 = oracle.match(a, b, ratio=0.0)
+    d0, d1 = np.float32(1) - s1, np.float32(1) - s2
+    want = [(i, int(idx[i])) for i in np.flatnonzero(d0 < d1 * np.float32(0.75))]
+    lf = lfp.LocalFeatures(64, 64, 64)
+    got = lf.match_ip_distance(a, b)
+    assert 0.1 < len(want) / len(a) < 0.95                       # both outcomes occur
+    # a differing decision must sit on the acceptance boundary (the two sides round a similarity differently by ~1e-7)
+    near = {i for i in range(len(a)) if abs(d0[i] - 0.75 * d1[i]) < 2e-6}
+    assert {p for p in got if p[0] not in near} == {p for p in want if p[0] not in near}
+    assert len(set(got) ^ set(want)) <= 3
+    # the rule is not Lowe's ratio on similarities: the two accept different sets
+    lowe = set(lf.match(a, b))
+    assert lowe != set(got)
+
+
 def test_cross_image_exclusion(lfp, torch, oracle):
     """BASELINE configs[3] form: b = the descriptors of all images, a row is not matched against its own image."""
     rng = np.random.default_rng(2)
