@@ -91,35 +91,49 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
         bool emit = false;
         float ox = 0.f, oy = 0.f, size = 0.f, contrast = 0.f;
         if (cand && __popcll(cm & below) < 8) {   // max_wg_extrema = 8 (scan_extrema.glsl:28)
-            const float dds = (at(1, 0, 0) - at(-1, 0, 0)) / 2.0f;
-            const float ddy = (at(0, 1, 0) - at(0, -1, 0)) / 2.0f;
-            const float ddx = (at(0, 0, 1) - at(0, 0, -1)) / 2.0f;
-            const float value2x = val * 2.0f;
-            const float h11 = at(1, 0, 0) + at(-1, 0, 0) - value2x;
-            const float h22 = at(0, 1, 0) + at(0, -1, 0) - value2x;
-            const float h33 = at(0, 0, 1) + at(0, 0, -1) - value2x;
-            const float h12 = (at(1, 1, 0) - at(-1, 1, 0) - at(1, -1, 0) + at(-1, -1, 0)) / 4.0f;
-            const float h13 = (at(1, 0, 1) - at(-1, 0, 1) - at(1, 0, -1) + at(-1, 0, -1)) / 4.0f;
-            const float h23 = (at(0, 1, 1) - at(0, 1, -1) - at(0, -1, 1) + at(0, -1, -1)) / 4.0f;
-            const float det =
-                h11 * h22 * h33 - h11 * h23 * h23 - h12 * h12 * h33 + 2.f * h12 * h13 * h23 - h13 * h13 * h22;
-            const float hinv11 = (h22 * h33 - h23 * h23) / det;
-            const float hinv12 = (h13 * h23 - h12 * h33) / det;
-            const float hinv13 = (h12 * h23 - h13 * h22) / det;
-            const float hinv22 = (h11 * h33 - h13 * h13) / det;
-            const float hinv23 = (h12 * h13 - h11 * h23) / det;
-            const float hinv33 = (h11 * h22 - h12 * h12) / det;
-            const float os = -(hinv11 * dds + hinv12 * ddy + hinv13 * ddx);
-            oy = -(hinv12 * dds + hinv22 * ddy + hinv23 * ddx);
-            ox = -(hinv13 * dds + hinv23 * ddy + hinv33 * ddx);
+            // Quadratic fit around the voxel (axes: s = scale layer, y, x).  The extremum test downstream decides on the
+            // last bits of these values, and the oracle evaluates the reference's formulas in the reference's order, so the
+            // ORDER OF OPERATIONS below is load-bearing (fma contraction is off in this file): central differences divide
+            // the difference, second differences subtract twice the centre last, a mixed difference runs
+            // (+u+v) - (-u+v) - (+u-v) + (-u-v) left to right, the determinant is the five-term cofactor expansion left to
+            // right, every adjugate entry is one 2x2 minor divided by the determinant, and each offset negates a
+            // three-term dot product summed left to right (scan_extrema.glsl:167-197).
+            struct Axis { int s, y, x; };
+            constexpr Axis kS{1, 0, 0}, kY{0, 1, 0}, kX{0, 0, 1};
+            auto tap = [&](int cu, Axis u, int cv, Axis v) {
+                return at(cu * u.s + cv * v.s, cu * u.y + cv * v.y, cu * u.x + cv * v.x);
+            };
+            auto first = [&](Axis u) { return (tap(1, u, 0, u) - tap(-1, u, 0, u)) / 2.0f; };
+            const float twice = val * 2.0f;
+            auto second = [&](Axis u) { return tap(1, u, 0, u) + tap(-1, u, 0, u) - twice; };
+            auto mixed = [&](Axis u, Axis v) {
+                return (tap(1, u, 1, v) - tap(-1, u, 1, v) - tap(1, u, -1, v) + tap(-1, u, -1, v)) / 4.0f;
+            };
+            const float g_s = first(kS), g_y = first(kY), g_x = first(kX);
+            // symmetric hessian: diagonal, then the three mixed terms (the y-x one differences x first)
+            const float h_ss = second(kS), h_yy = second(kY), h_xx = second(kX);
+            const float h_sy = mixed(kS, kY), h_sx = mixed(kS, kX), h_yx = mixed(kX, kY);
+            const float det = h_ss * h_yy * h_xx - h_ss * h_yx * h_yx - h_sy * h_sy * h_xx + 2.f * h_sy * h_sx * h_yx -
+                              h_sx * h_sx * h_yy;
+            auto minor_over_det = [&](float a, float b, float c, float d) { return (a * b - c * d) / det; };
+            const float i_ss = minor_over_det(h_yy, h_xx, h_yx, h_yx);
+            const float i_sy = minor_over_det(h_sx, h_yx, h_sy, h_xx);
+            const float i_sx = minor_over_det(h_sy, h_yx, h_sx, h_yy);
+            const float i_yy = minor_over_det(h_ss, h_xx, h_sx, h_sx);
+            const float i_yx = minor_over_det(h_sy, h_sx, h_ss, h_yx);
+            const float i_xx = minor_over_det(h_ss, h_yy, h_sy, h_sy);
+            const float os = -(i_ss * g_s + i_sy * g_y + i_sx * g_x);
+            oy = -(i_sy * g_s + i_yy * g_y + i_yx * g_x);
+            ox = -(i_sx * g_s + i_yx * g_y + i_xx * g_x);
             // |offset| > 0.5 in any direction: the shader moves x, y, z and emits nothing (lines 200-203).
             // A singular hessian gives NaN offsets; the shader would emit NaN coordinates, here it is dropped.
             const bool within = fabsf(ox) <= 0.5f && fabsf(oy) <= 0.5f && fabsf(os) <= 0.5f;
-            const float interp = os * dds + oy * ddy + ox * ddx;
+            const float interp = os * g_s + oy * g_y + ox * g_x;
             contrast = fabsf(val + interp / 2.0f);
-            const float denom = (h22 + h33) * (h22 + h33);
-            const float cmv = 1.f - 4.f * (h22 * h33 - h23 * h23) / denom;
-            emit = within && denom != 0.f && !(0.7f <= cmv && cmv <= 1.5f);
+            // edge response from the spatial 2x2 block of the hessian (lines 217-224)
+            const float trace2 = (h_yy + h_xx) * (h_yy + h_xx);
+            const float cmv = 1.f - 4.f * (h_yy * h_xx - h_yx * h_yx) / trace2;
+            emit = within && trace2 != 0.f && !(0.7f <= cmv && cmv <= 1.5f);
             size = 0.82f * 1.41421356237f * exp2f((float)z + os);
         }
         const unsigned long long em = __ballot(emit);
