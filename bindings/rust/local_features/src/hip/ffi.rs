@@ -21,6 +21,7 @@ pub const LF_MKD_POOL_DEFAULT: i32 = 0;
 pub const LF_MKD_POOL_F16X3: i32 = 1;
 pub const LF_MKD_POOL_F32: i32 = 2;
 pub const LF_MKD_FLAG_KERNEL_TIMING: u32 = 1;
+pub const LF_MKD_FLAG_NO_OVERLAP: u32 = 2;
 pub const LF_MKD_MAX_ANGLES_PER_EXTREMUM: usize = 18;
 
 /// `lf_mkd_params`: BuildTimeParams (lib.rs:54-75) + FeatureDetectParams (lib.rs:34-52) for this path; 0 = default.

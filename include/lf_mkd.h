@@ -61,6 +61,9 @@ typedef enum { LF_MKD_POOL_DEFAULT = 0, LF_MKD_POOL_F16X3 = 1, LF_MKD_POOL_F32 =
 /* lf_mkd_params.flags */
 #define LF_MKD_FLAG_KERNEL_TIMING 1u /* bracket every kernel launch with HIP events on its stream;
                                         read the sums with lf_mkd_kernel_times (bench.py's roofline) */
+#define LF_MKD_FLAG_NO_OVERLAP 2u    /* keypoint mode: sample, then describe, on the caller's stream only (by default
+                                        large batches are chunked and the sampler of one chunk runs on a second stream
+                                        beside the describe kernel of the previous one) */
 
 /* Mirrors BuildTimeParams (lib.rs:54-75) + FeatureDetectParams (lib.rs:34-52) for this path.
  * Zero-initialise, then set what you need; 0 means "default". */

@@ -754,13 +754,13 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
 // ---------------------------------------------------------------------------------------------
 // n_dev != nullptr: the patch count is read on the device (<= n, which then only sizes the grid)
 void launch_describe(const float *patches, long n, const unsigned long long *n_dev, const DeviceConsts &dc,
-                     int angle_mode, int pool_mode, float *out, float *raw_out, int num_cus, hipStream_t stream) {
+                     int angle_mode, int pool_mode, float *out, float *raw_out, int num_cus, hipStream_t stream, int waves) {
     if (n <= 0) return;
     // one 100-152 KiB-LDS workgroup per CU; requests of at most one round of 64-patch workgroups take the 4-wave form
 #ifdef LF_ABLATE_FORCE_W4   // timing-only build: the 4-wave form at every size
     const bool small = true;
 #else
-    const bool small = n <= 64L * num_cus;
+    const bool small = waves == 4 || (waves != 8 && n <= 64L * num_cus);
 #endif
     const long nbatch = small ? (n + 63) / 64 : (n + 127) / 128;
     const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);

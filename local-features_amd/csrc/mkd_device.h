@@ -36,8 +36,10 @@ struct DeviceConsts {
 
 // patches [n][32][32] -> out [n][128] (and, when raw_out != nullptr, the un-whitened [n][238])
 // (n_dev != nullptr: the count is read on the device, n only sizes the grid; same for the launchers below)
+// waves: 0 = choose by size (4-wave workgroups when the request fits one round of them, else 8-wave), 4 / 8 = that form
 void launch_describe(const float *patches, long n, const unsigned long long *n_dev, const DeviceConsts &dc,
-                     int angle_mode, int pool_mode, float *out, float *raw_out, int num_cus, hipStream_t stream);
+                     int angle_mode, int pool_mode, float *out, float *raw_out, int num_cus, hipStream_t stream,
+                     int waves = 0);
 // frame_of_kp == nullptr: every keypoint belongs to frame 0
 void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                            const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,

@@ -5,7 +5,6 @@
 // (paths under local_features/src/vulkan/)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "mkd_device.h"
 
@@ -366,145 +365,12 @@ __global__ __launch_bounds__(256) void sample_patches(const float *__restrict__ 
     for (int j = 0; j < 16; ++j) dst[j * 64] = tile[j * 64 + lane];
 }
 
-// The same stage with the texels staged through LDS.  The gather form above is bound by the texture-address unit: a
-// wave's 64 scattered addresses cost ~50 L1 lookups per load instruction, 4096 such lanes per keypoint.  Here the patch is
-// handled in four 16 x 16 pixel quadrants; the bounding box of a quadrant's footprint (at most 48 x 48 texels for every
-// scale remainder < 2 and every angle) is copied into LDS row by row -- each row ONE load instruction over consecutive
-// addresses, straight into LDS (LDS-DMA, no registers) -- and the four bilinear taps of a sample are two ds_read2_b32.
-// Arithmetic of a sample (coordinates, floor / fraction, blend order) is the gather form's, texel for texel: the two
-// kernels give the same bits.  MirroredRepeat is applied while copying (only boxes that leave the level pay for it).
-constexpr int kQuadBox = 48;   // >= 15 * 2 * sqrt2 + 4
-
-__device__ __forceinline__ void lds_dma16(const float *gsrc, float *ldst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
-}
-__device__ __forceinline__ void lds_dma4(const float *gsrc, float *ldst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)ldst, 4, 0, 0);
-}
-
-__global__ __launch_bounds__(256) void sample_patches_lds(const float *__restrict__ pyr, long pyr_stride, PyramidDesc pd,
-                                                          const float *__restrict__ kps /*[n][5]*/,
-                                                          const unsigned *__restrict__ frame_of_kp, long n_host,
-                                                          const unsigned long long *__restrict__ n_dev, float psf,
-                                                          float *__restrict__ patches) {
-    __shared__ __attribute__((aligned(16))) float s_box[4][kQuadBox * kQuadBox];
-    const long n = n_dev ? (long)*n_dev : n_host;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long k = (long)blockIdx.x * 4 + wave;
-    if (k >= n) return;
-    const int lane = threadIdx.x & 63;
-    if (frame_of_kp) pyr += (long)frame_of_kp[k] * pyr_stride;
-    const float *kp = kps + k * 5;
-    const float scale = kp[2] * psf / 32.f;
-    const float l2 = log2f(scale);
-    float lvl = floorf(l2);
-    lvl = lvl < 0.f ? 0.f : (lvl > (float)(pd.levels - 1) ? (float)(pd.levels - 1) : lvl);
-    const float rem = exp2f(l2 - lvl);
-    int l = (int)lvl;   // a non-finite size (caller-supplied keypoints) must not index outside the pyramid
-    l = l < 0 ? 0 : (l > pd.levels - 1 ? pd.levels - 1 : l);
-    const float ang = kp[3] * (3.14159265358979323846f / 180.f);
-    const float ca = cosf(ang), sa = sinf(ang);
-    const float inv = 1.f / exp2f(lvl);
-    const float *img = pyr + pd.offset[l];
-    const int w = pd.w[l], h = pd.h[l];
-    float *box = s_box[wave];
-    float *dst = patches + k * 1024;
-    const int col = lane & 15, row4 = lane >> 4;   // a step samples 4 patch rows x 16 columns of the quadrant
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-        const int px0 = 16 * (q & 1), py0 = 16 * (q >> 1);
-        // bounding box of the quadrant's samples: its four corner pixels, by the very expression the samples use
-        float xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float cdx = (float)(px0 + ((c & 1) ? 15 : 0)) - 16.f, cdy = (float)(py0 + ((c & 2) ? 15 : 0)) - 16.f;
-            const float xx = cdx * ca - cdy * sa, yy = cdx * sa + cdy * ca;
-            const float sx = xx * rem + kp[0] * inv, sy = yy * rem + kp[1] * inv;
-            xlo = fminf(xlo, sx); xhi = fmaxf(xhi, sx);
-            ylo = fminf(ylo, sy); yhi = fmaxf(yhi, sy);
-        }
-        const float bxf = floorf(xlo) - 1.f, byf = floorf(ylo) - 1.f;   // one texel of margin: +1 neighbour, rounding
-        const float bwf = floorf(xhi) + 3.f - bxf, bhf = floorf(yhi) + 3.f - byf;
-        // (comparisons are false for NaN: a non-finite keypoint takes the general path)
-        const bool boxed = bwf >= 2.f && bwf <= (float)kQuadBox && bhf >= 2.f && bhf <= (float)kQuadBox &&
-                           fabsf(bxf) < 1e9f && fabsf(byf) < 1e9f;
-        if (!boxed) {   // uniform over the wave
-#pragma unroll 1
-            for (int i = 0; i < 4; ++i) {
-                const int lx = px0 + col, ly = py0 + 4 * i + row4;
-                const float dx = (float)lx - 16.f, dy = (float)ly - 16.f;
-                const float xx = dx * ca - dy * sa, yy = dx * sa + dy * ca;
-                const float sx = xx * rem + kp[0] * inv, sy = yy * rem + kp[1] * inv;
-                dst[ly * 32 + lx] = tex_bilinear(img, w, h, sx + 0.5f, sy + 0.5f);
-            }
-            continue;
-        }
-        const int bx0 = __builtin_amdgcn_readfirstlane((int)bxf), by0 = __builtin_amdgcn_readfirstlane((int)byf);
-        const int bw = __builtin_amdgcn_readfirstlane((int)bwf), bh = __builtin_amdgcn_readfirstlane((int)bhf);
-        // the previous quadrant's LDS reads have returned before its texels are overwritten (LDS-DMA writes do not queue
-        // behind ds_read instructions)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (bx0 >= 0 && bx0 + kQuadBox <= w && by0 >= 0 && by0 + bh <= h) {
-            // Inside the level (MirroredRepeat is the identity) with room for full-width rows: the box is copied
-            // kQuadBox texels wide whatever bw is, 16 bytes per lane -- 12 lanes cover a row (the LDS pitch is exactly their
-            // 192 bytes), so one request moves five rows, and a quadrant takes at most ten of them.  Global addresses
-            // are only 4-byte aligned (gfx950 runs in unaligned access mode).
-            const int sub = lane / 12, chunk = lane - 12 * sub;
-            const float *src = img + (long)by0 * w + bx0;   // uniform
-            const long lane_off = (long)sub * w + 4 * chunk;
-            if (sub < 5) {
-                for (int r = 0; r < bh; r += 5)
-                    if (r + sub < bh) lds_dma16(src + (long)r * w + lane_off, box + r * kQuadBox);
-            }
-        } else if (bx0 >= 0 && bx0 + bw <= w && by0 >= 0 && by0 + bh <= h) {   // inside, but too close to the right edge
-            if (lane < bw) {
-                const float *src = img + (long)by0 * w + bx0;   // uniform; the lane offset is added by the load
-                for (int r = 0; r < bh; ++r) lds_dma4(src + (long)r * w + lane, box + r * kQuadBox);
-            }
-        } else {
-            if (lane < bw) {
-                const int gx = mirror_idx(bx0 + lane, w);
-                for (int r = 0; r < bh; ++r) lds_dma4(img + (long)mirror_idx(by0 + r, h) * w + gx, box + r * kQuadBox);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int lx = px0 + col, ly = py0 + 4 * i + row4;
-            const float dx = (float)lx - 16.f, dy = (float)ly - 16.f;
-            const float xx = dx * ca - dy * sa, yy = dx * sa + dy * ca;
-            const float sx = xx * rem + kp[0] * inv, sy = yy * rem + kp[1] * inv;
-            // tex_bilinear(img, w, h, sx + 0.5f, sy + 0.5f) with the texels read from the box
-            const float fu = (sx + 0.5f) - 0.5f, fv = (sy + 0.5f) - 0.5f;
-            const float x0f = floorf(fu), y0f = floorf(fv);
-            const float ax = fu - x0f, ay = fv - y0f;
-            int ix = (int)x0f - bx0, iy = (int)y0f - by0;
-            ix = ix < 0 ? 0 : (ix > bw - 2 ? bw - 2 : ix);   // never binding (margin); keeps the LDS reads in range
-            iy = iy < 0 ? 0 : (iy > bh - 2 ? bh - 2 : iy);
-            const float *t = box + iy * kQuadBox + ix;
-            const float t00 = t[0], t10 = t[1], t01 = t[kQuadBox], t11 = t[kQuadBox + 1];
-            const float top = t00 * (1.f - ax) + t10 * ax;
-            const float bot = t01 * (1.f - ax) + t11 * ax;
-            dst[ly * 32 + lx] = top * (1.f - ay) + bot * ay;
-        }
-    }
-}
-
-
 void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                            const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
                            float *patches, hipStream_t stream) {
     if (n <= 0) return;
-    // LF_MKD_SAMPLER=gather selects the gather form (same bits; kept for A/B timing and as a cross-check in the tests)
-    static const bool gather = [] { const char *e = getenv("LF_MKD_SAMPLER"); return e && e[0] == 'g'; }();
-    if (gather)
-        hipLaunchKernelGGL(sample_patches, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, pyr, pyr_stride, pd, kps,
-                           frame_of_kp, n, n_dev, psf, patches);
-    else
-        hipLaunchKernelGGL(sample_patches_lds, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, pyr, pyr_stride, pd,
-                           kps, frame_of_kp, n, n_dev, psf, patches);
+    hipLaunchKernelGGL(sample_patches, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, pyr, pyr_stride, pd, kps,
+                       frame_of_kp, n, n_dev, psf, patches);
 }
 
 // Builds the pyramids of `frames` frames (image_stride floats apart) into pyr (pyr_stride apart); tmp_a and tmp_b

@@ -77,7 +77,9 @@ def test_configs1_10k_keypoints_on_a_1080p_frame(lfp, torch, oracle):
     pick = np.sort(rng.choice(n, 1000, replace=False))
     # the same keypoints in a request of their own give the same bits
     assert np.array_equal(h.describe_keypoints(k5[pick]), d[pick])
-    assert_keypoint_parity(oracle, h, img, k5[pick], d[pick], what="configs[1]")
+    # (sample coordinates reach 1920: one ulp there is 1.2e-4 texel, and the two sides round their sin / cos / exp2
+    #  differently -- the sampled values agree to that times the local slope)
+    assert_keypoint_parity(oracle, h, img, k5[pick], d[pick], what="configs[1]", patch_tol=5e-5)
 
 
 def test_configs0_match_images_on_the_reference_photographs(lfp, oracle):

@@ -162,28 +162,6 @@ def test_keypoint_mode_vs_oracle_larger_frame(lfp, oracle):
     assert_keypoint_parity(oracle, lf._inner, img, k5, d)
 
 
-def test_lds_sampler_and_gather_sampler_give_the_same_bits(tmp_path):
-    """The sampler stages texels through LDS (sample_patches_lds); the gather form it replaced is kept behind
-    LF_MKD_SAMPLER=gather.  Same arithmetic, so the same bits -- on interior keypoints, on footprints that hang over the
-    level's edge (MirroredRepeat while copying), on sizes beyond both ends of the pyramid and on non-finite keypoints
-    (finite results or not, the two must agree and nothing may fault)."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tool = os.path.join(root, "tools", "sample_dump.py")
-    for size in ((333, 257), (1920, 1080), (40, 36)):
-        outs = []
-        for mode in ("lds", "gather"):
-            f = tmp_path / f"{mode}_{size[0]}.npy"
-            env = dict(os.environ, LF_MKD_SAMPLER=mode)
-            subprocess.check_call([sys.executable, tool, str(f), str(size[0]), str(size[1])], env=env, timeout=300)
-            outs.append(np.load(f))
-        a, b = outs
-        assert a.shape == b.shape and len(a) > 4000
-        same = (a == b) | (np.isnan(a) & np.isnan(b))
-        assert same.all(), (size, int((~same).sum()), np.argwhere(~same)[:5])
-        assert np.isfinite(a[:3000]).all() and (a[:3000] != -7.0).all()      # every pixel written
-
-
 def test_pyramid_levels_are_bit_exact(lfp, oracle):
     """Every level of the patch pyramid equals the oracle's bit for bit (blur, a-trous, blits and the binomial
     decimation are evaluated in the shader's operation order, without fma contraction)."""

@@ -55,7 +55,8 @@ def run(w, h, nk, frames, tag):
 def run_batched(w, h, nk, frames, tag):
     """all frames in one set_images + one describe_keypoints_frames call"""
     n = nk * frames
-    hnd = lfp.MkdHandle(max_features=n, max_image_width=w, max_image_height=h, pool_mode=lfp.POOL_F16X3, max_frames=frames)
+    hnd = lfp.MkdHandle(max_features=n, max_image_width=w, max_image_height=h, pool_mode=lfp.POOL_F16X3, max_frames=frames,
+                        flags=int(os.environ.get("LF_KP_FLAGS", "0")))
     s = torch.cuda.current_stream().cuda_stream
     imgs = torch.stack([frame(h, w, 100 + (f % 8)) for f in range(frames)]).contiguous()
     base = [np.concatenate([random_keypoints(nk, w, h, 200 + f, margin=8.0), np.zeros((nk, 1), np.float32)], axis=1) for f in range(8)]
