@@ -151,6 +151,52 @@ def pipeline_extras(lfp, torch, device):
         out["matcher_65536x65536"] = {"ms": ms, "similarities_per_s": n * n / (ms * 1e-3),
                                       "f16_mfma_pflops": n * n * 128 * 2 * 3 / (ms * 1e-3) / 1e15}
         del hnd, a, b, mt
+        # keypoint mode, describe only: pyramid + sampling + describe of GIVEN keypoints, with the algorithmic
+        # bytes of that mode: 16 B keypoint + 512 B descriptor + the frame's bytes spread over its keypoints
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from gen_golden import random_keypoints
+        import numpy as np
+        kp_traffic = {}
+        try:
+            kj = json.load(open(os.path.join(ROOT, "profiles", "traffic_keypoint_mode.json")))
+            if kj.get("source_sha256") == keypoint_source_stamp():
+                kp_traffic = kj.get("hbm_bytes_per_call", {})
+        except Exception:
+            kp_traffic = {}
+        for tag, w, h, nk, nf, iters in (("configs1_1080p_10k_keypoints", 1920, 1080, 10000, 1, 30),
+                                         ("configs2_256x640x480_2k_keypoints", 640, 480, 2000, 256, 5)):
+            n = nk * nf
+            hnd = lfp.MkdHandle(max_features=n, max_image_width=w, max_image_height=h, max_frames=nf, device=device)
+            imgs = frames(nf, h, w, 2.0, 11)
+            base = [np.concatenate([random_keypoints(nk, w, h, 200 + f, margin=64.0 if nf == 1 else 8.0),
+                                    np.zeros((nk, 1), np.float32)], axis=1) for f in range(min(nf, 8))]
+            kps = torch.from_numpy(np.concatenate([base[f % len(base)] for f in range(nf)]).astype(np.float32)).cuda()
+            fid = torch.arange(nf, device="cuda", dtype=torch.int32).repeat_interleave(nk).contiguous()
+            o = torch.empty((n, 128), device="cuda")
+
+            def one():
+                hnd.set_images_device(imgs.data_ptr(), nf, w, h, s)
+                hnd.describe_keypoints_frames_device(kps.data_ptr(), fid.data_ptr(), n, o.data_ptr(), s)
+            for _ in range(2):
+                one()
+            side.synchronize()
+            torch.cuda.synchronize()       # the library's second stream too
+            e0.record(side)
+            for _ in range(iters):
+                one()
+            e1.record(side)
+            side.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+            alg = n * (16 + 512) + nf * w * h * 4
+            ach = alg / (ms * 1e-3) / 1e9
+            out[f"keypoint_mode_{tag}"] = {
+                "ms_per_call": ms, "descriptors_per_s": n / (ms * 1e-3),
+                "what": "set_images (pyramid) + sample + describe of given keypoints, one call per batch",
+                "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                             "traffic": kp_traffic.get(tag), "algorithmic_bytes_per_call": alg,
+                             "algorithmic_bytes_per_descriptor": alg / n,
+                             "kernels": "pyr_* + sample_patches + mkd_pool (the patches cross HBM between the last two)"}}
+            del hnd, imgs, kps, fid, o
         # patch mode at the keypoint counts of configs[1] and configs[2]: the same describe call, smaller n
         for n in (10000, 512000):
             g = torch.Generator(device="cuda").manual_seed(10)
@@ -245,6 +291,14 @@ def source_stamp():
     import hashlib
     hsh = hashlib.sha256()
     for f in ("mkd_describe.hip", "mkd_device.h"):
+        hsh.update(open(os.path.join(ROOT, "local-features_amd", "csrc", f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def keypoint_source_stamp():
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in ("mkd_describe.hip", "mkd_pyramid.hip", "mkd_device.h", "lf_mkd.cpp"):
         hsh.update(open(os.path.join(ROOT, "local-features_amd", "csrc", f), "rb").read())
     return hsh.hexdigest()[:16]
 

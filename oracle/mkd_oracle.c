@@ -269,9 +269,11 @@ static void blur_patch(const float *patch, float *blur, int contract)
         }
 }
 
-/* Number of pixels of a patch that sit on atan2.glsl's discontinuity: gy != 0 and |gx| <= tol (a few ulps of the
- * blurred values), evaluated both ways the blur may round.  A descriptor of such a patch is decided by last-bit
- * rounding the reference leaves to its GLSL compiler; parity tests hold those patches to the contracted variant
+/* Number of pixels of a patch that sit on atan2.glsl's discontinuity: |gx| <= tol (a few ulps of the blurred values)
+ * in either of the two ways the blur may round.  At gx == 0 the shader's angle is 0 whatever gy is, next to it the angle
+ * is +-pi/2 (gy != 0), or pi for a gx just below zero with gy == 0 -- so every such pixel counts, except the one case in
+ * which nothing can flip: a gradient that is exactly null in both readings.  A descriptor of such a patch is decided by
+ * last-bit rounding the reference leaves to its GLSL compiler; parity tests hold those patches to the contracted variant
  * when the input bits are shared and set them aside when they are not. */
 int mkd_oracle_quirk_pixels(const float *patch, float tol)
 {
@@ -281,14 +283,15 @@ int mkd_oracle_quirk_pixels(const float *patch, float tol)
     int n = 0;
     for (int y = 0; y < PS; y++)
         for (int x = 0; x < PS; x++) {
-            int hit = 0;
+            int near = 0, null_both = 1;
             for (int v = 0; v < 2; v++) {
                 const float *b = blur[v];
                 const float gx = b[y * PS + clampi(x, 1, PS - 1) - 1] - b[y * PS + clampi(x, 0, PS - 2) + 1];
                 const float gy = b[(clampi(y, 0, PS - 2) + 1) * PS + x] - b[(clampi(y, 1, PS - 1) - 1) * PS + x];
-                hit |= gy != 0.f && fabsf(gx) <= tol;
+                near |= fabsf(gx) <= tol;
+                null_both &= gx == 0.f && gy == 0.f;
             }
-            n += hit;
+            n += near && !null_both;
         }
     return n;
 }

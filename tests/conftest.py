@@ -52,25 +52,38 @@ def golden(name):
 # compiler (no `precise`; mul+add may or may not become fma).  About 2 in 1000 random patches hold such a pixel.
 # The HIP kernel evaluates the blur as an fma chain in the shader's tap order, i.e. oracle mode BLUR_CONTRACT:
 #   * same input bits  -> every descriptor must meet the gate against the contracted oracle, and every descriptor of a
-#     patch without such a pixel must meet it against the uncontracted oracle too;
-#   * different input bits (keypoint mode: the sampler rounds differently) -> descriptors of patches with such a pixel,
+#     patch on which the two readings agree (`settled`) must meet it against the uncontracted oracle too;
+#   * different input bits (keypoint mode: the sampler rounds differently) -> descriptors of unsettled patches,
 #     in either side's patch, are set aside (and must be few).
 GATE = 1e-4
 
 
-def assert_patch_parity(oracle, patches, desc, atan_mode, gate=GATE, what=""):
+def settled(oracle, patches, atan_mode, gate=GATE):
+    """(mask of patches on which the reference's two readings of the blur give the same descriptor, the contracted and
+    the uncontracted descriptors).  Unsettled are: patches with a pixel on the shader's gx == 0 discontinuity, and --
+    a second, milder way in which the blur's last bit reaches the descriptor -- patches in which a pixel whose gradient is
+    null up to rounding (a critical point of the blurred patch: its angle is rounding noise, its magnitude still the floor
+    0.01) carries visible weight, i.e. low-contrast patches; told by the two readings themselves differing by more than
+    a quarter of the gate."""
     from oracle import ATAN_SHADER, BLUR_CONTRACT
+    ref_c = oracle.describe_patches(patches, atan_mode=atan_mode | BLUR_CONTRACT, nthreads=8)
+    ref_s = oracle.describe_patches(patches, atan_mode=atan_mode, nthreads=8)
+    ok = oracle.quirk_pixels(patches) == 0 if atan_mode == ATAN_SHADER else np.ones(len(patches), bool)
+    return ok & (rel_l2(ref_c, ref_s) < gate / 4), ref_c, ref_s
+
+
+def assert_patch_parity(oracle, patches, desc, atan_mode, gate=GATE, what="", min_settled=0.97):
     patches = np.asarray(patches, np.float32).reshape(-1, 32, 32)
-    e_c = rel_l2(desc, oracle.describe_patches(patches, atan_mode=atan_mode | BLUR_CONTRACT, nthreads=8))
+    clean, ref_c, ref_s = settled(oracle, patches, atan_mode, gate)
+    e_c = rel_l2(desc, ref_c)
     assert e_c.max(initial=0.0) < gate, (what, "contracted", int(e_c.argmax()), e_c.max())
-    e_s = rel_l2(desc, oracle.describe_patches(patches, atan_mode=atan_mode, nthreads=8))
-    clean = oracle.quirk_pixels(patches) == 0 if atan_mode == ATAN_SHADER else np.ones(len(patches), bool)
-    assert clean.mean() > 0.97, (what, clean.mean())
+    e_s = rel_l2(desc, ref_s)
+    assert clean.mean() > min_settled, (what, clean.mean())
     assert e_s[clean].max(initial=0.0) < gate, (what, "uncontracted", e_s[clean].max())
     return max(e_c.max(initial=0.0), e_s[clean].max(initial=0.0))
 
 
-def assert_keypoint_parity(oracle, handle, img, kps5, desc, gate=GATE, what="", patch_tol=1e-5):
+def assert_keypoint_parity(oracle, handle, img, kps5, desc, gate=GATE, what="", patch_tol=1e-5, min_settled=0.97):
     """desc = the library's descriptors of keypoints kps5 [n,5] on img (already set on `handle`).
     patch_tol: the sampling positions of the two sides differ by ~1e-5 texel (different libm sin/cos/exp2); on smooth
     test frames that is 1e-6 in the sampled values, on a sharp photograph up to the local gradient times that."""
@@ -87,8 +100,9 @@ def assert_keypoint_parity(oracle, handle, img, kps5, desc, gate=GATE, what="", 
     got_p = d_p.cpu().numpy()
     ref_p = oracle.sample_patches(oracle.build_pyramid(img), w, hgt, kps5[:, :4])
     assert np.abs(got_p - ref_p).max(initial=0.0) < patch_tol, (what, "sampled patches", np.abs(got_p - ref_p).max())
-    assert_patch_parity(oracle, got_p, desc, ATAN_SHADER, gate, what)        # describe stage, shared input bits
-    clean = (oracle.quirk_pixels(got_p) == 0) & (oracle.quirk_pixels(ref_p) == 0)
-    e = rel_l2(desc, oracle.describe_patches(ref_p, nthreads=8))             # end to end
-    assert clean.mean() > 0.97, (what, clean.mean())
+    assert_patch_parity(oracle, got_p, desc, ATAN_SHADER, gate, what, min_settled)   # describe stage, shared input bits
+    clean_ref, _, ref_s = settled(oracle, ref_p, ATAN_SHADER, gate)
+    clean = settled(oracle, got_p, ATAN_SHADER, gate)[0] & clean_ref
+    e = rel_l2(desc, ref_s)                                                  # end to end
+    assert clean.mean() > min_settled, (what, clean.mean())
     assert e[clean].max(initial=0.0) < gate, (what, "end to end", e[clean].max())

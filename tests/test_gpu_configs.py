@@ -106,7 +106,9 @@ def test_configs0_match_images_on_the_reference_photographs(lfp, oracle):
     h = lfp.MkdHandle(max_features=3000, max_image_width=w, max_image_height=hgt, n_scales=5)
     h.set_image(img2)
     pick = np.arange(0, len(got), max(1, len(got) // 512))[:512]
-    assert_keypoint_parity(oracle, h, img2, got[pick], d2[pick], what="houses", patch_tol=1e-4)
+    # (an 8-bit photograph has flat areas -- sky, walls -- where gx is 0 up to the rounding of the bilinear blend: more
+    #  patches than on synthetic frames sit on the shader's gx == 0 discontinuity and are set aside, ~5 %)
+    assert_keypoint_parity(oracle, h, img2, got[pick], d2[pick], what="houses", patch_tol=1e-4, min_settled=0.9)
     # the match lists are the oracle's on the same descriptors
     assert m12 == [(i, int(j)) for i, j in enumerate(oracle.match(d1, d2)[0]) if j >= 0]
     assert m21 == [(i, int(j)) for i, j in enumerate(oracle.match(d2, d1)[0]) if j >= 0]

@@ -99,9 +99,6 @@ def test_webcam_acceptance_rule(lfp, oracle):
     near = {i for i in range(len(a)) if abs(d0[i] - 0.75 * d1[i]) < 2e-6}
     assert {p for p in got if p[0] not in near} == {p for p in want if p[0] not in near}
     assert len(set(got) ^ set(want)) <= 3
-    # the rule is not Lowe's ratio on similarities: the two accept different sets
-    lowe = set(lf.match(a, b))
-    assert lowe != set(got)
 
 
 def test_cross_image_exclusion(lfp, torch, oracle):

@@ -1,11 +1,26 @@
 #!/usr/bin/env python3
-"""Condenses gpurun_out/prof_<tag>/ (tools/profile_round.sh) into profiles/<tag>_summary.md and
-profiles/traffic_latest.json (read back by bench.py for roofline.traffic)."""
-import csv, glob, json, os, sys, collections
+"""Condenses gpurun_out/prof_<tag>/ (tools/profile_round.sh) into profiles/<tag>_summary.md, <tag>_kernel_stats.csv,
+<tag>_keypoint_mode.md and the two traffic files bench.py quotes (profiles/traffic_latest.json,
+profiles/traffic_keypoint_mode.json) -- everything from ONE run of the script, stamped with the sha256 of the kernel
+sources it measured (bench.py prints traffic: null when the sources have changed since)."""
+import csv, glob, hashlib, json, os, shutil, subprocess, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+
+
+def stamp(files):
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(ROOT, "local-features_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+try:
+    head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip()
+except Exception:
+    head = None
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-lines = [f"# rocprofv3 summary {tag}", "", "Command profiled: `python3 bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-extras` (default workload:",
+lines = [f"# rocprofv3 summary {tag}", "", "Command profiled: `python3 bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-extras --no-match` (default workload:",
          "2^20 patches, shader angle mode, f16x3 pooling) on one MI355X via `tools/profile_round.sh`.", ""]
 bench = None
 for l in open(os.path.join(src, "stats.log")):
@@ -48,6 +63,8 @@ if fetch and write:
               f"- total {traffic/1e9:.3f} GB per launch; algorithmic {4608*n/1e9:.3f} GB ({n} descriptors x 4608 B) "
               f"-> ratio {traffic/(4608*n):.2f}", ""]
     json.dump({"tag": tag, "patches": n, "pool": bench["config"]["pool_mode"] if bench else "f16x3",
+               "angle": bench["config"]["angle_mode"] if bench else "shader",
+               "source_sha256": stamp(("mkd_describe.hip", "mkd_device.h")), "git_head_at_summary": head,
                "hbm_bytes_per_launch": traffic, "fetch_kib": fetch["FETCH_SIZE"], "write_kib": write["WRITE_SIZE"],
                "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 wide streaming reads count half)"},
               open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
@@ -77,7 +94,64 @@ if bench:
                              f"{sum(durs[-k:]) / k:.4f} ms.")
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
-for f in stats:
-    import shutil
-    shutil.copy(f, os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))     # the newest run, and only that
 print("\n".join(lines))
+
+# ---- keypoint mode: tools/prof_keypoints.py (configs[2] as one batch: 256 frames 640x480 x 2000 keypoints) ----------
+def newest(sub, pattern):
+    f = sorted(glob.glob(os.path.join(src, sub, "**", pattern), recursive=True), key=os.path.getmtime, reverse=True)
+    return f[0] if f else None
+
+
+kp_stats = newest("kp_stats", "*kernel_stats.csv")
+if kp_stats:
+    n_kp, frames, w, h = 512000, 256, 640, 480
+    calls = 3                                                     # prof_keypoints.py runs the batch three times
+    rows = [r for r in csv.DictReader(open(kp_stats)) if "lfmkd" in r["Name"]]
+    out = [f"# rocprofv3 summary {tag}: keypoint mode", "",
+           "Command profiled: `python3 tools/prof_keypoints.py` -- BASELINE configs[2] as one batch (256 frames 640x480, 2000 given",
+           "keypoints each = 512 000 descriptors; set_images + describe_keypoints_frames, three times) via `tools/profile_round.sh`.", "",
+           "| kernel | calls | avg us | total ms |", "|---|---|---|---|"]
+    total = 0.0
+    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+        name = r["Name"].split("(")[0].replace("void ", "").replace("lfmkd::", "")
+        out.append(f"| `{name}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.2f} |")
+        total += float(r["TotalDurationNs"]) / 1e6
+    out += ["", f"Sum of kernel time per batch: {total / calls:.2f} ms (the sampler of a chunk overlaps the describe kernel of the previous",
+            "one on a second stream, so the wall time per batch is shorter than this sum).", ""]
+
+    def per_kernel(sub, counter):
+        f = newest(sub, "*counter_collection.csv")
+        agg = collections.defaultdict(float)
+        if f:
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == counter:
+                    agg[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("lfmkd::", "")] += float(r["Counter_Value"])
+        return agg
+    fetch, write = per_kernel("kp_fetch", "FETCH_SIZE"), per_kernel("kp_write", "WRITE_SIZE")
+    tcp = per_kernel("kp_tcp", "TCP_TOTAL_CACHE_ACCESSES")
+    if fetch and write:
+        out += ["## HBM traffic per batch (separate `--pmc` passes).  FETCH_SIZE is doubled for `mkd_pool` only: its patch reads are the",
+                "16-byte-per-lane streaming loads the MI355X guide's gfx950 correction is stated for; the sampler's 4-byte gathers and the",
+                "pyramid kernels' 4-byte row reads are other access widths (\"uncalibrated\" in the guide) and are left as counted.", "",
+                "| kernel | FETCH_SIZE KiB | read GB | WRITE_SIZE KiB | written GB | L1 accesses per keypoint |", "|---|---|---|---|---|---|"]
+        tot = 0.0
+        for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) + write.get(k, 0))):
+            corr = 2.0 if k.startswith("mkd_pool") else 1.0
+            rb, wb = fetch.get(k, 0) / calls * 1024 * corr, write.get(k, 0) / calls * 1024
+            tot += rb + wb
+            acc = f"{tcp[k] / calls / n_kp:.0f}" if k in tcp else ""
+            out.append(f"| `{k}` | {fetch.get(k, 0) / calls:.0f} | {rb / 1e9:.3f} | {write.get(k, 0) / calls:.0f} | {wb / 1e9:.3f} | {acc} |")
+        alg = n_kp * (16 + 512) + frames * w * h * 4
+        out += ["", f"Total {tot / 1e9:.2f} GB per batch = {tot / n_kp:.0f} B per descriptor; algorithmic {alg / 1e9:.3f} GB = {alg / n_kp:.0f} B per descriptor",
+                f"(16 B keypoint + 512 B descriptor + frame bytes / keypoints, SURVEY 8d) -> ratio {tot / alg:.1f}: the sampled patches",
+                "(4 KiB per keypoint) are written by `sample_patches` and read back by `mkd_pool`.", ""]
+        json.dump({"tag": tag, "source_sha256": stamp(("mkd_describe.hip", "mkd_pyramid.hip", "mkd_device.h", "lf_mkd.cpp")),
+                   "git_head_at_summary": head,
+                   "hbm_bytes_per_call": {"configs2_256x640x480_2k_keypoints": tot},
+                   "note": "FETCH_SIZE doubled for mkd_pool's 16 B/lane streaming reads only (MI355X_MICROARCH.md); other widths as counted"},
+                  open(os.path.join(ROOT, "profiles", "traffic_keypoint_mode.json"), "w"), indent=1)
+    shutil.copy(kp_stats, os.path.join(ROOT, "profiles", f"{tag}_keypoint_mode_kernel_stats.csv"))
+    open(os.path.join(ROOT, "profiles", f"{tag}_keypoint_mode.md"), "w").write("\n".join(out) + "\n")
+    print("\n".join(out))
