@@ -171,7 +171,6 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     }
     HostConsts hc;
     build_host_consts(pca, hc);
-    LF_CREATE_HIP(upload(&h->dc.phi_cs, hc.phi_cs.data(), hc.phi_cs.size() * 4));
     LF_CREATE_HIP(upload(&h->dc.colmap, hc.colmap.data(), hc.colmap.size() * 2));
     LF_CREATE_HIP(upload(&h->dc.pool_b_f32, hc.pool_b_f32.data(), hc.pool_b_f32.size() * 4));
     LF_CREATE_HIP(upload(&h->dc.pool_b_f16, hc.pool_b_f16.data(), hc.pool_b_f16.size() * 2));
@@ -408,7 +407,7 @@ void lf_mkd_destroy(lf_mkd *h) {
     if (!h) return;
     (void)hipSetDevice(h->params.device);
     (void)hipDeviceSynchronize();   // work of this handle may be in flight on the caller's streams too
-    void *ptrs[] = {h->dc.phi_cs,      h->dc.colmap,     h->dc.pool_b_f32, h->dc.pool_b_f16, h->dc.white_a_f16,
+    void *ptrs[] = {h->dc.colmap,     h->dc.pool_b_f32, h->dc.pool_b_f16, h->dc.white_a_f16,
                     h->dc.white_a_f32, h->dc.white_bias, h->d_patches,     h->d_out,         h->d_kps,
                     h->d_image,        h->d_pyr,         h->d_tmp_a,       h->d_tmp_b,       h->d_coarse,
                     h->d_extrema,      h->d_angles,      h->d_counts,      h->d_kps_out,     h->d_totals,

@@ -47,41 +47,46 @@ float f16_value(uint16_t b) {
     return static_cast<float>(h);
 }
 
-// One packed output column: which spatial kernel, which descriptor slot, which coefficient.
-struct Column {
-    int desc;       // 0..237 or -1 (padding)
+// One column of a LUT tile: which spatial kernel, rotated by which harmonic of phi.
+struct LutColumn {
+    bool used;
     bool polar;     // EP or EC
-    int j;          // kernel index within EP/EC
-    float coef;     // von-Mises coefficient of the in-dim (embedding.glsl:27-32)
+    int j;          // kernel index within EP / EC
+    int k;          // harmonic (von-Mises coefficient c_k; 0 for the m stream)
+    int rot;        // 0: as is, 1: times cos(k phi), 2: times sin(k phi)
 };
 
-Column column_of(int tile, int c) {
-    const int s = kTileStream[tile];
-    Column col{-1, false, 0, 0.f};
-    // in-dim of the stream: m -> 0, cos k -> k, sin k -> k+3 (both for abs and rel streams)
-    int i = 0, k = 0;
-    if (s >= 1 && s <= 3) { k = s; i = k; }
-    if (s >= 4 && s <= 6) { k = s - 3; i = k + 3; }
-    if (s >= 7 && s <= 9) { k = s - 6; i = k; }
-    if (s >= 10 && s <= 12) { k = s - 9; i = k + 3; }
-    col.coef = kVmN3K8[k];
-    // first tile of the stream? (streams with polar columns own two consecutive tiles; m owns three)
-    int first = tile;
-    while (first > 0 && kTileStream[first - 1] == s) --first;
-    const int part = tile - first;
-    const bool has_polar = (s == 0) || s >= 7;
-    const bool has_cart = s <= 6;
-    if (has_polar && part == 0) {  // EP 0..15
-        col = {i * kPolar + c, true, c, col.coef};
-    } else if (has_polar && part == 1) {  // EP 16..24, then (m only) EC 0..6
-        if (c < 9) col = {i * kPolar + 16 + c, true, 16 + c, col.coef};
-        else if (s == 0) col = {kDimsIn * kPolar + (c - 9), false, c - 9, col.coef};
-    } else if (s == 0 && part == 2) {  // m: EC 7, 8
-        if (c < 2) col = {kDimsIn * kPolar + 7 + c, false, 7 + c, col.coef};
-    } else if (has_cart && s != 0) {  // abs streams: EC 0..8
-        if (c < kCart) col = {kDimsIn * kPolar + i * kCart + c, false, c, col.coef};
+LutColumn lut_column(int ut, int c) {
+    LutColumn z{false, false, 0, 0, 0};
+    if (ut == 0) return {true, true, c, 0, 0};                                        // m: EP 0..15
+    if (ut == 1) return c < 9 ? LutColumn{true, true, 16 + c, 0, 0} : LutColumn{true, false, c - 9, 0, 0};   // EP 16..24 | EC 0..6
+    if (ut == 2) return c < 2 ? LutColumn{true, false, 7 + c, 0, 0} : z;               // EC 7, 8
+    const int k = (ut - 3) / 4 + 1, part = (ut - 3) % 4;
+    if (part == 0) return {true, true, c, k, 1};                                       // P0
+    if (part == 1) return {true, true, c, k, 2};                                       // Q0
+    if (part == 2) return c < 9 ? LutColumn{true, true, 16 + c, k, 1} : LutColumn{true, false, c - 9, k, 0};   // R
+    if (c < 9) return {true, true, 16 + c, k, 2};                                      // S
+    return c < 11 ? LutColumn{true, false, 7 + (c - 9), k, 0} : z;
+}
+
+// Packed output column (tile after the epilogue's combine step, slot) -> descriptor index, or -1.
+// Descriptor order (shaders/common.glsl:114-139): polar block [in-dim i][kernel j] (175), then cartesian [i][j] (63);
+// in-dims: 0 = m, k = cos k, k + 3 = sin k.
+int packed_desc(int tile, int c) {
+    const int cart0 = kDimsIn * kPolar;
+    if (tile == 0) return c;
+    if (tile == 1) return c < 9 ? 16 + c : cart0 + (c - 9);
+    if (tile == 2) return c < 2 ? cart0 + 7 + c : -1;
+    const int k = (tile - 3) / 6 + 1, part = (tile - 3) % 6;
+    const int ic = k, is = k + 3;
+    switch (part) {
+        case 0: return ic * kPolar + c;
+        case 1: return is * kPolar + c;
+        case 2: return c < 9 ? ic * kPolar + 16 + c : cart0 + ic * kCart + (c - 9);
+        case 3: return c < 9 ? is * kPolar + 16 + c : cart0 + is * kCart + (c - 9);
+        case 4: return (c == 9 || c == 10) ? cart0 + ic * kCart + 7 + (c - 9) : -1;
+        default: return (c == 9 || c == 10) ? cart0 + is * kCart + 7 + (c - 9) : -1;
     }
-    return col;
 }
 
 }  // namespace
@@ -164,33 +169,36 @@ void build_host_consts(const PcaModel &pca, HostConsts &hc) {
     }
 
     // ---- device layouts ----
-    hc.phi_cs.resize(size_t(kPx) * 2);
-    for (int p = 0; p < kPx; ++p) {
-        hc.phi_cs[2 * p] = float(std::cos(double(hc.gradient_angle[p])));
-        hc.phi_cs[2 * p + 1] = float(std::sin(double(hc.gradient_angle[p])));
-    }
     hc.colmap.assign(kPackedCols, -1);
-    for (int t = 0; t < kTiles; ++t)
-        for (int c = 0; c < kTileCols; ++c) hc.colmap[t * kTileCols + c] = int16_t(column_of(t, c).desc);
-
-    auto lut_value = [&](const Column &col, int px) -> float {
-        if (col.desc < 0) return 0.f;
-        const float e = col.polar ? hc.embedding_polar[size_t(col.j) * kPx + px]
-                                  : hc.embedding_cartesian[size_t(col.j) * kPx + px];
-        return col.coef * e;
+    {
+        std::vector<int> seen(kRaw, 0);
+        for (int t = 0; t < kTiles; ++t)
+            for (int c = 0; c < kTileCols; ++c) {
+                const int d = packed_desc(t, c);
+                hc.colmap[t * kTileCols + c] = int16_t(d);
+                if (d >= 0) ++seen[d];
+            }
+        for (int d = 0; d < kRaw; ++d)
+            if (seen[d] != 1) std::abort();   // every descriptor entry has exactly one packed column
+    }
+    auto lut_value = [&](const LutColumn &col, int px) -> float {
+        if (!col.used) return 0.f;
+        const double e = col.polar ? hc.embedding_polar[size_t(col.j) * kPx + px]
+                                   : hc.embedding_cartesian[size_t(col.j) * kPx + px];
+        const double ph = double(col.k) * double(hc.gradient_angle[px]);
+        const double rot = col.rot == 1 ? std::cos(ph) : (col.rot == 2 ? std::sin(ph) : 1.0);
+        return float(double(kVmN3K8[col.k]) * e * rot);
     };
     hc.pool_b_f32.assign(size_t(kPatch) * kUniqueTiles * 2 * 64 * 4, 0.f);
     hc.pool_b_f16.assign(size_t(kPatch) * kUniqueTiles * 2 * 64 * 8, 0);
     for (int y = 0; y < kPatch; ++y)
         for (int ut = 0; ut < kUniqueTiles; ++ut)
             for (int lane = 0; lane < 64; ++lane) {
-                const Column col = column_of(unique_tile_repr(ut), lane & 15);
-                const Column twin = column_of(unique_tile_twin(ut), lane & 15);
+                const LutColumn col = lut_column(ut, lane & 15);
                 const int q = lane >> 4;
                 for (int e = 0; e < 8; ++e) {
                     const int px = y * kPatch + 8 * q + e;
                     const float v = lut_value(col, px);
-                    if (v != lut_value(twin, px)) std::abort();  // cos/sin twins must share their LUT tile
                     hc.pool_b_f32[(((size_t(y) * kUniqueTiles + ut) * 2 + (e >> 2)) * 64 + lane) * 4 + (e & 3)] = v;
                     const uint16_t hi = f16_bits(v);
                     const uint16_t lo = f16_bits(v - f16_value(hi));  // f16 subnormals survive the MFMA (tools/micro)

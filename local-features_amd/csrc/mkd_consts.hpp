@@ -19,24 +19,27 @@ constexpr int kRaw = 238;       // shaders/common.glsl:33
 constexpr int kOut = 128;       // shaders/common.glsl:20
 
 // Pooling as a GEMM: rows = patches, K = pixels, columns = (stream, kernel) pairs.
-// A "stream" is one per-pixel A-operand value:
-//   0: m | 1..3: m cos(k t) | 4..6: m sin(k t) | 7..9: m cos(k(t+phi)) | 10..12: m sin(k(t+phi))
-// (t = gradient angle, m = sqrt(|grad|); embedding.glsl:34-51,70-77).  A 16-column tile
-// belongs to exactly one stream; 21 tiles cover the 238 outputs (71 % column efficiency).
-constexpr int kStreams = 13;
-constexpr int kTiles = 21;
+// A "stream" is one per-pixel operand value; there are SEVEN:
+//   0: m | 1..3: m cos(k t) | 4..6: m sin(k t)          (t = gradient angle, m = sqrt(|grad|); embedding.glsl:34-51)
+// The reference also embeds the RELATIVE angle t + phi(px) (embedding.glsl:70-77, polar kernels).  phi depends on the
+// pixel only, so its rotation is folded into the LUT instead of into six more streams:
+//   sum_px m cos(k(t+phi)) EP_j = sum_px [m cos kt] (EP_j cos k phi) - [m sin kt] (EP_j sin k phi)
+//   sum_px m sin(k(t+phi)) EP_j = sum_px [m sin kt] (EP_j cos k phi) + [m cos kt] (EP_j sin k phi)
+// Per harmonic k both streams meet the same four LUT tiles of 16 columns:
+//   P0 = EPc[0:16] | Q0 = EPs[0:16] | R = EPc[16:25], EC[0:7] | S = EPs[16:25], EC[7:9], 5 unused
+// (EPc_j = c_k EP_j cos k phi, EPs_j = c_k EP_j sin k phi, EC_j scaled by c_k; c_k the von-Mises coefficient), into 8
+// products; the m stream keeps its 3 tiles.  24 accumulator tiles in the row loop (the two products of relsin[0:16] share
+// one); the epilogue adds / subtracts
+// them into the 21 tiles of packed output columns the whitening consumes.
+constexpr int kStreams = 7;
+constexpr int kAccTiles = 24;     // row loop: 0-2 m | per harmonic h = k-1, base 3 + 7h: cos x P0, sin x Q0, sin x P0 + cos x Q0,
+                                  //           cos x R, sin x R, cos x S, sin x S
+constexpr int kTiles = 21;        // after the epilogue's combine step (what `colmap` and the whitening fragments index):
+                                  // 0-2 m | per harmonic, base 3 + 6h: relcos[0:16] | relsin[0:16] | relcos[16:25],abscos[0:7]
+                                  //        | relsin[16:25],abssin[0:7] | abscos[7:9] in slots 9,10 | abssin[7:9] in slots 9,10
 constexpr int kTileCols = 16;
 constexpr int kPackedCols = kTiles * kTileCols;  // 336
-
-// tile -> stream (device code keeps an identical constexpr table)
-constexpr int kTileStream[kTiles] = {0, 0, 0, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12,
-                                     1, 2, 3, 4, 5, 6};
-
-// The cos and the sin stream of one harmonic meet identical LUT columns (same kernels, same von-Mises
-// coefficient), so a LUT row stores 12 unique tiles: 0-2 m | 3-5 abs k=1..3 | 6-11 rel k=1..3 (2 each).
-constexpr int kUniqueTiles = 12;
-constexpr int unique_tile_repr(int ut) { return ut < 3 ? ut : (ut < 6 ? 15 + (ut - 3) : 3 + (ut - 6)); }   // a tile holding it
-constexpr int unique_tile_twin(int ut) { return ut < 3 ? ut : (ut < 6 ? 18 + (ut - 3) : 9 + (ut - 6)); }   // its sin twin
+constexpr int kUniqueTiles = 15;  // LUT tiles per patch row: 0-2 m | 3 + 4h + {0: P0, 1: Q0, 2: R, 3: S}
 
 struct PcaModel {
     std::vector<float> mean, eigvals, eigvecs;  // [238], [238], [238*238] row-major
@@ -54,13 +57,12 @@ struct HostConsts {
     std::vector<float> w_t;                  // [128][238]  scaled eigenvectors, transposed
 
     // device layouts
-    std::vector<float> phi_cs;      // [1024][2] cos(phi), sin(phi)
-    std::vector<int16_t> colmap;    // [336] packed column -> descriptor index (0..237) or -1
+    std::vector<int16_t> colmap;    // [336] packed column (after the combine step) -> descriptor index (0..237) or -1
     // f32 pooling fragments for v_mfma_f32_16x16x4_f32:
-    //   [row y 32][unique tile 12][jg 2][lane 64][e 4] = coef * E_col(lane&15)[y][8*(lane>>4) + 4*jg + e]
+    //   [row y 32][unique tile 15][jg 2][lane 64][e 4] = LUT_col(lane&15)[y][8*(lane>>4) + 4*jg + e]
     std::vector<float> pool_b_f32;
     // f16 hi/lo pooling fragments for v_mfma_f32_16x16x32_f16 (B[k][col], k = 8*(lane>>4)+e):
-    //   [row y 32][unique tile 12][hi|lo 2][lane 64][e 8] (uint16 bit patterns); v = hi + lo, both f16
+    //   [row y 32][unique tile 15][hi|lo 2][lane 64][e 8] (uint16 bit patterns); v = hi + lo, both f16
     std::vector<uint16_t> pool_b_f16;
     // Whitening as out^T = W_T x raw with the pooling accumulators as B operand: a lane (patch p, q) holds
     // packed columns 16t + 4q + i in accumulator (t, i).  A fragments = rows of W_T, K ordered to match:

@@ -32,21 +32,26 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 pk_set(float v) { return f32x2{v, v}; }
 
-constexpr int kTiles = 21;   // accumulator tiles (16 packed columns each), see mkd_consts.hpp
-// Accumulator tile numbering: m 0-2 | rel cos k 3+2(k-1).. | rel sin k 9+2(k-1).. | abs cos k 14+k | abs sin k 17+k.
-// The cos and sin streams of one harmonic meet the same LUT columns, so a LUT row holds 12 unique tiles:
-//   0-2 m | 3-5 abs k=1..3 | 6-11 rel k=1..3 (two tiles each).
-constexpr int kUniqueTiles = 12;
+// Seven per-pixel streams -- m, and m cos / sin (k theta) for k = 1..3 -- are pooled; the rotation by gradient_angle(px)
+// that the polar kernels' streams carry (embedding.glsl:70-72) is folded into the LUT (mkd_consts.hpp):
+//   LUT tiles of a patch row: 0-2 m | per harmonic h = k-1, 3 + 4h + {0: P0 = EPc[0:16], 1: Q0 = EPs[0:16],
+//                                      2: R = EPc[16:25] | EC[0:7], 3: S = EPs[16:25] | EC[7:9]}
+//   accumulator tiles of the row loop: 0-2 m | base 3 + 7h: cos x P0 | sin x Q0 | sin x P0 + cos x Q0 (one tile: both
+//                                      products of relsin[0:16]) | cos x R | sin x R | cos x S | sin x S
+//   packed output tiles after the epilogue's combine step (colmap, whitening fragments): 21, see combine_tiles.
+constexpr int kAccTiles = 24;
+constexpr int kTiles = 21;
+constexpr int kUniqueTiles = 15;
+constexpr int kLutPieces = 2 * kUniqueTiles;   // 1 KiB pieces per LUT row
 
 // 5-tap sigma=0.7 kernel, patch_gradients.glsl:22-28
 constexpr float kB0 = 0.0096f, kB1 = 0.2054f, kB2 = 0.5699f;
 
 // LDS map of the pooling kernel (bytes)
-constexpr int kRowBytes = kUniqueTiles * 2 * 1024;   // 24576: one LUT row image, 2 x 1 KiB pieces per tile
-constexpr int kPhiOff = 2 * kRowBytes;               // cos/sin(phi) table, 8 KiB
-constexpr int kRingOff = kPhiOff + 8192;             // raw patch rows: [wave 8][slot 6][2 KiB]
+constexpr int kRowBytes = kLutPieces * 1024;          // 30720: one LUT row image, 2 x 1 KiB pieces per tile
+constexpr int kRingOff = 2 * kRowBytes;              // raw patch rows: [wave 8][slot 6][2 KiB]
 constexpr int kRingSlots = 6;
-// total: kRingOff + waves * kRingSlots * 2048 = 155648 B for 8 waves, 106496 B for 4
+// total: kRingOff + waves * kRingSlots * 2048 = 159744 B for 8 waves, 110592 B for 4
 
 __device__ __forceinline__ float lane_fetch(int byte_addr, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
@@ -70,15 +75,17 @@ __device__ __forceinline__ void lds_dma16_sv(const unsigned char *uniform_base, 
 // hipcc then selects the SGPR-base form `global_load_lds_dwordx4 v_off, s[base:base+1]`, which costs no 64-bit VALU add and
 // no VGPR pair per request (written as per-lane pointer + uniform offset, every request carried its own v_lshl_add_u64
 // and the hoisted address pairs were spilled).
-// one LUT row (24 pieces) into an LDS row buffer, 24 / W pieces per wave
+// one LUT row (30 pieces) into an LDS row buffer, piece p by wave p mod W (the first waves take one piece more)
 template <int W>
 __device__ __forceinline__ void issue_lut_row(const unsigned char *__restrict__ lut_rows, int row,
                                               unsigned char *lds_row, int wave, int lane) {
     const unsigned lane16 = (unsigned)lane * 16u;
 #pragma unroll
-    for (int j = 0; j < 24 / W; ++j) {
-        const unsigned char *g = lut_rows + ((size_t)row * kRowBytes + (size_t)(wave + W * j) * 1024);   // uniform
-        lds_dma16_sv(g, lane16, lds_row + (wave + W * j) * 1024);
+    for (int j = 0; j < (kLutPieces + W - 1) / W; ++j) {
+        if (wave + W * j < kLutPieces) {   // uniform
+            const unsigned char *g = lut_rows + ((size_t)row * kRowBytes + (size_t)(wave + W * j) * 1024);   // uniform
+            lds_dma16_sv(g, lane16, lds_row + (wave + W * j) * 1024);
+        }
     }
 }
 
@@ -88,7 +95,7 @@ __device__ __forceinline__ void issue_lut_row(const unsigned char *__restrict__ 
 // can be requested into buffer 0 while the last step is still being consumed).
 constexpr int kWStepBytes = 16384;
 __device__ __forceinline__ constexpr int wstage_slot(int step) { return step % 3 == 0 ? 0 : (step % 3 == 1 ? 32768 : 16384); }
-static_assert(wstage_slot(0) + kWStepBytes <= kRowBytes && wstage_slot(10) >= kRowBytes && 3 * kWStepBytes <= 2 * kRowBytes, "");
+static_assert(wstage_slot(0) + kWStepBytes <= kRowBytes && wstage_slot(10) >= kRowBytes && wstage_slot(10) + kWStepBytes <= 2 * kRowBytes, "");
 
 template <int W>
 __device__ __forceinline__ void issue_w_step(const unsigned char *__restrict__ wfrag, int step, unsigned char *lds,
@@ -185,14 +192,13 @@ __device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 r2,
 // f16: hi / lo halves of all 8 pixels (K = 32 MFMAs).  16 B per lane either way.
 struct BFrag { u32x4 p0, p1; };
 
-template <int UT>
-__device__ __forceinline__ BFrag load_b(const unsigned char *brow) {
+__device__ __forceinline__ BFrag load_b(const unsigned char *brow, int ut) {   // ut: a constant after unrolling
     BFrag b;
 #ifdef LF_ABLATE_BLOAD  // timing-only build: no LUT fragment reads
-    b.p0 = u32x4{(unsigned)UT, 1u, 2u, 3u}; b.p1 = b.p0; return b;
+    b.p0 = u32x4{(unsigned)ut, 1u, 2u, 3u}; b.p1 = b.p0; return b;
 #endif
-    b.p0 = *reinterpret_cast<const u32x4 *>(brow + (UT * 2 + 0) * 1024);
-    b.p1 = *reinterpret_cast<const u32x4 *>(brow + (UT * 2 + 1) * 1024);
+    b.p0 = *reinterpret_cast<const u32x4 *>(brow + (ut * 2 + 0) * 1024);
+    b.p1 = *reinterpret_cast<const u32x4 *>(brow + (ut * 2 + 1) * 1024);
     return b;
 }
 
@@ -264,18 +270,6 @@ __device__ __forceinline__ void mma_part(const AFrag<POOL> &a, const BFrag &b, f
     }
 }
 
-// cos and sin streams of one harmonic against the NT tiles they share
-template <int POOL, int NT>
-__device__ __forceinline__ void mma_pair(const AFrag<POOL> &ac, const AFrag<POOL> &as, const BFrag (&b)[NT],
-                                         f32x4 *acc_c, f32x4 *acc_s) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { mma_part<POOL, 0>(ac, b[t], acc_c[t]); mma_part<POOL, 0>(as, b[t], acc_s[t]); }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { mma_part<POOL, 1>(ac, b[t], acc_c[t]); mma_part<POOL, 1>(as, b[t], acc_s[t]); }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { mma_part<POOL, 2>(ac, b[t], acc_c[t]); mma_part<POOL, 2>(as, b[t], acc_s[t]); }
-}
-
 // Blurred row of this lane's segment from the raw-row ring (patch_gradients.glsl:72-92): vertical 5 taps over
 // ring slots s0..s0+4, then horizontal 5 taps with the neighbours fetched from lanes -/+16.
 // Returns the row plus its x-1 / x+8 neighbours.
@@ -321,12 +315,13 @@ __device__ __forceinline__ void blur_row(const unsigned char *ring_lane, int s0,
     out_r = has_r ? hr : out[7];
 }
 
-// One orientation family (absolute or relative angle): harmonics k = 1..3 by angle addition; harmonic k
-// uses unique LUT tiles [U0 + NT*(k-1), +NT) and accumulator tiles C0 + NT*(k-1).. (cos), S0 + NT*(k-1).. (sin).
-// `bnext` holds the fragments of harmonic 1 on entry (prefetched by the caller).
-template <int POOL, int NT, int U0, int C0, int S0>
-__device__ __forceinline__ void pool_family(const f32x2 (&m)[4], const f32x2 (&c1)[4], const f32x2 (&s1)[4],
-                                            const unsigned char *brow, BFrag (&b)[NT], f32x4 (&acc)[kTiles]) {
+// Harmonics k = 1..3 of the gradient angle by angle addition, each stream pair against its four LUT tiles.  The 21 matrix
+// instructions of a harmonic (7 accumulators x 3 terms) are issued term by term across the accumulators, so dependent
+// ones are seven apart; `g` holds the fragments of P0 on entry (prefetched by the caller) and P0 of the next harmonic on
+// exit.
+template <int POOL>
+__device__ __forceinline__ void pool_harmonics(const f32x2 (&m)[4], const f32x2 (&c1)[4], const f32x2 (&s1)[4],
+                                               const unsigned char *brow, BFrag &g, f32x4 (&acc)[kAccTiles]) {
     // The recurrence runs on the products themselves, (pk, qk) = m (cos, sin)(k theta), as a three-term (Chebyshev)
     // recurrence x_{k+1} = 2 c1 x_k - x_{k-1} with x_0 = (m, 0): one instruction per stream and harmonic instead of a
     // rotation of the unit vector (two) plus a product.
@@ -338,15 +333,7 @@ __device__ __forceinline__ void pool_family(const f32x2 (&m)[4], const f32x2 (&c
     for (int k = 0; k < 3; ++k) {
         ac.set(pk);
         as.set(qk);
-        BFrag bcur[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bcur[t] = b[t];
-        if (k < 2) {  // fragments of the next harmonic: in flight behind this harmonic's matrix work
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (k == 0) b[t] = load_b<U0 + NT>(brow + t * 2048);
-                else b[t] = load_b<U0 + 2 * NT>(brow + t * 2048);
-            }
+        if (k < 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const f32x2 pn = pk_fma(tc[e], pk[e], k == 0 ? -m[e] : -pp[e]);
@@ -355,8 +342,53 @@ __device__ __forceinline__ void pool_family(const f32x2 (&m)[4], const f32x2 (&c
                 pk[e] = pn; qk[e] = qn;
             }
         }
-        mma_pair<POOL, NT>(ac, as, bcur, &acc[C0 + NT * k], &acc[S0 + NT * k]);
+        const int a0 = 3 + 7 * k, u0 = 3 + 4 * k;
+        const BFrag p0 = g, q0 = load_b(brow, u0 + 1), r = load_b(brow, u0 + 2), sf = load_b(brow, u0 + 3);
+        if (k < 2) g = load_b(brow, u0 + 4);
+        // cos x P0 -> a0 | sin x P0 -> a0+2 | sin x Q0 -> a0+1 | cos x R, sin x R -> a0+3, a0+4 | cos x S, sin x S -> a0+5, a0+6
+        mma_part<POOL, 0>(ac, p0, acc[a0 + 0]); mma_part<POOL, 0>(as, p0, acc[a0 + 2]); mma_part<POOL, 0>(as, q0, acc[a0 + 1]);
+        mma_part<POOL, 0>(ac, r, acc[a0 + 3]); mma_part<POOL, 0>(as, r, acc[a0 + 4]);
+        mma_part<POOL, 0>(ac, sf, acc[a0 + 5]); mma_part<POOL, 0>(as, sf, acc[a0 + 6]);
+        mma_part<POOL, 1>(ac, p0, acc[a0 + 0]); mma_part<POOL, 1>(as, p0, acc[a0 + 2]); mma_part<POOL, 1>(as, q0, acc[a0 + 1]);
+        mma_part<POOL, 1>(ac, r, acc[a0 + 3]); mma_part<POOL, 1>(as, r, acc[a0 + 4]);
+        mma_part<POOL, 1>(ac, sf, acc[a0 + 5]); mma_part<POOL, 1>(as, sf, acc[a0 + 6]);
+        mma_part<POOL, 2>(ac, p0, acc[a0 + 0]); mma_part<POOL, 2>(as, p0, acc[a0 + 2]); mma_part<POOL, 2>(as, q0, acc[a0 + 1]);
+        mma_part<POOL, 2>(ac, r, acc[a0 + 3]); mma_part<POOL, 2>(as, r, acc[a0 + 4]);
+        mma_part<POOL, 2>(ac, sf, acc[a0 + 5]); mma_part<POOL, 2>(as, sf, acc[a0 + 6]);
+        // cos x Q0: the second product of relsin[0:16], into the accumulator of the first
+        mma_part<POOL, 0>(ac, q0, acc[a0 + 2]); mma_part<POOL, 1>(ac, q0, acc[a0 + 2]); mma_part<POOL, 2>(ac, q0, acc[a0 + 2]);
     }
+}
+
+// The 24 accumulator tiles of the row loop -> the 21 tiles of packed output columns (mkd_consts.hpp, packed_desc):
+//   relcos_k = cos x EPc - sin x EPs, relsin_k = sin x EPc + cos x EPs (columns 0-15 in P0 / Q0, 16-24 in slots 0-8 of R / S),
+//   abscos_k / abssin_k = the EC columns: 0-6 in slots 9-15 of R, 7-8 in slots 9-10 of S.
+// Slot of (lane, i) in a tile: 4 (lane >> 4) + i.  Unused slots are set to zero (the norms run over whole tiles).
+__device__ __forceinline__ void combine_tiles(const f32x4 (&a)[kAccTiles], int q, f32x4 (&o)[kTiles]) {
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        const int b = 3 + 7 * h, l = 3 + 6 * h;
+        o[l + 0] = a[b + 0] - a[b + 1];
+        o[l + 1] = a[b + 2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int slot = 4 * q + i;
+            const bool lo9 = slot < 9, s910 = slot == 9 || slot == 10;
+            o[l + 2][i] = a[b + 3][i] - (lo9 ? a[b + 6][i] : 0.f);   // cos x R - sin x S
+            o[l + 3][i] = a[b + 4][i] + (lo9 ? a[b + 5][i] : 0.f);   // sin x R + cos x S
+            o[l + 4][i] = s910 ? a[b + 5][i] : 0.f;
+            o[l + 5][i] = s910 ? a[b + 6][i] : 0.f;
+        }
+    }
+}
+
+// which block of the raw descriptor a packed tile's slots belong to (normalize.glsl: polar | cartesian):
+// 0 = all polar, 1 = all cartesian (or unused = 0), 2 = slots 0-8 polar, 9-15 cartesian
+__device__ __forceinline__ constexpr int tile_block(int t) {
+    if (t < 3) return t == 0 ? 0 : (t == 1 ? 2 : 1);
+    const int part = (t - 3) % 6;
+    return part < 2 ? 0 : (part < 4 ? 2 : 1);
 }
 
 // Epilogue, per wave and batch: acc[t][i] holds the pooled sum of packed column 16t + 4q + i for the lane's
@@ -367,33 +399,34 @@ __device__ __forceinline__ void pool_family(const f32x2 (&m)[4], const f32x2 (&c
 // f16 path: on entry step 0 of the fragments is on its way into its slot (requested by the caller during patch row 31);
 // on exit LUT row 0 of the next batch is on its way into row buffer 0 if `more`.  Every wave of the workgroup must call.
 template <int POOL, int W>
-__device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lane, int wave, bool valid, long patch,
+__device__ __forceinline__ void finish_descriptors(const f32x4 (&acc_row)[kAccTiles], int lane, int wave, bool valid, long patch,
                                                    const short *__restrict__ colmap,
                                                    const unsigned char *__restrict__ wfrag,
                                                    const float *__restrict__ bias, float *__restrict__ out,
                                                    float *__restrict__ raw_out, unsigned char *s_mem,
                                                    const unsigned char *__restrict__ lut_rows, bool more) {
     const int q = lane >> 4;
+    f32x4 acc[kTiles];
+    combine_tiles(acc_row, q, acc);
     if constexpr (POOL == LF_POOL_F16X3) {
         __syncthreads();   // every wave has left patch row 31: row buffer 1 is free too
         issue_w_step<W>(wfrag, 1, s_mem, wave, lane);
         issue_w_step<W>(wfrag, 2, s_mem, wave, lane);
     }
-    // tile 1 mixes polar (packed columns 0-8 of the tile) and cartesian (9-15) kernels of the m stream
-    bool t1_polar[4];
+    // mixed tiles hold polar kernels in packed columns 0-8 and cartesian ones in 9-15
+    bool lo9[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) t1_polar[i] = 4 * q + i < 9;
+    for (int i = 0; i < 4; ++i) lo9[i] = 4 * q + i < 9;
     float sp = 0.f, sc = 0.f;
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bool polar = t == 0 || (t >= 3 && t <= 14) || (t == 1 && t1_polar[i]);
-            if (t == 1) {
+            if (tile_block(t) == 2) {
                 const float v2 = acc[t][i] * acc[t][i];
-                sp += polar ? v2 : 0.f;
-                sc += polar ? 0.f : v2;
-            } else if (polar) {
+                sp += lo9[i] ? v2 : 0.f;
+                sc += lo9[i] ? 0.f : v2;
+            } else if (tile_block(t) == 0) {
                 sp = fmaf(acc[t][i], acc[t][i], sp);
             } else {
                 sc = fmaf(acc[t][i], acc[t][i], sc);
@@ -412,7 +445,7 @@ __device__ __forceinline__ void finish_descriptors(f32x4 (&acc)[kTiles], int lan
     for (int t = 0; t < kTiles; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bool polar = t == 0 || (t >= 3 && t <= 14) || (t == 1 && t1_polar[i]);
+            const bool polar = tile_block(t) == 0 || (tile_block(t) == 2 && lo9[i]);
             acc[t][i] *= polar ? k_p : k_c;
         }
     if (raw_out) {  // verification tap: the 238-D descriptor before whitening
@@ -548,7 +581,6 @@ template <int ANGLE, int POOL, int W>
 __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ patches, long n_host,
                                                 const unsigned long long *__restrict__ n_dev,
                                                 const unsigned char *__restrict__ lut_rows,
-                                                const float *__restrict__ phi_cs,
                                                 const short *__restrict__ colmap,
                                                 const unsigned char *__restrict__ wfrag,
                                                 const float *__restrict__ bias,
@@ -556,11 +588,6 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kRingOff + W * kRingSlots * 2048];
     // number of patches: given by the host, or (graph-captured pipelines) left on the device by the previous stage
     const long n = n_dev ? (long)*n_dev : n_host;
-    float *s_phi = reinterpret_cast<float *>(s_mem + kPhiOff);
-    // (cos, sin) per pixel in the table; in LDS per pixel pair as (cos, cos, sin, sin), so that a 16-byte read lands as
-    // two aligned register pairs (interleaved, every pair cost three v_mov to take apart)
-    for (int i = threadIdx.x; i < 2048; i += 64 * W) s_phi[(i >> 2) * 4 + (i & 1) * 2 + ((i >> 1) & 1)] = phi_cs[i];
-
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = lane & 15, q = lane >> 4;
@@ -609,9 +636,9 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
         const bool more = batch + gridDim.x < nbatch;
         const RawSrc src_next = more ? raw_src(pt, batch + gridDim.x) : src;
 
-        f32x4 acc[kTiles];
+        f32x4 acc[kAccTiles];
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < kAccTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         float cur[8], prv[8], cur_l = 0.f, cur_r = 0.f;  // blurred rows g and g-1 (row -1 replicates row 0)
         int s0 = 1;                                      // ring slot of raw row g-1 (rows g-1..g+3 feed hb(g+1))
 
@@ -636,7 +663,7 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
             else if (POOL == LF_POOL_F16X3)
                 issue_w_step<W>(wf, 0, s_mem, wave, lane);
             par ^= 1;
-            BFrag bm[3] = {load_b<0>(brow), load_b<1>(brow), load_b<2>(brow)};   // m-stream fragments
+            BFrag bm[3] = {load_b(brow, 0), load_b(brow, 1), load_b(brow, 2)};   // m-stream fragments
 
 #ifdef LF_ABLATE_FRONT  // timing-only build: no blur, no gradient direction
 #define blur_row(rl, s, al, ar, hl, hr, o, ol, or_) do { const f32x4 a_ = *reinterpret_cast<const f32x4 *>(rl + (s) * 2048); const f32x4 b_ = *reinterpret_cast<const f32x4 *>(rl + (s) * 2048 + 256); for (int x_ = 0; x_ < 4; ++x_) { o[x_] = a_[x_]; o[4 + x_] = b_[x_]; } ol = o[0]; or_ = o[7]; } while (0)
@@ -698,7 +725,7 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
             LF_PT(2);
 
             // m stream x (polar | cartesian) kernels: accumulator tiles 0-2
-            BFrag babs[1] = {load_b<3>(brow)};
+            BFrag gfrag = load_b(brow, 3);   // first harmonic: P0
             {
                 AFrag<POOL> am;
                 am.set(m);
@@ -710,23 +737,9 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
                 for (int t = 0; t < 3; ++t) mma_part<POOL, 2>(am, bm[t], acc[t]);
             }
             LF_PT(3);
-            // absolute angle x cartesian kernels: unique tiles 3-5, accumulators 15-17 (cos), 18-20 (sin)
-            BFrag brel[2] = {load_b<6>(brow), load_b<7>(brow)};
-            pool_family<POOL, 1, 3, 15, 18>(m, c1, s1, brow, babs, acc);
+            // cos / sin streams of the three harmonics x their four LUT tiles: accumulator tiles 3-23
+            pool_harmonics<POOL>(m, c1, s1, brow, gfrag, acc);
             LF_PT(4);
-            // angle + gradient_angle(px) (embedding.glsl:70-72) x polar kernels: unique tiles 6-11
-            f32x2 d1[4], e1[4];
-            {
-                const f32x4 *pp = reinterpret_cast<const f32x4 *>(&s_phi[(g * 32 + 8 * q) * 2]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const f32x4 t4 = pp[e];   // cos of phi for pixels 2e, 2e+1, then their sines
-                    const f32x2 cp = {t4[0], t4[1]}, sp = {t4[2], t4[3]};
-                    d1[e] = pk_fma(c1[e], cp, -(s1[e] * sp));
-                    e1[e] = pk_fma(s1[e], cp, c1[e] * sp);
-                }
-            }
-            pool_family<POOL, 2, 6, 3, 9>(m, d1, e1, brow, brel, acc);
             LF_PT(5);
         };
         patch_row(std::integral_constant<int, 0>(), 0);
@@ -734,7 +747,7 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
         for (int g = 1; g < 31; ++g) patch_row(std::integral_constant<int, 1>(), g);
         patch_row(std::integral_constant<int, 2>(), 31);
 #ifdef LF_ABLATE_EPILOGUE  // timing-only build
-        { f32x4 sum = acc[0]; for (int t = 1; t < kTiles; ++t) sum += acc[t];
+        { f32x4 sum = acc[0]; for (int t = 1; t < kAccTiles; ++t) sum += acc[t];
           if (base + p < n) *reinterpret_cast<f32x4 *>(out + (base + p) * 128 + 4 * q) = sum;
           if (POOL == LF_POOL_F16X3) { __syncthreads(); if (more) issue_lut_row<W>(lr, 0, s_mem, wave, lane); } }
 #else
@@ -770,7 +783,7 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
     const unsigned char *wf = f16 ? reinterpret_cast<const unsigned char *>(dc.white_a_f16)
                                   : reinterpret_cast<const unsigned char *>(dc.white_a_f32);
 #define LF_LAUNCH_W(A, P, WV)                                                                                          \
-    hipLaunchKernelGGL((mkd_pool<A, P, WV>), dim3(grid), dim3(64 * WV), 0, stream, patches, n, n_dev, lut, dc.phi_cs, \
+    hipLaunchKernelGGL((mkd_pool<A, P, WV>), dim3(grid), dim3(64 * WV), 0, stream, patches, n, n_dev, lut, \
                        dc.colmap, wf, dc.white_bias, out, raw_out)
 #define LF_LAUNCH(A, P)            \
     do {                           \

@@ -25,10 +25,9 @@ struct PyramidDesc {
 
 // Device copies of HostConsts' device layouts (mkd_consts.hpp).
 struct DeviceConsts {
-    float *phi_cs = nullptr;        // [1024][2]
     short *colmap = nullptr;        // [336]
-    float *pool_b_f32 = nullptr;    // [32][12][2][64][4]
-    uint16_t *pool_b_f16 = nullptr; // [32][12][2][64][8]
+    float *pool_b_f32 = nullptr;    // [32][15][2][64][4]
+    uint16_t *pool_b_f16 = nullptr; // [32][15][2][64][8]
     uint16_t *white_a_f16 = nullptr; // [11][8][2][64][8]
     float *white_a_f32 = nullptr;    // [21][4][8][64]
     float *white_bias = nullptr;     // [128]  -W mean

@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 for r in $(seq $ROUNDS); do
   for lib in "$@"; do
     echo "== $lib (round $r)" >> gpurun_out/ab_describe.log
-    LF_MKD_LIB=$(realpath $lib) timeout -k 10 200 python tools/gpu_quick.py 1048576 2>/dev/null | grep "pool=1" >> gpurun_out/ab_describe.log
+    LF_MKD_LIB=$(realpath $lib) timeout -k 10 200 python tools/gpu_quick.py 1048576 2>/dev/null >> gpurun_out/ab_describe.log
   done
 done
 cat gpurun_out/ab_describe.log
