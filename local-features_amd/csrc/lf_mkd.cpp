@@ -594,7 +594,7 @@ int lf_mkd_describe_keypoints_frames_device(lf_mkd *h, const lf_mkd_keypoint *d_
             const uint64_t mc = std::min<uint64_t>(kOverlapChunk, m - c);
             launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(kps + c),
                                   fo ? fo + c : nullptr, long(mc), nullptr, h->params.patch_scale_factor,
-                                  h->d_patches + c * kPx, h->side_stream);
+                                  h->d_patches + c * kPx, h->side_stream, true);
             LF_HIP(h, hipGetLastError());
             ++ev;
             LF_HIP(h, hipEventRecord(h->side_events[ev], h->side_stream));

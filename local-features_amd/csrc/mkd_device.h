@@ -42,7 +42,7 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
 // frame_of_kp == nullptr: every keypoint belongs to frame 0
 void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                            const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
-                           float *patches, hipStream_t stream);
+                           float *patches, hipStream_t stream, bool beside_describe = false);
 void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,
                           float *tmp_b, const PyramidDesc &pd, int frames, float *layer1, long layer1_stride,
                           hipStream_t stream);

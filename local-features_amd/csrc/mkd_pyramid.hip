@@ -5,6 +5,7 @@
 // (paths under local_features/src/vulkan/)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mkd_device.h"
 
@@ -365,12 +366,145 @@ __global__ __launch_bounds__(256) void sample_patches(const float *__restrict__ 
     for (int j = 0; j < 16; ++j) dst[j * 64] = tile[j * 64 + lane];
 }
 
+// The same stage with the texels of INTERIOR footprints staged through LDS.  The gather form above is bound by the
+// texture-address path: 4096 scattered lane-loads per keypoint, ~3500 L1 accesses.  Here the patch is handled in four
+// 16 x 16 pixel quadrants; where the bounding box of a quadrant's footprint (at most 48 x 48 texels for every scale
+// remainder < 2 and every angle) lies inside the pyramid level with room to spare, it is copied into LDS by LDS-DMA --
+// 16 bytes per lane over consecutive addresses, five box rows per request, no registers -- and the four bilinear taps of
+// a sample are two ds_read2_b32.  A quadrant whose box touches the level's border (MirroredRepeat) takes the gather path
+// for its 256 samples.  This form is bound by the instructions it issues, so everything uniform over the wave lives in
+// scalar registers, the copy is five scalar instructions per request, per-lane constants are hoisted out of the sample loop.
+// Arithmetic of a sample (coordinates, floor / fraction, blend) follows the gather form term by term.
+constexpr int kQuadBox = 48;    // texels per box row: >= 15 * 2 * sqrt2 + 5
+constexpr int kQuadRows = 50;   // box rows: ten requests of five
+
+// (uniform base) + (32-bit lane offset): the SGPR-base addressing form, no 64-bit VALU add per request (see the
+// describe kernel's lds_dma16_sv for the two empty asm statements)
+__device__ __forceinline__ void lds_dma16_sv(const unsigned char *uniform_base, unsigned lane_off, void *ldst) {
+    asm("" : "+s"(uniform_base));
+    asm volatile("" : "+v"(lane_off));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uniform_base + lane_off),
+                                     (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void sample_patches_lds(const float *__restrict__ pyr, long pyr_stride, PyramidDesc pd,
+                                                          const float *__restrict__ kps /*[n][5]*/,
+                                                          const unsigned *__restrict__ frame_of_kp, long n_host,
+                                                          const unsigned long long *__restrict__ n_dev, float psf,
+                                                          float *__restrict__ patches) {
+    __shared__ __attribute__((aligned(16))) float s_box[4][kQuadRows * kQuadBox];
+    const long n = n_dev ? (long)*n_dev : n_host;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long k = (long)blockIdx.x * 4 + wave;
+    if (k >= n) return;
+    const int lane = threadIdx.x & 63;
+    if (frame_of_kp) pyr += (long)__builtin_amdgcn_readfirstlane((int)frame_of_kp[k]) * pyr_stride;
+    const float *kp = kps + k * 5;
+    const float scale = kp[2] * psf / 32.f;
+    const float l2 = log2f(scale);
+    float lvl = floorf(l2);
+    lvl = lvl < 0.f ? 0.f : (lvl > (float)(pd.levels - 1) ? (float)(pd.levels - 1) : lvl);
+    const float rem = exp2f(l2 - lvl);
+    int l = (int)lvl;   // a non-finite size (caller-supplied keypoints) must not index outside the pyramid
+    l = l < 0 ? 0 : (l > pd.levels - 1 ? pd.levels - 1 : l);
+    l = __builtin_amdgcn_readfirstlane(l);   // uniform, but computed on the vector side: level geometry into scalar registers
+    const float ang = kp[3] * (3.14159265358979323846f / 180.f);
+    const float ca = cosf(ang), sa = sinf(ang);
+    const float inv = 1.f / exp2f(lvl);
+    const float *img = pyr + pd.offset[l];
+    const int w = pd.w[l], h = pd.h[l];
+    const float cx = kp[0] * inv, cy = kp[1] * inv;
+    float *box = s_box[wave];
+    float *dst = patches + k * 1024;
+    // a step samples 4 patch rows x 16 columns of the quadrant
+    const int col = lane & 15, row4 = lane >> 4;
+    const float colf = (float)col - 16.f, row4f = (float)row4 - 16.f;
+    float *dst_lane = dst + row4 * 32 + col;
+    // copy: lane = (row within a group of five, 16-byte chunk within the row)
+    const int sub = lane / 12, chunk = lane - 12 * sub;
+    const unsigned copy_off = ((unsigned)sub * (unsigned)w + 4u * (unsigned)chunk) * 4u;
+    // A quadrant's samples lie within +-ext of its centre in x and in y (half-size 7.5 pixels, rotated, scaled); with the
+    // +1 neighbour and margin either side (rounding of the centre against the samples' own arithmetic) the box is `bsz`
+    // texels wide and high, the same for the four quadrants.
+    const float ext = 7.5f * rem * (fabsf(ca) + fabsf(sa));
+    const float bszf = floorf(2.f * ext) + 6.f;
+    // (comparisons are false for NaN: a non-finite keypoint takes the gather path)
+    const bool finite = bszf >= 6.f && bszf <= (float)kQuadBox && fabsf(cx) < 1e9f && fabsf(cy) < 1e9f;
+    const int bsz = __builtin_amdgcn_readfirstlane(finite ? (int)bszf : kQuadBox);
+    const int n_req = (bsz + 4) / 5, rows = 5 * n_req;   // rows <= kQuadRows
+    const int n_chunk = (bsz + 3) / 4;                   // 16-byte chunks of a box row that are needed
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int px0 = 16 * (q & 1), py0 = 16 * (q >> 1);
+        // centre of the quadrant (pixel offset 7.5 into it), by the samples' expression
+        const float qdx = (float)px0 - 8.5f, qdy = (float)py0 - 8.5f;
+        const float qx = (qdx * ca - qdy * sa) * rem + cx, qy = (qdx * sa + qdy * ca) * rem + cy;
+        const int bx0 = __builtin_amdgcn_readfirstlane(finite ? (int)floorf(qx - ext) : -1) - 2;
+        const int by0 = __builtin_amdgcn_readfirstlane(finite ? (int)floorf(qy - ext) : -1) - 2;
+        if (!(bx0 >= 0 && bx0 + 4 * n_chunk <= w && by0 >= 0 && by0 + rows <= h)) {   // uniform: the gather path
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+                const int lx = px0 + col, ly = py0 + 4 * i + row4;
+                const float dx = (float)lx - 16.f, dy = (float)ly - 16.f;
+                const float xx = dx * ca - dy * sa, yy = dx * sa + dy * ca;
+                const float sx = xx * rem + kp[0] * inv, sy = yy * rem + kp[1] * inv;
+                dst[ly * 32 + lx] = tex_bilinear(img, w, h, sx + 0.5f, sy + 0.5f);
+            }
+            continue;
+        }
+        // the previous quadrant's LDS reads have returned before its texels are overwritten (LDS-DMA writes do not queue
+        // behind ds_read instructions)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // Inside the level (MirroredRepeat is the identity) with room for full-width rows and whole groups of five:
+        // 12 lanes cover a box row (the LDS pitch is exactly their 192 bytes), one request moves five rows.  Global
+        // addresses are only 4-byte aligned (gfx950 runs in unaligned access mode).
+        if (sub < 5 && chunk < n_chunk) {
+            // (the offset goes through readfirstlane: left to itself hipcc forms part of this address on the vector side)
+            const int first = __builtin_amdgcn_readfirstlane(by0 * w + bx0);   // a level holds < 2^31 texels
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(img + first);   // uniform
+            for (int r = 0; r < n_req; ++r)
+                lds_dma16_sv(src + (long)r * 5 * w * 4, copy_off, box + r * 5 * kQuadBox);
+        }
+        const float a_q = ((float)px0 + colf) * ca, b_q = ((float)px0 + colf) * sa;   // dx ca, dx sa of this lane's column
+        const float bxf = (float)bx0, byf = (float)by0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dy = row4f + (float)(py0 + 4 * i);
+            const float xx = __builtin_fmaf(-dy, sa, a_q), yy = __builtin_fmaf(dy, ca, b_q);
+            const float sx = __builtin_fmaf(xx, rem, cx), sy = __builtin_fmaf(yy, rem, cy);
+            // tex_bilinear(img, w, h, sx + 0.5f, sy + 0.5f) with the texels read from the box
+            const float fu = (sx + 0.5f) - 0.5f, fv = (sy + 0.5f) - 0.5f;
+            const float x0f = floorf(fu), y0f = floorf(fv);
+            const float ax = fu - x0f, ay = fv - y0f;
+            int ix = (int)(x0f - bxf), iy = (int)(y0f - byf);
+            ix = min(max(ix, 0), bsz - 2);   // never binding (margins); keeps the LDS reads inside what was copied
+            iy = min(max(iy, 0), rows - 2);
+            const float *t = box + __umul24(iy, kQuadBox) + ix;   // 24-bit multiply: full rate
+            const float t00 = t[0], t10 = t[1], t01 = t[kQuadBox], t11 = t[kQuadBox + 1];
+            const float top = t00 * (1.f - ax) + t10 * ax;
+            const float bot = t01 * (1.f - ax) + t11 * ax;
+            dst_lane[(py0 + 4 * i) * 32 + px0] = top * (1.f - ay) + bot * ay;
+        }
+    }
+}
+
 void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                            const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
-                           float *patches, hipStream_t stream) {
+                           float *patches, hipStream_t stream, bool beside_describe) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(sample_patches, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, pyr, pyr_stride, pd, kps,
-                       frame_of_kp, n, n_dev, psf, patches);
+    // The LDS-staged form is 10-30 % faster on its own.  Beside the describe kernel (large batches, lf_mkd.cpp) the
+    // all-gather form is used: it leaves the vector ALUs and the LDS to the describe kernel (19 KiB of LDS per workgroup
+    // against 38, so that two of its workgroups fit next to a describe workgroup on a CU), and the pair is 1.5 % faster.
+    // LF_MKD_SAMPLER=gather / lds forces one form everywhere (A/B timing, and the cross-check in the tests).
+    static const int forced = [] { const char *e = getenv("LF_MKD_SAMPLER"); return e ? (e[0] == 'g' ? 1 : (e[0] == 'l' ? 2 : 0)) : 0; }();
+    const bool gather = forced == 1 || (forced == 0 && beside_describe);
+    if (gather)
+        hipLaunchKernelGGL(sample_patches, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, pyr, pyr_stride, pd, kps,
+                           frame_of_kp, n, n_dev, psf, patches);
+    else
+        hipLaunchKernelGGL(sample_patches_lds, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, pyr, pyr_stride, pd,
+                           kps, frame_of_kp, n, n_dev, psf, patches);
 }
 
 // Builds the pyramids of `frames` frames (image_stride floats apart) into pyr (pyr_stride apart); tmp_a and tmp_b

@@ -358,3 +358,27 @@ def test_extreme_patch_values(lfp, oracle):
         assert np.all(np.isfinite(d))
         assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-5)
         assert rel_l2(d[:6], ref[:6]).max() < GATE, (pool, rel_l2(d, ref))
+
+
+def test_the_two_sampler_forms_agree(tmp_path):
+    """The sampler stages the texels of interior footprints through LDS (sample_patches_lds) and gathers the rest; the
+    all-gather form (sample_patches) runs beside the describe kernel in large batches and behind LF_MKD_SAMPLER=gather.
+    Same texels, same weights: they agree to the rounding of the sample coordinates (the two kernels contract the same
+    expressions into different fma's) -- on interior keypoints, footprints over the level's edge, sizes beyond both ends
+    of the pyramid, and non-finite keypoints (finite or not, the two agree and nothing faults)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "sample_dump.py")
+    for size, tol in (((333, 257), 5e-6), ((1920, 1080), 3e-5), ((40, 36), 5e-6)):
+        outs = []
+        for mode in ("lds", "gather"):
+            f = tmp_path / f"{mode}_{size[0]}.npy"
+            subprocess.check_call([sys.executable, tool, str(f), str(size[0]), str(size[1])],
+                                  env=dict(os.environ, LF_MKD_SAMPLER=mode), timeout=300)
+            outs.append(np.load(f))
+        a, b = outs
+        assert a.shape == b.shape and len(a) > 4000
+        assert (np.isfinite(a) == np.isfinite(b)).all(), size
+        fin = np.isfinite(a)
+        assert np.abs(a[fin] - b[fin]).max() < tol, (size, np.abs(a[fin] - b[fin]).max())
+        assert np.isfinite(a[:3000]).all() and (a[:3000] != -7.0).all()      # every pixel written
