@@ -86,6 +86,22 @@ def test_raw_descriptor_statistics_follow_the_reference_pca_models(natural, orac
     assert spread < 0.4, spread
 
 
+def test_whitened_descriptor_spectrum_has_the_attenuation_exponent(natural, oracle):
+    """The whitening is W = eigvecs[:, :128] diag(eigvals^-0.35) (t = 0.7, exponent -0.5 t; vulkan/mod.rs:1604-1612,
+    mkd_ref.rs:61-75): "attenuated" PCA whitening.  On data whose variance along eigenvector k is proportional to
+    eigvals[k] (the test above), output dimension k then has variance proportional to eigvals[k]^(1 - 0.7) = eigvals[k]^0.3
+    (the final L2 normalisation rescales a whole descriptor and leaves the ratios).  On these photographs the variance along
+    eigenvector k follows eigvals[k] with an exponent slightly below 1 (log-spectrum spread 0.22), so the measured slope is
+    0.26; full whitening (exponent -0.5) would give about -0.05, no scaling about 0.95."""
+    patches, _ = natural
+    desc = oracle.describe_patches(patches[::4], nthreads=8).astype(np.float64)
+    var = desc.var(0)
+    slope, _ = np.polyfit(np.log(oracle.eigvals[:128].astype(np.float64)), np.log(var), 1)
+    print(f"log-variance of the whitened descriptor against log eigvals: slope {slope:.3f} (0.3 expected)")
+    assert 0.15 < slope < 0.45, slope
+    assert _spearman(var, oracle.eigvals[:128]) > 0.9
+
+
 def test_the_obvious_misreadings_score_clearly_worse(natural, oracle):
     """Feature order, block order and the sign conventions of the angle are what two restatements by one author could
     get wrong together; each such variant must fit the reference's model clearly worse than the oracle's reading:
