@@ -112,3 +112,43 @@ def test_configs0_match_images_on_the_reference_photographs(lfp, oracle):
     # the match lists are the oracle's on the same descriptors
     assert m12 == [(i, int(j)) for i, j in enumerate(oracle.match(d1, d2)[0]) if j >= 0]
     assert m21 == [(i, int(j)) for i, j in enumerate(oracle.match(d2, d1)[0]) if j >= 0]
+
+
+def test_large_keypoint_batches_run_sampler_and_describe_side_by_side(lfp, torch, oracle):
+    """Batches of >= 65 536 keypoints are chunked: chunk i+1 is sampled on a second stream while chunk i is described
+    (lf_mkd.cpp).  The result must be what the single-stream order gives (LF_MKD_FLAG_NO_OVERLAP) up to the two samplers'
+    rounding, a sample of it what the oracle gives, and repeated calls must agree bit for bit (no race between the streams)."""
+    from conftest import settled
+    from oracle import ATAN_SHADER
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gen_golden import random_keypoints, smooth_image
+    w, hgt, nf, nk = 320, 240, 4, 20000
+    n = nf * nk
+    imgs = np.ascontiguousarray(np.stack([smooth_image(hgt, w, 70 + f) for f in range(nf)]), np.float32)
+    k5 = np.concatenate([np.concatenate([random_keypoints(nk, w, hgt, 80 + f), np.zeros((nk, 1), np.float32)], axis=1)
+                         for f in range(nf)]).astype(np.float32)
+    fid = np.repeat(np.arange(nf, dtype=np.int32), nk)
+    d_img, d_k, d_f = torch.from_numpy(imgs).cuda(), torch.from_numpy(k5).cuda(), torch.from_numpy(fid).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for flags in (0, lfp.FLAG_NO_OVERLAP, 0):
+        h = lfp.MkdHandle(max_features=n, max_image_width=w, max_image_height=hgt, max_frames=nf, flags=flags)
+        out = torch.zeros((n, 128), device="cuda")
+        h.set_images_device(d_img.data_ptr(), nf, w, hgt, s)
+        h.describe_keypoints_frames_device(d_k.data_ptr(), d_f.data_ptr(), n, out.data_ptr(), s)
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+        del h
+    a, b, a2 = outs
+    assert np.array_equal(a, a2)                                           # deterministic across handles and calls
+    assert np.isfinite(a).all() and np.abs(np.linalg.norm(a, axis=1) - 1).max() < 1e-5
+    e = rel_l2(a, b)
+    assert np.quantile(e, 0.995) < 2e-5 and (e > GATE).mean() < 0.005, (np.quantile(e, 0.995), (e > GATE).mean())
+    # a sample of every chunk against the oracle, end to end (patches on which the reference's own readings differ set aside)
+    pick = np.arange(0, n, 160)
+    for f in range(nf):
+        sel = pick[fid[pick] == f]
+        ref_p = oracle.sample_patches(oracle.build_pyramid(imgs[f]), w, hgt, k5[sel, :4])
+        ok, _, ref = settled(oracle, ref_p, ATAN_SHADER)
+        err = rel_l2(a[sel], ref)
+        assert ok.mean() > 0.9 and (err[ok] > GATE).mean() < 0.02, (f, ok.mean(), err[ok].max())
