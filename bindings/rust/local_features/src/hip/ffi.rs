@@ -136,6 +136,7 @@ extern "C" {
                                d_best: *mut f32, d_second: *mut f32, stream: *mut c_void) -> c_int;
     pub fn lf_mkd_match(h: *mut lf_mkd, a: *const f32, na: u64, b: *const f32, nb: u64, ratio: f32,
                         matches: *mut i32) -> c_int;
+    pub fn lf_mkd_match_overflowed(h: *mut lf_mkd, stream: *mut c_void, n_rows: *mut u64) -> c_int;
 
     pub fn lf_mkd_get_coarse_layer(h: *mut lf_mkd, layer: u32, out: *mut f32) -> c_int;
     pub fn lf_mkd_sample_patches_device(h: *mut lf_mkd, d_kps: *const lf_mkd_keypoint, n: u64, d_patches: *mut f32,

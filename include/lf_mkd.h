@@ -251,15 +251,24 @@ int lf_mkd_stream_frame(lf_mkd *h, void *stream);
  * (examples/webcam/src/main.rs:261-265).  d_exclude_lo / d_exclude_hi (may both be NULL): b rows [lo[i], hi[i]) are not candidates for
  * a row i -- the cross-image form of BASELINE configs[3], where b is the all-gathered descriptor set and a row
  * must not match its own image.  nb must be at least 2 (the reference indexes the second-to-last candidate).
- * The similarities are computed on the matrix cores from f16 hi+lo splits of both sides (f32 accumulate,
- * ~2^-21 relative): decisions can differ from an f32 dot product only where two similarities, or best*ratio and
- * second, agree to ~1e-7.  Device pointers, asynchronous on `stream`. */
+ * Two passes: every pair is screened on the matrix cores with the f16 roundings of both sides (error bounded by
+ * ~1e-3 |a||b|, from the rows' norms), every candidate within that bound of a row's second best is re-scored as an f32
+ * dot product, and the decision is taken on the re-scored values: the result is that of an exhaustive f32 scan, and
+ * decisions can differ from the reference's only where two similarities, or best*ratio and second, agree to ~1e-7.
+ * A row with more than 64 such candidates in one lane's share of b (thousands of near-duplicates of its best match)
+ * is redone by a full scan on f16 hi+lo splits (~2^-21 relative) -- inside the same call, decided on the device.
+ * Elements must be finite and below 65504 in magnitude (f16 range).  ~5e12 pairs/s on an MI355X for unit-norm
+ * descriptors; LF_MKD_MATCH=scan in the environment selects the full hi+lo scan alone (~1.7e12 pairs/s).
+ * Device pointers, asynchronous on `stream`. */
 int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d_b, uint64_t nb,
                         const uint32_t *d_exclude_lo, const uint32_t *d_exclude_hi, float ratio,
                         int32_t *d_match, float *d_best, float *d_second, void *stream);
 /* Host pointers, synchronous. */
 int lf_mkd_match(lf_mkd *h, const float *a, uint64_t na, const float *b, uint64_t nb, float ratio,
                  int32_t *match);
+/* Diagnostic: *n_rows = rows of a that the handle's latest match call had to redo by the full scan (0 in the ordinary
+ * case).  Waits for that call to finish (synchronises `stream`, NULL = the handle's own). */
+int lf_mkd_match_overflowed(lf_mkd *h, void *stream, uint64_t *n_rows);
 
 /* The same stage on the reference's own buffer formats, for a caller that keeps the reference's detect graph and host
  * filter and swaps only the extract graph.  Host pointers; synchronous.

@@ -64,6 +64,14 @@ struct lf_mkd {
     float *d_match_part = nullptr, *d_match_in = nullptr;
     int *d_match_out = nullptr;
     uint64_t match_a_cap = 0, match_b_cap = 0, match_part_cap = 0, match_in_cap = 0, match_out_cap = 0;
+    unsigned char *d_match_rec = nullptr;      // two-pass form: candidate records, their counts, |a| per row, two words
+    unsigned char *d_match_cnt = nullptr;      // (largest |b| as float bits, number of overflowed rows)
+    float *d_match_norm = nullptr;
+    unsigned *d_match_misc = nullptr;
+    unsigned char *d_match_few_tiles = nullptr;   // the overflowed rows' own tiles; their indices, exclusion ranges, partials
+    unsigned *d_match_few = nullptr;
+    uint64_t match_rec_cap = 0, match_cnt_cap = 0, match_norm_cap = 0, match_misc_cap = 0, match_few_tiles_cap = 0,
+             match_few_cap = 0;
     int num_cus = 256;
     // LF_MKD_FLAG_KERNEL_TIMING: (start, end) of the describe kernel per batch
     std::vector<hipEvent_t> ev_pending, ev_free;
@@ -415,7 +423,9 @@ void lf_mkd_destroy(lf_mkd *h) {
                     h->d_cube_counts,  h->d_cube_sums,   h->d_sel_count,   h->d_match_a,     h->d_match_b,
                     h->d_orient_sums,  h->d_topk_work,
                     h->d_match_part,   h->d_match_in,    h->d_match_out,   h->d_mf_padded,   h->d_mf_list,
-                    h->d_mf_frame_start, h->d_mf_offsets, h->d_mf_frame_of};
+                    h->d_mf_frame_start, h->d_mf_offsets, h->d_mf_frame_of,
+                    h->d_match_rec,    h->d_match_cnt,   h->d_match_norm,  h->d_match_misc,
+                    h->d_match_few_tiles, h->d_match_few};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
@@ -914,13 +924,57 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
     if (int rc = grow(h, &h->d_match_a, &h->match_a_cap, match_tiles_bytes(long(na)), 1)) return rc;
     if (int rc = grow(h, &h->d_match_b, &h->match_b_cap, match_tiles_bytes(long(nb)), 1)) return rc;
     if (int rc = grow(h, &h->d_match_part, &h->match_part_cap, uint64_t(splits) * na * 3, sizeof(float))) return rc;
-    launch_match_split(d_a, long(na), h->d_match_a, s);
-    launch_match_split(d_b, long(nb), h->d_match_b, s);
     float *p_best = h->d_match_part, *p_second = p_best + uint64_t(splits) * na;
     int *p_index = reinterpret_cast<int *>(p_second + uint64_t(splits) * na);
+    static const bool three_term_only = [] {
+        const char *e = getenv("LF_MKD_MATCH");            // "scan": the three-term scan alone (the round-1 form)
+        return e && e[0] == 's';
+    }();
+    if (three_term_only) {
+        launch_match_split(d_a, long(na), h->d_match_a, nullptr, nullptr, s);
+        launch_match_split(d_b, long(nb), h->d_match_b, nullptr, nullptr, s);
+        launch_match(h->d_match_a, long(na), h->d_match_b, long(nb), d_exclude_lo, d_exclude_hi, ratio, splits, p_best,
+                     p_index, p_second, d_match, d_best, d_second, nullptr, s);
+        LF_HIP(h, hipGetLastError());
+        return LF_MKD_OK;
+    }
+    if (int rc = grow(h, &h->d_match_rec, &h->match_rec_cap, match_record_bytes(long(na), splits), 1)) return rc;
+    if (int rc = grow(h, &h->d_match_cnt, &h->match_cnt_cap, match_count_bytes(long(na), splits), 1)) return rc;
+    if (int rc = grow(h, &h->d_match_norm, &h->match_norm_cap, na, sizeof(float))) return rc;
+    if (int rc = grow(h, &h->d_match_misc, &h->match_misc_cap, 2, sizeof(unsigned))) return rc;
+    if (int rc = grow(h, &h->d_match_few_tiles, &h->match_few_tiles_cap, match_few_tiles_bytes(), 1)) return rc;
+    if (int rc = grow(h, &h->d_match_few, &h->match_few_cap, match_few_words(), sizeof(unsigned))) return rc;
+    LF_HIP(h, hipMemsetAsync(h->d_match_misc, 0, 2 * sizeof(unsigned), s));
+    unsigned *b_max = h->d_match_misc;
+    int *n_over = reinterpret_cast<int *>(h->d_match_misc + 1);
+    launch_match_split(d_a, long(na), h->d_match_a, h->d_match_norm, nullptr, s);
+    launch_match_split(d_b, long(nb), h->d_match_b, nullptr, b_max, s);
+    launch_match_screen(h->d_match_a, long(na), h->d_match_b, long(nb), d_exclude_lo, d_exclude_hi, splits,
+                        h->d_match_norm, b_max, h->d_match_rec, h->d_match_cnt, s);
+    launch_match_verify(d_a, long(na), d_b, h->d_match_norm, b_max, h->d_match_rec, h->d_match_cnt, splits, ratio,
+                        d_match, d_best, d_second, n_over, reinterpret_cast<int *>(h->d_match_few), s);
+    // rows whose records overflowed (more than 64 near-best candidates in one lane's share of b) are redone by the
+    // three-term scan: on their own when they are few, else with everybody; both are enqueued unconditionally and
+    // read the count on the device -- no host round trip, and nothing to do in the ordinary case
+    launch_match_few(d_a, h->d_match_b, long(nb), d_exclude_lo, d_exclude_hi, ratio, n_over, h->d_match_few_tiles,
+                     h->d_match_few, d_match, d_best, d_second, s);
     launch_match(h->d_match_a, long(na), h->d_match_b, long(nb), d_exclude_lo, d_exclude_hi, ratio, splits, p_best,
-                 p_index, p_second, d_match, d_best, d_second, s);
+                 p_index, p_second, d_match, d_best, d_second, n_over, s);
     LF_HIP(h, hipGetLastError());
+    return LF_MKD_OK;
+}
+
+int lf_mkd_match_overflowed(lf_mkd *h, void *stream, uint64_t *n_rows) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!n_rows) return fail(h, LF_MKD_ERR_BAD_ARG, "match_overflowed: null pointer");
+    *n_rows = 0;
+    if (!h->d_match_misc) return LF_MKD_OK;           // no two-pass match yet
+    LF_HIP(h, hipSetDevice(h->params.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    int n = 0;
+    LF_HIP(h, hipMemcpyAsync(&n, h->d_match_misc + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    LF_HIP(h, hipStreamSynchronize(s));
+    *n_rows = uint64_t(n);
     return LF_MKD_OK;
 }
 

@@ -88,9 +88,29 @@ void launch_segments_compact(const float *padded, const unsigned *counts, const 
 // p_* hold splits x na partial results; excl_lo/hi (nullable): b rows [lo[i], hi[i]) are skipped for a row i.
 size_t match_tiles_bytes(long n);
 int match_splits(long na, long nb, int num_cus);
-void launch_match_split(const float *x, long n, unsigned char *tiles, hipStream_t stream);
+// norms [n] (nullable): |x_row| rounded up; max_norm_bits (nullable): running maximum of them as float bits
+void launch_match_split(const float *x, long n, unsigned char *tiles, float *norms, unsigned *max_norm_bits,
+                        hipStream_t stream);
+// the three-term scan; n_over (nullable, device): as the fallback of the two-pass form the launch does nothing unless
+// more rows overflowed than launch_match_few takes
 void launch_match(const unsigned char *a_tiles, long na, const unsigned char *b_tiles, long nb, const unsigned *excl_lo,
                   const unsigned *excl_hi, float ratio, int splits, float *p_best, int *p_index, float *p_second,
-                  int *match, float *best, float *second, hipStream_t stream);
+                  int *match, float *best, float *second, const int *n_over, hipStream_t stream);
+// the same scan over the overflowed rows alone (few_words: their indices first, written by launch_match_verify)
+size_t match_few_tiles_bytes();
+size_t match_few_words();
+void launch_match_few(const float *a, const unsigned char *b_tiles, long nb, const unsigned *excl_lo,
+                      const unsigned *excl_hi, float ratio, const int *n_over, unsigned char *few_tiles, unsigned *few_words,
+                      int *match, float *best, float *second, hipStream_t stream);
+// the two-pass form: screen (one-term scan, candidate records per a row) then verify (exact f32 re-scoring, decision);
+// *n_over (device, zeroed by the caller) counts a rows whose records overflowed
+size_t match_record_bytes(long na, int splits);
+size_t match_count_bytes(long na, int splits);
+void launch_match_screen(const unsigned char *a_tiles, long na, const unsigned char *b_tiles, long nb,
+                         const unsigned *excl_lo, const unsigned *excl_hi, int splits, const float *a_norms,
+                         const unsigned *b_max_norm_bits, void *rec, void *rec_info, hipStream_t stream);
+void launch_match_verify(const float *a, long na, const float *b, const float *a_norms, const unsigned *b_max_norm_bits,
+                         const void *rec, const void *rec_info, int splits, float ratio, int *match, float *best,
+                         float *second, int *n_over, int *over_rows, hipStream_t stream);
 
 }  // namespace lfmkd

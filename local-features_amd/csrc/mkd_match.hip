@@ -9,6 +9,11 @@
 // kernel (hi*hi + lo*hi + hi*lo, f32 accumulate, ~2^-21 relative): both sides are split once by `match_split`
 // into MFMA operand order, so the hot loop only moves fragments.
 //
+// Two passes (the default): SCREEN with the hi*hi term alone (a third of the matrix work), which is within a known
+// margin of the true similarity, recording every candidate that could still be among the two best; VERIFY re-scores the
+// few survivors in f32 and decides.  The result is that of an exact scan (see `screen_margin`); a query whose record list
+// overflows sends the call to the three-term scan below, gated on the device (no host round trip).
+//
 //   workgroup = 8 waves x 64 a rows = 512 a rows, resident in registers (2 x 64 VGPRs of fragments per wave);
 //   b streams through LDS in 32-row tiles (16 KiB, LDS-DMA, double buffered), each tile read once per workgroup;
 //   grid = (a blocks, b splits): a split scans one contiguous range of b tiles and writes partial
@@ -30,6 +35,32 @@ constexpr int kTileRows = 32;                 // rows of a / b per MFMA tile
 constexpr int kTileBytes = 2 * 8 * 2 * 32 * 16;  // [hi|lo][k-step 8][k-half 2][row 32][8 f16] = 16 KiB
 constexpr int kWaves = 8, kATiles = 2;        // per wave: 2 a tiles
 
+}  // namespace
+
+// When the three-term scan runs as the fallback of the two-pass form it is enqueued unconditionally and decides on the
+// device whether it has anything to do: `count` = a rows whose screening records overflowed.
+//   rows == nullptr ("all"):   active when *count > above; scans every a row
+//   rows != nullptr ("few"):   active when 0 < *count <= upto; the a tiles hold only the overflowed rows, rows[j] = the
+//                              a row of compact row j, and *count replaces na
+struct MatchGate {
+    const int *count;
+    const int *rows;
+    int above, upto;
+};
+
+namespace {
+
+__device__ __forceinline__ bool gate_open(const MatchGate &g, long &na) {
+    if (!g.count) return true;
+    const int n = *g.count;
+    if (g.rows) {
+        if (n <= 0 || n > g.upto) return false;
+        na = n;
+        return true;
+    }
+    return n > g.above;
+}
+
 __device__ __forceinline__ void lds_dma16(const void *g, void *l) {
     __builtin_amdgcn_global_load_lds(g, reinterpret_cast<__attribute__((address_space(3))) void *>(
                                             reinterpret_cast<uintptr_t>(l)), 16, 0, 0);
@@ -39,7 +70,9 @@ __device__ __forceinline__ void lds_dma16(const void *g, void *l) {
 
 // x [n][128] f32 -> tiles of 32 rows in MFMA operand order: [tile][part: hi, lo][s 8][h 2][r 32][8 f16], where
 // element j of (s, h, r) is x[32 tile + r][16 s + 8 h + j]; rows beyond n are zero.
-__global__ __launch_bounds__(256) void match_split(const float *__restrict__ x, long n, unsigned char *__restrict__ out) {
+// norms (may be null) receives |x_row| rounded up; max_norm_bits (may be null) the largest of them, as float bits.
+__global__ __launch_bounds__(256) void match_split(const float *__restrict__ x, long n, unsigned char *__restrict__ out,
+                                                   float *__restrict__ norms, unsigned *__restrict__ max_norm_bits) {
     const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);   // 16 threads per row, 8 floats each
     const int c8 = threadIdx.x & 15;                               // k = 8 c8 .. 8 c8 + 7  ->  s = c8 >> 1, h = c8 & 1
     const long tiles = (n + kTileRows - 1) / kTileRows;
@@ -58,6 +91,49 @@ __global__ __launch_bounds__(256) void match_split(const float *__restrict__ x, 
     unsigned char *base = out + tile * kTileBytes + ((s * 2 + h) * 32 + r) * 16;
     *reinterpret_cast<h8 *>(base) = hi;
     *reinterpret_cast<h8 *>(base + kTileBytes / 2) = lo;
+    if (norms || max_norm_bits) {
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss = fmaf(v[j], v[j], ss);
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) ss += __shfl_xor(ss, m, 16);
+        if (c8 == 0 && row < n) {
+            const float nr = sqrtf(ss) * 1.00001f;
+            if (norms) norms[row] = nr;
+            // one address for everybody: ask first, the maximum settles after a few rows
+            if (max_norm_bits && __float_as_uint(nr) > __atomic_load_n(max_norm_bits, __ATOMIC_RELAXED))
+                atomicMax(max_norm_bits, __float_as_uint(nr));
+        }
+    }
+}
+
+// The overflowed rows of a (rows[0 .. *count)), gathered and split into tiles of their own, with their exclusion ranges.
+__global__ __launch_bounds__(256) void match_split_rows(const float *__restrict__ x, const int *__restrict__ rows,
+                                                        const int *__restrict__ count, int upto,
+                                                        const unsigned *__restrict__ excl_lo,
+                                                        const unsigned *__restrict__ excl_hi,
+                                                        unsigned char *__restrict__ out, unsigned *__restrict__ lo_out,
+                                                        unsigned *__restrict__ hi_out) {
+    const int n = *count;
+    if (n <= 0 || n > upto) return;
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int c8 = threadIdx.x & 15;
+    const long tiles = ((long)n + kTileRows - 1) / kTileRows;
+    if (row >= tiles * kTileRows) return;
+    const long src = row < n ? rows[row] : -1;
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = src >= 0 ? x[src * 128 + c8 * 8 + j] : 0.f;
+        hi[j] = (_Float16)v;
+        lo[j] = (_Float16)(v - (float)hi[j]);
+    }
+    const long tile = row / kTileRows;
+    const int r = (int)(row - tile * kTileRows), s = c8 >> 1, h = c8 & 1;
+    unsigned char *base = out + tile * kTileBytes + ((s * 2 + h) * 32 + r) * 16;
+    *reinterpret_cast<h8 *>(base) = hi;
+    *reinterpret_cast<h8 *>(base + kTileBytes / 2) = lo;
+    if (c8 == 0 && src >= 0 && excl_lo) { lo_out[row] = excl_lo[src]; hi_out[row] = excl_hi[src]; }
 }
 
 // partial results: [split][a row]: best value, best index, second value
@@ -65,8 +141,11 @@ __global__ __launch_bounds__(512) void match_scan(const unsigned char *__restric
                                                   const unsigned char *__restrict__ b_tiles, long nb,
                                                   long tiles_per_split, const unsigned *__restrict__ excl_lo,
                                                   const unsigned *__restrict__ excl_hi, float *__restrict__ p_best,
-                                                  int *__restrict__ p_index, float *__restrict__ p_second) {
+                                                  int *__restrict__ p_index, float *__restrict__ p_second,
+                                                  MatchGate gate) {
     __shared__ __attribute__((aligned(16))) unsigned char s_b[2][kTileBytes];
+    if (!gate_open(gate, na)) return;
+    if ((long)blockIdx.x * kWaves * kATiles * kTileRows >= na) return;   // (the grid of the "few" form is sized for its capacity)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
     const long a_tile0 = ((long)blockIdx.x * kWaves + wave) * kATiles;
@@ -187,9 +266,9 @@ __global__ __launch_bounds__(512) void match_scan(const unsigned char *__restric
 __global__ __launch_bounds__(256) void match_merge(const float *__restrict__ p_best, const int *__restrict__ p_index,
                                                    const float *__restrict__ p_second, long na, int splits, float ratio,
                                                    int *__restrict__ match, float *__restrict__ best_out,
-                                                   float *__restrict__ second_out) {
+                                                   float *__restrict__ second_out, MatchGate gate) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= na) return;
+    if (!gate_open(gate, na) || i >= na) return;
     float b = -INFINITY, s = -INFINITY;
     int bi = -1;
     for (int k = 0; k < splits; ++k) {
@@ -200,9 +279,223 @@ __global__ __launch_bounds__(256) void match_merge(const float *__restrict__ p_b
         bi = other ? oi : bi;
         b = other ? ob : b;
     }
-    match[i] = (bi >= 0 && (ratio <= 0.f || b * ratio > s)) ? bi : -1;   // ratio <= 0: no test, the best index as is
-    if (best_out) best_out[i] = b;
-    if (second_out) second_out[i] = s;
+    const long o = gate.rows ? gate.rows[i] : i;
+    match[o] = (bi >= 0 && (ratio <= 0.f || b * ratio > s)) ? bi : -1;   // ratio <= 0: no test, the best index as is
+    if (best_out) best_out[o] = b;
+    if (second_out) second_out[o] = s;
+}
+
+
+// ---- two-pass form ----------------------------------------------------------------------------------------------
+// Screen: s~ = <hi(a), hi(b)> on the matrix cores.  With a = hi(a) + da, |da_k| <= 2^-11 |a_k| (f16 round to nearest;
+// below 2^-14 the f16 grid is 2^-24 wide, the MFMA does not flush) and the same for b,
+//   |s - s~| = |<da, b> + <a, db> - <da, db>| <= (2^-10 + 2^-22) |a||b| + 2^-25 sqrt(128) (|a| + |b|),
+// plus 128 f32 roundings of the accumulation (<= 7.7e-6 |a||b|): eps(a, b) <= 1.01e-3 |a||b| + 2.5e-7 (|a| + |b|).
+// `screen_margin` is 2 eps with |b| replaced by the largest candidate norm.  If u is the second-largest s~ of a query,
+// two candidates have s >= u - eps, so the true best and second best have s >= u - eps and s~ >= u - 2 eps: every
+// candidate with s~ >= u - margin is re-scored exactly, nothing else can be among the two best.  During the scan u is not
+// known yet; a lane's running second-largest only grows towards it, so recording against the running value keeps a
+// superset.
+constexpr int kOverRows = 16384;   // overflowed rows the "few" form of the fallback takes; beyond that every row is redone
+constexpr int kOverSplits = 64;
+constexpr int kRecCap = 64;   // records per stream (one a row x one k-half lane x one b split); ~2.3 ln(rows scanned) expected
+
+__device__ __forceinline__ float screen_margin(float a_norm, float b_norm_max) {
+    return 2.02e-3f * a_norm * b_norm_max + 5e-7f * (a_norm + b_norm_max);
+}
+
+constexpr int kStageTiles = 4;   // b tiles per LDS stage of the screen (one barrier per stage): 4 x 8 KiB, double buffered
+
+__global__ __launch_bounds__(512, 4) void match_screen(const unsigned char *__restrict__ a_tiles, long na,
+                                                       const unsigned char *__restrict__ b_tiles, long nb,
+                                                       long tiles_per_split, const unsigned *__restrict__ excl_lo,
+                                                       const unsigned *__restrict__ excl_hi,
+                                                       const float *__restrict__ a_norms,
+                                                       const unsigned *__restrict__ b_max_norm_bits,
+                                                       uint2 *rec, uint2 *__restrict__ rec_info) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_b[2][kStageTiles][kTileBytes / 2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const long a_tile0 = ((long)blockIdx.x * kWaves + wave) * kATiles;
+    const long a_tiles_total = (na + kTileRows - 1) / kTileRows;
+    const long b_tiles_total = (nb + kTileRows - 1) / kTileRows;
+    const long t_begin = (long)blockIdx.y * tiles_per_split;
+    long t_end = t_begin + tiles_per_split;
+    t_end = t_end < b_tiles_total ? t_end : b_tiles_total;
+    const float b_max = __uint_as_float(*b_max_norm_bits);
+
+    h8 ah[kATiles][8];
+    unsigned lo_x[kATiles], hi_x[kATiles];
+    float margin[kATiles];
+    bool live[kATiles];
+    long stream[kATiles];
+#pragma unroll
+    for (int t = 0; t < kATiles; ++t) {
+        const long at = a_tile0 + t < a_tiles_total ? a_tile0 + t : a_tiles_total - 1;
+        const unsigned char *src = a_tiles + at * kTileBytes + (h * 32 + r) * 16;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) ah[t][s] = *reinterpret_cast<const h8 *>(src + s * 1024);
+        const long arow = at * kTileRows + r;
+        live[t] = a_tile0 + t < a_tiles_total && arow < na;
+        lo_x[t] = excl_lo && arow < na ? excl_lo[arow] : 0u;
+        hi_x[t] = excl_lo && arow < na ? excl_hi[arow] : 0u;
+        margin[t] = live[t] ? screen_margin(a_norms[arow], b_max) : 0.f;
+        stream[t] = (((long)blockIdx.y * na + (live[t] ? arow : 0)) * 2 + h) * kRecCap;
+    }
+    float best[kATiles], second[kATiles], lost[kATiles];
+    int cnt[kATiles];
+#pragma unroll
+    for (int t = 0; t < kATiles; ++t) { best[t] = -INFINITY; second[t] = -INFINITY; lost[t] = -INFINITY; cnt[t] = 0; }
+
+    auto issue = [&](long t, int buf) {   // the hi halves of tiles t .. t + 3: 8 KiB each = 512 threads x 16 B
+#pragma unroll
+        for (int u = 0; u < kStageTiles; ++u)
+            if (t + u < t_end)
+                lds_dma16(b_tiles + (t + u) * kTileBytes + threadIdx.x * 16, &s_b[buf][u][0] + wave * 1024);
+    };
+    auto tile = [&](long t, const unsigned char *bb) {
+        h8 bh[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bh[s] = *reinterpret_cast<const h8 *>(bb + s * 1024);
+        f32x16 acc[kATiles];
+#pragma unroll
+        for (int q = 0; q < kATiles; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int q = 0; q < kATiles; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s], ah[q][s], acc[q], 0, 0, 0);
+        const int row0 = (int)(t * kTileRows) + 4 * h;
+        const bool tail = (t + 1) * kTileRows > nb;
+#pragma unroll
+        for (int q = 0; q < kATiles; ++q) {
+            const bool touch = tail || ((unsigned)(t * kTileRows) < hi_x[q] && (unsigned)((t + 1) * kTileRows) > lo_x[q]);
+            if (__builtin_amdgcn_ballot_w64(touch)) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const unsigned row = (unsigned)(row0 + (i & 3) + 8 * (i >> 2));
+                    if (row >= (unsigned)nb || (row >= lo_x[q] && row < hi_x[q])) acc[q][i] = -INFINITY;
+                }
+            }
+            float m = acc[q][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) m = fmaxf(m, acc[q][i]);
+            if (__builtin_amdgcn_ballot_w64(live[q] && m >= second[q] - margin[q])) {   // rare once the scan is under way
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float v = acc[q][i];
+                    const int row = row0 + (i & 3) + 8 * (i >> 2);
+                    if (live[q] && v > -INFINITY && v >= second[q] - margin[q]) {
+                        // a ring: beyond the capacity the oldest record goes, and the largest value that went is kept --
+                        // verify needs only to know that nothing it would have re-scored was lost
+                        uint2 *slot = rec + stream[q] + (cnt[q] & (kRecCap - 1));
+                        if (cnt[q] >= kRecCap) lost[q] = fmaxf(lost[q], __uint_as_float(slot->x));
+                        *slot = make_uint2(__float_as_uint(v), (unsigned)row);
+                        ++cnt[q];
+                    }
+                    const bool nb_ = v >= best[q] && v > -INFINITY;
+                    const bool ns = !nb_ && v > second[q];
+                    second[q] = nb_ ? best[q] : (ns ? v : second[q]);
+                    best[q] = nb_ ? v : best[q];
+                }
+            }
+        }
+    };
+    if (t_begin < t_end) issue(t_begin, 0);
+    for (long t = t_begin; t < t_end; t += kStageTiles) {
+        const int buf = (int)(((t - t_begin) / kStageTiles) & 1);
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of the stage have landed
+        __syncthreads();                      // ... and everybody's; everybody is also done with the other buffer
+        if (t + kStageTiles < t_end) issue(t + kStageTiles, buf ^ 1);
+#pragma unroll
+        for (int u = 0; u < kStageTiles; ++u)
+            if (t + u < t_end) tile(t + u, &s_b[buf][u][0] + (h * 32 + r) * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < kATiles; ++q)
+        if (live[q]) rec_info[stream[q] / kRecCap] = make_uint2((unsigned)cnt[q], __float_as_uint(lost[q]));
+}
+
+// 16 lanes per a row: the survivors of the screen are re-scored as f32 dot products (each lane 8 elements as an fma
+// chain, then a fixed shuffle tree), best / second / index decided with the scan's tie rule (the later index wins).
+__global__ __launch_bounds__(256) void match_verify(const float *__restrict__ a, long na, const float *__restrict__ b,
+                                                    const float *__restrict__ a_norms,
+                                                    const unsigned *__restrict__ b_max_norm_bits,
+                                                    const uint2 *__restrict__ rec, const uint2 *__restrict__ rec_info,
+                                                    int splits, float ratio, int *__restrict__ match,
+                                                    float *__restrict__ best_out, float *__restrict__ second_out,
+                                                    int *__restrict__ n_over, int *__restrict__ over_rows) {
+    const int l = threadIdx.x & 15, gw = (threadIdx.x >> 4) & 3;
+    const long i = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= na) return;                               // whole 16-lane groups leave together
+    float av[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) av[j] = a[i * 128 + l * 8 + j];
+    const float margin = screen_margin(a_norms[i], __uint_as_float(*b_max_norm_bits));
+
+    // the query's second-largest screened similarity
+    float b1 = -INFINITY, b2 = -INFINITY, lost = -INFINITY;
+    for (int k = 0; k < 2 * splits; ++k) {
+        const long stream = ((long)(k >> 1) * na + i) * 2 + (k & 1);
+        const uint2 info = rec_info[stream];
+        int c = (int)info.x;
+        if (c > kRecCap) lost = fmaxf(lost, __uint_as_float(info.y));
+        c = c < kRecCap ? c : kRecCap;
+        for (int j = l; j < c; j += 16) {
+            const float v = __uint_as_float(rec[stream * kRecCap + j].x);
+            b2 = v > b1 ? b1 : fmaxf(b2, v);
+            b1 = fmaxf(b1, v);
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        const float o1 = __shfl_xor(b1, m, 16), o2 = __shfl_xor(b2, m, 16);
+        b2 = fmaxf(fminf(b1, o1), fmaxf(b2, o2));
+        b1 = fmaxf(b1, o1);
+    }
+    // (b2 is the second largest of the records that survive; had a lost one been larger, `over` says so)
+    const float keep_from = b2 - margin;
+    const bool over = lost >= keep_from;
+
+    float e1 = -INFINITY, e2 = -INFINITY;
+    int ei = -1;
+    for (int k = 0; k < 2 * splits; ++k) {
+        const long stream = ((long)(k >> 1) * na + i) * 2 + (k & 1);
+        int c = (int)rec_info[stream].x;
+        c = c < kRecCap ? c : kRecCap;
+        for (int j0 = 0; j0 < c; j0 += 16) {
+            const int j = j0 + l;
+            const uint2 rc = j < c ? rec[stream * kRecCap + j] : make_uint2(0xff800000u, 0u);
+            const bool pass = j < c && __uint_as_float(rc.x) >= keep_from;
+            unsigned todo = (unsigned)(__builtin_amdgcn_ballot_w64(pass) >> (16 * gw)) & 0xffffu;
+            while (todo) {
+                const int src = __builtin_ctz(todo);
+                todo &= todo - 1;
+                const int row = __shfl((int)rc.y, src, 16);
+                const float4 *bp = reinterpret_cast<const float4 *>(b + (long)row * 128 + l * 8);
+                const float4 u0 = bp[0], u1 = bp[1];
+                float p = av[0] * u0.x;
+                p = fmaf(av[1], u0.y, p); p = fmaf(av[2], u0.z, p); p = fmaf(av[3], u0.w, p);
+                p = fmaf(av[4], u1.x, p); p = fmaf(av[5], u1.y, p); p = fmaf(av[6], u1.z, p); p = fmaf(av[7], u1.w, p);
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) p += __shfl_xor(p, m, 16);
+                const bool nb_ = p > e1 || (p == e1 && row > ei);
+                e2 = nb_ ? e1 : fmaxf(e2, p);
+                ei = nb_ ? row : ei;
+                e1 = nb_ ? p : e1;
+            }
+        }
+    }
+    if (l == 0) {
+        if (over) {                                   // the fallback scan redoes this row (and overwrites what follows)
+            const int j = atomicAdd(n_over, 1);
+            if (j < kOverRows) over_rows[j] = (int)i;
+        }
+        match[i] = (ei >= 0 && (ratio <= 0.f || e1 * ratio > e2)) ? ei : -1;
+        if (best_out) best_out[i] = e1;
+        if (second_out) second_out[i] = e2;
+    }
 }
 
 size_t match_tiles_bytes(long n) { return (size_t)((n + kTileRows - 1) / kTileRows) * kTileBytes; }
@@ -217,23 +510,78 @@ int match_splits(long na, long nb, int num_cus) {
     return (int)(want < 1 ? 1 : want);
 }
 
-void launch_match_split(const float *x, long n, unsigned char *tiles, hipStream_t stream) {
+void launch_match_split(const float *x, long n, unsigned char *tiles, float *norms, unsigned *max_norm_bits,
+                        hipStream_t stream) {
     if (n <= 0) return;
     const long rows = (n + kTileRows - 1) / kTileRows * kTileRows;
-    hipLaunchKernelGGL(match_split, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, x, n, tiles);
+    hipLaunchKernelGGL(match_split, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, x, n, tiles, norms,
+                       max_norm_bits);
 }
 
-void launch_match(const unsigned char *a_tiles, long na, const unsigned char *b_tiles, long nb, const unsigned *excl_lo,
-                  const unsigned *excl_hi, float ratio, int splits, float *p_best, int *p_index, float *p_second,
-                  int *match, float *best, float *second, hipStream_t stream) {
-    if (na <= 0) return;
+static void launch_scan_merge(const unsigned char *a_tiles, long na, const unsigned char *b_tiles, long nb,
+                              const unsigned *excl_lo, const unsigned *excl_hi, float ratio, int splits, float *p_best,
+                              int *p_index, float *p_second, int *match, float *best, float *second, MatchGate gate,
+                              hipStream_t stream) {
     const long a_blocks = (na + kWaves * kATiles * kTileRows - 1) / (kWaves * kATiles * kTileRows);
     const long n_b_tiles = (nb + kTileRows - 1) / kTileRows;
     const long per = (n_b_tiles + splits - 1) / splits;
     hipLaunchKernelGGL(match_scan, dim3((unsigned)a_blocks, (unsigned)splits), dim3(512), 0, stream, a_tiles, na, b_tiles,
-                       nb, per, excl_lo, excl_hi, p_best, p_index, p_second);
+                       nb, per, excl_lo, excl_hi, p_best, p_index, p_second, gate);
     hipLaunchKernelGGL(match_merge, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, stream, (const float *)p_best,
-                       (const int *)p_index, (const float *)p_second, na, splits, ratio, match, best, second);
+                       (const int *)p_index, (const float *)p_second, na, splits, ratio, match, best, second, gate);
+}
+
+void launch_match(const unsigned char *a_tiles, long na, const unsigned char *b_tiles, long nb, const unsigned *excl_lo,
+                  const unsigned *excl_hi, float ratio, int splits, float *p_best, int *p_index, float *p_second,
+                  int *match, float *best, float *second, const int *n_over, hipStream_t stream) {
+    if (na <= 0) return;
+    launch_scan_merge(a_tiles, na, b_tiles, nb, excl_lo, excl_hi, ratio, splits, p_best, p_index, p_second, match, best,
+                      second, MatchGate{n_over, nullptr, kOverRows, 0}, stream);
+}
+
+size_t match_few_tiles_bytes() { return match_tiles_bytes(kOverRows); }
+size_t match_few_words() { return (size_t)kOverRows * (3 + 3 * kOverSplits); }   // rows, lo, hi + partials
+
+// the overflowed rows alone (0 < *n_over <= kOverRows): gathered, scanned with the three terms, scattered back
+void launch_match_few(const float *a, const unsigned char *b_tiles, long nb, const unsigned *excl_lo,
+                      const unsigned *excl_hi, float ratio, const int *n_over, unsigned char *few_tiles, unsigned *few_words,
+                      int *match, float *best, float *second, hipStream_t stream) {
+    int *rows = reinterpret_cast<int *>(few_words);
+    unsigned *lo = few_words + kOverRows, *hi = few_words + 2 * kOverRows;
+    float *p_best = reinterpret_cast<float *>(few_words + 3 * kOverRows);
+    float *p_second = p_best + (size_t)kOverSplits * kOverRows;
+    int *p_index = reinterpret_cast<int *>(p_second + (size_t)kOverSplits * kOverRows);
+    hipLaunchKernelGGL(match_split_rows, dim3(kOverRows / 16), dim3(256), 0, stream, a, (const int *)rows, n_over,
+                       kOverRows, excl_lo, excl_hi, few_tiles, lo, hi);
+    const long n_b_tiles = (nb + kTileRows - 1) / kTileRows;
+    const int splits = (int)(n_b_tiles < kOverSplits ? n_b_tiles : kOverSplits);
+    launch_scan_merge(few_tiles, kOverRows, b_tiles, nb, excl_lo ? lo : nullptr, excl_lo ? hi : nullptr, ratio, splits,
+                      p_best, p_index, p_second, match, best, second, MatchGate{n_over, rows, 0, kOverRows}, stream);
+}
+
+size_t match_record_bytes(long na, int splits) { return (size_t)splits * na * 2 * kRecCap * sizeof(uint2); }
+size_t match_count_bytes(long na, int splits) { return (size_t)splits * na * 2 * sizeof(uint2); }
+
+void launch_match_screen(const unsigned char *a_tiles, long na, const unsigned char *b_tiles, long nb,
+                         const unsigned *excl_lo, const unsigned *excl_hi, int splits, const float *a_norms,
+                         const unsigned *b_max_norm_bits, void *rec, void *rec_info, hipStream_t stream) {
+    if (na <= 0) return;
+    const long a_blocks = (na + kWaves * kATiles * kTileRows - 1) / (kWaves * kATiles * kTileRows);
+    const long n_b_tiles = (nb + kTileRows - 1) / kTileRows;
+    const long per = (n_b_tiles + splits - 1) / splits;
+    hipLaunchKernelGGL(match_screen, dim3((unsigned)a_blocks, (unsigned)splits), dim3(512), 0, stream, a_tiles, na, b_tiles,
+                       nb, per, excl_lo, excl_hi, a_norms, b_max_norm_bits, static_cast<uint2 *>(rec),
+                       static_cast<uint2 *>(rec_info));
+}
+
+void launch_match_verify(const float *a, long na, const float *b, const float *a_norms, const unsigned *b_max_norm_bits,
+                         const void *rec, const void *rec_info, int splits, float ratio, int *match, float *best,
+                         float *second, int *n_over, int *over_rows, hipStream_t stream) {
+    if (na <= 0) return;
+    hipLaunchKernelGGL(match_verify, dim3((unsigned)((na + 15) / 16)), dim3(256), 0, stream, a, na, b, a_norms,
+                       b_max_norm_bits, static_cast<const uint2 *>(rec), static_cast<const uint2 *>(rec_info), splits, ratio,
+                       match, best, second,
+                       n_over, over_rows);
 }
 
 }  // namespace lfmkd

@@ -26,7 +26,7 @@ SYMBOLS = (
     "lf_mkd_build_constants", "lf_mkd_kernel_times", "lf_mkd_synchronize", "lf_mkd_version",
     "lf_mkd_orient_keypoints", "lf_mkd_orient_keypoints_device", "lf_mkd_get_coarse_layer",
     "lf_mkd_detect_extrema", "lf_mkd_detect_extrema_device", "lf_mkd_filter_extrema_device", "lf_mkd_detect",
-    "lf_mkd_match", "lf_mkd_match_device", "lf_mkd_stream_create", "lf_mkd_stream_frame",
+    "lf_mkd_match", "lf_mkd_match_device", "lf_mkd_match_overflowed", "lf_mkd_stream_create", "lf_mkd_stream_frame",
     "lf_mkd_detect_frames_device", "lf_mkd_orient_keypoints_blocked",
 )
 
@@ -100,6 +100,7 @@ def load_library():
     L.lf_mkd_detect.argtypes = [vp, vp, u32, u32, u32, ctypes.c_float, vp, vp, u64, pu64, pu64, pu64]
     L.lf_mkd_match_device.argtypes = [vp, vp, u64, vp, u64, vp, vp, ctypes.c_float, vp, vp, vp, vp]
     L.lf_mkd_match.argtypes = [vp, vp, u64, vp, u64, ctypes.c_float, vp]
+    L.lf_mkd_match_overflowed.argtypes = [vp, vp, ctypes.POINTER(u64)]
     L.lf_mkd_stream_create.argtypes = [vp, u32, u32, u32, ctypes.c_float, u64, vp, vp, vp, vp]
     L.lf_mkd_stream_frame.argtypes = [vp, vp]
     L.lf_mkd_orient_keypoints_blocked.argtypes = [vp, vp, u64, u32, vp, u64, vp, vp, vp, u64, pu64, pu64]
@@ -291,6 +292,12 @@ class MkdHandle:
                      d_second=None, stream=None):
         self._check(self.L.lf_mkd_match_device(self._h, d_a, na, d_b, nb, d_exclude_lo, d_exclude_hi, ratio, d_match,
                                                d_best, d_second, stream), "lf_mkd_match_device")
+
+    def match_overflowed(self, stream=None):
+        """Rows of the latest match call that were redone by the full scan (diagnostic; waits for the call)."""
+        n = ctypes.c_uint64()
+        self._check(self.L.lf_mkd_match_overflowed(self._h, stream, ctypes.byref(n)), "lf_mkd_match_overflowed")
+        return n.value
 
     def detect_frames_device(self, d_images, n_frames, width, height, top_n, min_size, d_keypoints, d_frame_of_kp,
                              d_descriptors, max_out, stream=None):

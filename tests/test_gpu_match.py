@@ -144,3 +144,64 @@ def test_match_real_descriptors(lfp, oracle):
     dx = np.array([k2[j].x - k1[i].x for i, j in pairs]); dy = np.array([k2[j].y - k1[i].y for i, j in pairs])
     ok = (np.abs(dx + 14) < 1.0) & (np.abs(dy - 9) < 1.0)
     assert ok.mean() > 0.9
+
+
+def run_device(lfp, torch, a, b, ratio=0.8, overflowed=None):
+    h = lfp.MkdHandle(max_features=64)
+    d_a, d_b = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    d_m = torch.empty(len(a), dtype=torch.int32, device="cuda")
+    d_1, d_2 = torch.empty(len(a), device="cuda"), torch.empty(len(a), device="cuda")
+    h.match_device(d_a.data_ptr(), len(a), d_b.data_ptr(), len(b), d_m.data_ptr(), ratio, None, None, d_1.data_ptr(),
+                   d_2.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    if overflowed is not None:
+        n = h.match_overflowed(torch.cuda.current_stream().cuda_stream)
+        assert overflowed[0] <= n <= overflowed[1], (n, overflowed)
+    return d_m.cpu().numpy(), d_1.cpu().numpy(), d_2.cpu().numpy()
+
+
+def test_crowded_candidates_take_the_full_scan(lfp, torch, oracle):
+    """The screening pass keeps at most 64 candidates per lane's share of b; hundreds of near-duplicates of a row's best
+    match (a static scene seen in every frame) overflow that, and such rows must be redone by the full-precision scan --
+    alone when they are few, everybody when they are many -- with the oracle's answers either way."""
+    rng = np.random.default_rng(5)
+    centre = unit(rng.normal(size=(1, 128)))
+    cluster = unit(centre + 2e-4 * rng.normal(size=(600, 128)))             # contiguous: one split of b holds them all
+    b = np.concatenate([cluster, unit(rng.normal(size=(20000, 128)))])
+    a = unit(np.concatenate([centre + 1e-4 * rng.normal(size=(4, 128)), rng.normal(size=(20000, 128))]))
+    want, s1, s2 = oracle.match(a, b)
+    got, g1, g2 = run_device(lfp, torch, a, b, overflowed=(4, 64))          # the four rows near the centre, redone alone
+    compare(got, g1, g2, want, s1, s2, np.float32(0.8), "crowded, few rows")
+    # every row crowded: more than the few-rows form takes, so every row is redone
+    many = unit(centre + 1e-4 * rng.normal(size=(20000, 128)))
+    want, s1, s2 = oracle.match(many, b)
+    got, g1, g2 = run_device(lfp, torch, many, b, overflowed=(16385, 20000))
+    compare(got, g1, g2, want, s1, s2, np.float32(0.8), "crowded, all rows")
+    # an ordinary set overflows nowhere
+    a0, b0 = descriptor_sets(3000, 20000, 3)
+    run_device(lfp, torch, a0, b0, overflowed=(0, 0))
+    # ascending similarity to one query: every candidate is a new best, the worst case for the record lists
+    q = unit(rng.normal(size=(1, 128)))
+    n2 = 200000
+    other = unit(rng.normal(size=(n2, 128)))
+    t = np.linspace(0.0, 0.9, n2)[:, None]
+    b2 = unit((1 - t) * other + t * q)
+    want, s1, s2 = oracle.match(q, b2, ratio=0.0)
+    got, g1, g2 = run_device(lfp, torch, q, b2, ratio=0.0, overflowed=(1, 1))
+    compare(got, g1, g2, want, s1, s2, np.float32(0.0), "ascending")
+
+
+@pytest.mark.parametrize("scale_a,scale_b", [(1e-3, 1.0), (3e-5, 2e-4), (50.0, 0.01), (300.0, 120.0)])
+def test_match_of_unnormalised_rows(lfp, torch, oracle, scale_a, scale_b):
+    """The screening margin is derived from the rows' norms, not assumed: scaled inputs (f16 subnormals included) decide
+    as the oracle does."""
+    a, b = descriptor_sets(1500, 3000, 11)
+    rng = np.random.default_rng(12)
+    a = (a * scale_a * rng.uniform(0.5, 2.0, (len(a), 1))).astype(np.float32)
+    b = (b * scale_b * rng.uniform(0.5, 2.0, (len(b), 1))).astype(np.float32)
+    want, s1, s2 = oracle.match(a, b, ratio=0.0)
+    got, g1, g2 = run_device(lfp, torch, a, b, ratio=0.0)
+    tol = 2e-6 * np.abs(s1).max()
+    assert np.abs(g1 - s1).max() < tol and np.abs(g2 - s2).max() < tol
+    diff = np.flatnonzero(got != want)
+    assert all(abs(s1[i] - s2[i]) < tol for i in diff) and len(diff) <= 3
