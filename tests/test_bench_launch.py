@@ -17,7 +17,8 @@ def test_gpus_n_without_a_launcher_starts_n_ranks_and_propagates_failure():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--patches", "64"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0                                       # no GPU here: both ranks refuse, the parent says so
-    assert r.stderr.count("bench.py needs an MI355X") == 2          # two ranks were started
+    # two ranks were started (torchrun may stop the second one before it gets to say so, once the first has failed)
+    assert 1 <= r.stderr.count("bench.py needs an MI355X") <= 2 and "ChildFailedError" in r.stderr
     assert '"n_gpus"' not in r.stdout                               # and no one-rank line was printed in their place
 
 
