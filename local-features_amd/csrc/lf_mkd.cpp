@@ -226,6 +226,7 @@ int mark(lf_mkd *h, hipStream_t s) {
     return LF_MKD_OK;
 }
 
+constexpr uint64_t kMatchChunk = 1 << 20;   // a rows per pass of the two-pass matcher (2 GiB of records at one b split)
 // keypoint mode overlaps sampling and describing for batches of at least kOverlapMin keypoints, kOverlapChunk at a time
 constexpr uint64_t kOverlapMin = 1 << 16, kOverlapChunk = 1 << 15;   // measured: 16 k .. 64 k chunks within 1 %, 128 k loses the gain
 
@@ -920,16 +921,18 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
     if (na > 0x7FFFFFFFull || nb > 0x7FFFFFFFull) return fail(h, LF_MKD_ERR_BAD_ARG, "match: more than 2^31 rows");
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
-    const int splits = match_splits(long(na), long(nb), h->num_cus);
-    if (int rc = grow(h, &h->d_match_a, &h->match_a_cap, match_tiles_bytes(long(na)), 1)) return rc;
-    if (int rc = grow(h, &h->d_match_b, &h->match_b_cap, match_tiles_bytes(long(nb)), 1)) return rc;
-    if (int rc = grow(h, &h->d_match_part, &h->match_part_cap, uint64_t(splits) * na * 3, sizeof(float))) return rc;
-    float *p_best = h->d_match_part, *p_second = p_best + uint64_t(splits) * na;
-    int *p_index = reinterpret_cast<int *>(p_second + uint64_t(splits) * na);
     static const bool three_term_only = [] {
         const char *e = getenv("LF_MKD_MATCH");            // "scan": the three-term scan alone (the round-1 form)
         return e && e[0] == 's';
     }();
+    // a goes through in chunks, so that the per-row scratch (2 KiB of candidate records per a row and b split) stays bounded
+    const uint64_t chunk = three_term_only ? na : std::min<uint64_t>(na, kMatchChunk);
+    const int splits = match_splits(long(chunk), long(nb), h->num_cus);
+    if (int rc = grow(h, &h->d_match_a, &h->match_a_cap, match_tiles_bytes(long(chunk)), 1)) return rc;
+    if (int rc = grow(h, &h->d_match_b, &h->match_b_cap, match_tiles_bytes(long(nb)), 1)) return rc;
+    if (int rc = grow(h, &h->d_match_part, &h->match_part_cap, uint64_t(splits) * chunk * 3, sizeof(float))) return rc;
+    float *p_best = h->d_match_part, *p_second = p_best + uint64_t(splits) * chunk;
+    int *p_index = reinterpret_cast<int *>(p_second + uint64_t(splits) * chunk);
     if (three_term_only) {
         launch_match_split(d_a, long(na), h->d_match_a, nullptr, nullptr, s);
         launch_match_split(d_b, long(nb), h->d_match_b, nullptr, nullptr, s);
@@ -938,28 +941,36 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
         LF_HIP(h, hipGetLastError());
         return LF_MKD_OK;
     }
-    if (int rc = grow(h, &h->d_match_rec, &h->match_rec_cap, match_record_bytes(long(na), splits), 1)) return rc;
-    if (int rc = grow(h, &h->d_match_cnt, &h->match_cnt_cap, match_count_bytes(long(na), splits), 1)) return rc;
-    if (int rc = grow(h, &h->d_match_norm, &h->match_norm_cap, na, sizeof(float))) return rc;
-    if (int rc = grow(h, &h->d_match_misc, &h->match_misc_cap, 2, sizeof(unsigned))) return rc;
+    if (int rc = grow(h, &h->d_match_rec, &h->match_rec_cap, match_record_bytes(long(chunk), splits), 1)) return rc;
+    if (int rc = grow(h, &h->d_match_cnt, &h->match_cnt_cap, match_count_bytes(long(chunk), splits), 1)) return rc;
+    if (int rc = grow(h, &h->d_match_norm, &h->match_norm_cap, chunk, sizeof(float))) return rc;
+    if (int rc = grow(h, &h->d_match_misc, &h->match_misc_cap, 3, sizeof(unsigned))) return rc;
     if (int rc = grow(h, &h->d_match_few_tiles, &h->match_few_tiles_cap, match_few_tiles_bytes(), 1)) return rc;
     if (int rc = grow(h, &h->d_match_few, &h->match_few_cap, match_few_words(), sizeof(unsigned))) return rc;
-    LF_HIP(h, hipMemsetAsync(h->d_match_misc, 0, 2 * sizeof(unsigned), s));
+    // misc: [0] largest |b| (float bits), [1] rows of the current chunk whose records overflowed, [2] the same over the call
+    LF_HIP(h, hipMemsetAsync(h->d_match_misc, 0, 3 * sizeof(unsigned), s));
     unsigned *b_max = h->d_match_misc;
     int *n_over = reinterpret_cast<int *>(h->d_match_misc + 1);
-    launch_match_split(d_a, long(na), h->d_match_a, h->d_match_norm, nullptr, s);
     launch_match_split(d_b, long(nb), h->d_match_b, nullptr, b_max, s);
-    launch_match_screen(h->d_match_a, long(na), h->d_match_b, long(nb), d_exclude_lo, d_exclude_hi, splits,
-                        h->d_match_norm, b_max, h->d_match_rec, h->d_match_cnt, s);
-    launch_match_verify(d_a, long(na), d_b, h->d_match_norm, b_max, h->d_match_rec, h->d_match_cnt, splits, ratio,
-                        d_match, d_best, d_second, n_over, reinterpret_cast<int *>(h->d_match_few), s);
-    // rows whose records overflowed (more than 64 near-best candidates in one lane's share of b) are redone by the
-    // three-term scan: on their own when they are few, else with everybody; both are enqueued unconditionally and
-    // read the count on the device -- no host round trip, and nothing to do in the ordinary case
-    launch_match_few(d_a, h->d_match_b, long(nb), d_exclude_lo, d_exclude_hi, ratio, n_over, h->d_match_few_tiles,
-                     h->d_match_few, d_match, d_best, d_second, s);
-    launch_match(h->d_match_a, long(na), h->d_match_b, long(nb), d_exclude_lo, d_exclude_hi, ratio, splits, p_best,
-                 p_index, p_second, d_match, d_best, d_second, n_over, s);
+    for (uint64_t at = 0; at < na; at += chunk) {
+        const long n = long(std::min(chunk, na - at));
+        const float *a = d_a + at * kOut;
+        const uint32_t *lo = d_exclude_lo ? d_exclude_lo + at : nullptr, *hi = d_exclude_hi ? d_exclude_hi + at : nullptr;
+        float *best = d_best ? d_best + at : nullptr, *second = d_second ? d_second + at : nullptr;
+        if (at) LF_HIP(h, hipMemsetAsync(n_over, 0, sizeof(int), s));
+        launch_match_split(a, n, h->d_match_a, h->d_match_norm, nullptr, s);
+        launch_match_screen(h->d_match_a, n, h->d_match_b, long(nb), lo, hi, splits, h->d_match_norm, b_max,
+                            h->d_match_rec, h->d_match_cnt, s);
+        launch_match_verify(a, n, d_b, h->d_match_norm, b_max, h->d_match_rec, h->d_match_cnt, splits, ratio,
+                            d_match + at, best, second, n_over, reinterpret_cast<int *>(h->d_match_few), s);
+        // rows whose records overflowed (more than 64 near-best candidates in one lane's share of b) are redone by the
+        // three-term scan: on their own when they are few, else the whole chunk; both are enqueued unconditionally and
+        // read the count on the device -- no host round trip, and nothing to do in the ordinary case
+        launch_match_few(a, h->d_match_b, long(nb), lo, hi, ratio, n_over, h->d_match_few_tiles, h->d_match_few,
+                         d_match + at, best, second, s);
+        launch_match(h->d_match_a, n, h->d_match_b, long(nb), lo, hi, ratio, splits, p_best, p_index, p_second,
+                     d_match + at, best, second, n_over, s);
+    }
     LF_HIP(h, hipGetLastError());
     return LF_MKD_OK;
 }
@@ -972,7 +983,7 @@ int lf_mkd_match_overflowed(lf_mkd *h, void *stream, uint64_t *n_rows) {
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     int n = 0;
-    LF_HIP(h, hipMemcpyAsync(&n, h->d_match_misc + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    LF_HIP(h, hipMemcpyAsync(&n, h->d_match_misc + 2, sizeof(int), hipMemcpyDeviceToHost, s));
     LF_HIP(h, hipStreamSynchronize(s));
     *n_rows = uint64_t(n);
     return LF_MKD_OK;

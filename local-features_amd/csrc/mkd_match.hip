@@ -298,24 +298,48 @@ __global__ __launch_bounds__(256) void match_merge(const float *__restrict__ p_b
 // superset.
 constexpr int kOverRows = 16384;   // overflowed rows the "few" form of the fallback takes; beyond that every row is redone
 constexpr int kOverSplits = 64;
-constexpr int kRecCap = 64;   // records per stream (one a row x one k-half lane x one b split); ~2.3 ln(rows scanned) expected
+constexpr int kRecCap = 64;   // records per stream (one a row x one of its 4 lanes x one b split); ~2.3 ln(rows scanned) expected
+
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 
 __device__ __forceinline__ float screen_margin(float a_norm, float b_norm_max) {
     return 2.02e-3f * a_norm * b_norm_max + 5e-7f * (a_norm + b_norm_max);
 }
 
-constexpr int kStageTiles = 4;   // b tiles per LDS stage of the screen (one barrier per stage): 4 x 8 KiB, double buffered
+constexpr int kStageTiles = 2;   // b tiles per LDS stage of the screen (one barrier per stage): 2 x 8 KiB, double buffered
+constexpr int kSub = 4;          // a sub-tiles of 16 rows per wave (the same 64 a rows as the scan's two tiles of 32)
+constexpr int kLanesPerRow = 4;  // lanes that hold values of one a row: streams per (a row, b split)
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// The screen uses v_mfma_f32_16x16x32_f16 (the chip holds a higher clock under this shape than under 32x32x16 on
+// non-trivial operands, MI355X_MICROARCH.md "DVFS give-back" (7)): b rows on the M side again, so lane (n = lane & 15,
+// g = lane >> 4) of an accumulator holds a column n and b rows 4 g .. 4 g + 3.  The operand tiles are the scan's:
+// chunk c8 = 4 s + g of a row (k = 8 c8 .. 8 c8 + 7) is the lane's share of k-step s for either operand, and a 32-row
+// tile is two 16-row halves.
+//
+// Registers: 64 hold the wave's a rows, 16 the accumulators of one half tile; to stay within 128 (four waves per SIMD,
+// nothing spilled in the loop: a spill reload would wait on vmcnt, i.e. on the LDS-DMA in flight) the running (best,
+// second, count) of a lane's stream live in LDS and only the threshold second - margin in a register.  Common path per
+// half tile: 16 MFMA, then two max3 and a compare per sub-tile; the rare path (a candidate near the threshold) fetches
+// its state from LDS and writes the record.
 __global__ __launch_bounds__(512, 4) void match_screen(const unsigned char *__restrict__ a_tiles, long na,
                                                        const unsigned char *__restrict__ b_tiles, long nb,
                                                        long tiles_per_split, const unsigned *__restrict__ excl_lo,
                                                        const unsigned *__restrict__ excl_hi,
                                                        const float *__restrict__ a_norms,
                                                        const unsigned *__restrict__ b_max_norm_bits,
-                                                       uint2 *rec, uint2 *__restrict__ rec_info) {
+                                                       uint2 *rec, uint2 *rec_info) {
     __shared__ __attribute__((aligned(16))) unsigned char s_b[2][kStageTiles][kTileBytes / 2];
+    __shared__ float2 s_top[kSub][512];                     // a stream's running (best, second)
+    __shared__ float s_margin[kSub][512];
+    __shared__ int s_cnt[kSub][512];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = lane & 31, h = lane >> 5;
+    const int n = lane & 15, g = lane >> 4;
     const long a_tile0 = ((long)blockIdx.x * kWaves + wave) * kATiles;
     const long a_tiles_total = (na + kTileRows - 1) / kTileRows;
     const long b_tiles_total = (nb + kTileRows - 1) / kTileRows;
@@ -323,82 +347,138 @@ __global__ __launch_bounds__(512, 4) void match_screen(const unsigned char *__re
     long t_end = t_begin + tiles_per_split;
     t_end = t_end < b_tiles_total ? t_end : b_tiles_total;
     const float b_max = __uint_as_float(*b_max_norm_bits);
+    const long arow0 = a_tile0 * kTileRows + n;          // sub-tile j holds a row arow0 + 16 j
 
-    h8 ah[kATiles][8];
-    unsigned lo_x[kATiles], hi_x[kATiles];
-    float margin[kATiles];
-    bool live[kATiles];
-    long stream[kATiles];
+    h8 ah[kSub][4];
+    float thr[kSub];                                      // second best so far - margin: what a candidate must reach
+    unsigned any_lo = 0xffffffffu, any_hi = 0u;           // the union of the wave's excluded ranges
 #pragma unroll
-    for (int t = 0; t < kATiles; ++t) {
-        const long at = a_tile0 + t < a_tiles_total ? a_tile0 + t : a_tiles_total - 1;
-        const unsigned char *src = a_tiles + at * kTileBytes + (h * 32 + r) * 16;
+    for (int j = 0; j < kSub; ++j) {
+        const long arow = arow0 + 16 * j;
+        const long at = a_tile0 + (j >> 1) < a_tiles_total ? a_tile0 + (j >> 1) : a_tiles_total - 1;   // idle: redo the last
+        const unsigned char *src = a_tiles + at * kTileBytes + (g * 32 + 16 * (j & 1) + n) * 16;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) ah[t][s] = *reinterpret_cast<const h8 *>(src + s * 1024);
-        const long arow = at * kTileRows + r;
-        live[t] = a_tile0 + t < a_tiles_total && arow < na;
-        lo_x[t] = excl_lo && arow < na ? excl_lo[arow] : 0u;
-        hi_x[t] = excl_lo && arow < na ? excl_hi[arow] : 0u;
-        margin[t] = live[t] ? screen_margin(a_norms[arow], b_max) : 0.f;
-        stream[t] = (((long)blockIdx.y * na + (live[t] ? arow : 0)) * 2 + h) * kRecCap;
+        for (int s = 0; s < 4; ++s) ah[j][s] = *reinterpret_cast<const h8 *>(src + s * 2048);
+        const bool live = arow < na;
+        thr[j] = live ? -INFINITY : INFINITY;             // a dead lane never has a candidate
+        s_top[j][threadIdx.x] = make_float2(-INFINITY, -INFINITY);
+        s_cnt[j][threadIdx.x] = 0;
+        s_margin[j][threadIdx.x] = live ? screen_margin(a_norms[arow], b_max) : 0.f;
+        if (live) {
+            rec_info[((long)blockIdx.y * na + arow) * kLanesPerRow + g] = make_uint2(0u, 0xff800000u);   // (count, lost)
+            if (excl_lo) {
+                any_lo = min(any_lo, excl_lo[arow]);
+                any_hi = max(any_hi, excl_hi[arow]);
+            }
+        }
     }
-    float best[kATiles], second[kATiles], lost[kATiles];
-    int cnt[kATiles];
 #pragma unroll
-    for (int t = 0; t < kATiles; ++t) { best[t] = -INFINITY; second[t] = -INFINITY; lost[t] = -INFINITY; cnt[t] = 0; }
+    for (int m = 1; m < 64; m <<= 1) {
+        any_lo = min(any_lo, (unsigned)__shfl_xor((int)any_lo, m));
+        any_hi = max(any_hi, (unsigned)__shfl_xor((int)any_hi, m));
+    }
+    any_lo = __builtin_amdgcn_readfirstlane(any_lo);
+    any_hi = __builtin_amdgcn_readfirstlane(any_hi);
 
-    auto issue = [&](long t, int buf) {   // the hi halves of tiles t .. t + 3: 8 KiB each = 512 threads x 16 B
+    auto issue = [&](long t, int buf) {   // the hi halves of the stage's tiles: 8 KiB each = 512 threads x 16 B
 #pragma unroll
         for (int u = 0; u < kStageTiles; ++u)
             if (t + u < t_end)
                 lds_dma16(b_tiles + (t + u) * kTileBytes + threadIdx.x * 16, &s_b[buf][u][0] + wave * 1024);
     };
-    auto tile = [&](long t, const unsigned char *bb) {
-        h8 bh[8];
+    // a candidate near the threshold in sub-tile j, rows 16 hf .. of tile t: record, update the stream's state
+    auto near = [&](int j, long t, int hf, f32x4 v4) {
+        const long arow = arow0 + 16 * j;
+        if (!(arow < na)) return;
+        const long sidx = ((long)blockIdx.y * na + arow) * kLanesPerRow + g;
+        // The four lanes of an a row share what they know: the row's second best is at least every lane's second and at
+        // least the second largest of the lanes' bests.  Values only grow, so whatever a lane reads of the others (they
+        // may be in here too) is a valid bound; a lane that comes with a stale threshold leaves again at once.
+        const float margin = s_margin[j][threadIdx.x];
+        const float2 *row_top = &s_top[j][threadIdx.x & ~48];
+        auto row_bound = [&]() {
+            float b1 = -INFINITY, b2 = -INFINITY, s2 = -INFINITY;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) bh[s] = *reinterpret_cast<const h8 *>(bb + s * 1024);
-        f32x16 acc[kATiles];
+            for (int k = 0; k < kLanesPerRow; ++k) {
+                const float2 o = row_top[16 * k];
+                b2 = o.x > b1 ? b1 : fmaxf(b2, o.x);
+                b1 = fmaxf(b1, o.x);
+                s2 = fmaxf(s2, o.y);
+            }
+            return fmaxf(b2, s2) - margin;
+        };
+        float from = row_bound();
+        thr[j] = from;
+        if (!(fmaxf(fmaxf(v4[0], v4[1]), fmaxf(v4[2], v4[3])) >= from)) return;
+        int cnt = s_cnt[j][threadIdx.x];
+        float best = row_top[16 * g].x, second = row_top[16 * g].y;
+        const int row0 = (int)(t * kTileRows) + 16 * hf + 4 * g;
 #pragma unroll
-        for (int q = 0; q < kATiles; ++q)
+        for (int e = 0; e < 4; ++e) {
+            const float v = v4[e];
+            if (v > -INFINITY && v >= fmaxf(from, second - margin)) {
+                // a ring: beyond the capacity the oldest record goes, and the largest value that went is kept --
+                // verify needs only to know that nothing it would have re-scored was lost
+                uint2 *slot = rec + sidx * kRecCap + (cnt & (kRecCap - 1));
+                if (cnt >= kRecCap) rec_info[sidx].y = __float_as_uint(fmaxf(__uint_as_float(rec_info[sidx].y),
+                                                                             __uint_as_float(slot->x)));
+                *slot = make_uint2(__float_as_uint(v), (unsigned)(row0 + e));
+                ++cnt;
+            }
+            const bool nb_ = v >= best && v > -INFINITY;
+            const bool ns = !nb_ && v > second;
+            second = nb_ ? best : (ns ? v : second);
+            best = nb_ ? v : best;
+        }
+        s_cnt[j][threadIdx.x] = cnt;
+        s_top[j][threadIdx.x] = make_float2(best, second);
+        thr[j] = row_bound();
+    };
+    auto tile = [&](long t, const unsigned char *bb) {   // bb: the lane's chunk of row n of the tile, k-step 0
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+        for (int hf = 0; hf < 2; ++hf) {                  // the tile's two halves of 16 rows, one after the other
+            h8 bh[4];
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
+            for (int s = 0; s < 4; ++s) bh[s] = *reinterpret_cast<const h8 *>(bb + hf * 256 + s * 2048);
+            f32x4 acc[kSub];
 #pragma unroll
-            for (int q = 0; q < kATiles; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s], ah[q][s], acc[q], 0, 0, 0);
-        const int row0 = (int)(t * kTileRows) + 4 * h;
-        const bool tail = (t + 1) * kTileRows > nb;
+            for (int j = 0; j < kSub; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < kATiles; ++q) {
-            const bool touch = tail || ((unsigned)(t * kTileRows) < hi_x[q] && (unsigned)((t + 1) * kTileRows) > lo_x[q]);
-            if (__builtin_amdgcn_ballot_w64(touch)) {
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const unsigned row = (unsigned)(row0 + (i & 3) + 8 * (i >> 2));
-                    if (row >= (unsigned)nb || (row >= lo_x[q] && row < hi_x[q])) acc[q][i] = -INFINITY;
+                for (int j = 0; j < kSub; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[s], ah[j][s], acc[j], 0, 0, 0);
+            // rows masked for an a row: beyond nb, or inside its own excluded range (scalar test on the wave's union first)
+            const unsigned tr0 = (unsigned)(t * kTileRows) + 16 * hf;
+            if (tr0 + 16 > (unsigned)nb || (tr0 < any_hi && tr0 + 16 > any_lo)) {
+#pragma unroll
+                for (int j = 0; j < kSub; ++j) {
+                    const long arow = arow0 + 16 * j;
+                    const unsigned lo = excl_lo && arow < na ? excl_lo[arow] : 0u, hi = excl_lo && arow < na ? excl_hi[arow] : 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned row = tr0 + 4 * g + e;
+                        if (row >= (unsigned)nb || (row >= lo && row < hi)) acc[j][e] = -INFINITY;
+                    }
                 }
             }
-            float m = acc[q][0];
+            // (fmaxf would first canonicalise each input: more instructions than the maximum itself)
+            float m[kSub];
+            bool hit[kSub];
 #pragma unroll
-            for (int i = 1; i < 16; ++i) m = fmaxf(m, acc[q][i]);
-            if (__builtin_amdgcn_ballot_w64(live[q] && m >= second[q] - margin[q])) {   // rare once the scan is under way
+            for (int j = 0; j < kSub; ++j) {
+                m[j] = max3(max3(acc[j][0], acc[j][1], acc[j][2]), acc[j][3], acc[j][3]);
+                hit[j] = m[j] >= thr[j];
+            }
+#if defined(LF_SCREEN_ABLATE_EPILOGUE) || defined(LF_SCREEN_ABLATE_NEAR)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float v = acc[q][i];
-                    const int row = row0 + (i & 3) + 8 * (i >> 2);
-                    if (live[q] && v > -INFINITY && v >= second[q] - margin[q]) {
-                        // a ring: beyond the capacity the oldest record goes, and the largest value that went is kept --
-                        // verify needs only to know that nothing it would have re-scored was lost
-                        uint2 *slot = rec + stream[q] + (cnt[q] & (kRecCap - 1));
-                        if (cnt[q] >= kRecCap) lost[q] = fmaxf(lost[q], __uint_as_float(slot->x));
-                        *slot = make_uint2(__float_as_uint(v), (unsigned)row);
-                        ++cnt[q];
-                    }
-                    const bool nb_ = v >= best[q] && v > -INFINITY;
-                    const bool ns = !nb_ && v > second[q];
-                    second[q] = nb_ ? best[q] : (ns ? v : second[q]);
-                    best[q] = nb_ ? v : best[q];
-                }
+            for (int j = 0; j < kSub; ++j) thr[j] = hit[j] ? m[j] : thr[j];
+            continue;
+#endif
+            if (__builtin_amdgcn_ballot_w64(hit[0] | hit[1] | hit[2] | hit[3])) {   // one branch; rare once the scan is under way
+#pragma unroll
+                for (int j = 0; j < kSub; ++j)
+                    if (hit[j]) near(j, t, hf, acc[j]);
             }
         }
     };
@@ -406,15 +486,21 @@ __global__ __launch_bounds__(512, 4) void match_screen(const unsigned char *__re
     for (long t = t_begin; t < t_end; t += kStageTiles) {
         const int buf = (int)(((t - t_begin) / kStageTiles) & 1);
         __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of the stage have landed
+#ifndef LF_SCREEN_ABLATE_BARRIER
         __syncthreads();                      // ... and everybody's; everybody is also done with the other buffer
+#endif
         if (t + kStageTiles < t_end) issue(t + kStageTiles, buf ^ 1);
 #pragma unroll
         for (int u = 0; u < kStageTiles; ++u)
-            if (t + u < t_end) tile(t + u, &s_b[buf][u][0] + (h * 32 + r) * 16);
+            if (t + u < t_end) tile(t + u, &s_b[buf][u][0] + (g * 32 + n) * 16);
     }
 #pragma unroll
-    for (int q = 0; q < kATiles; ++q)
-        if (live[q]) rec_info[stream[q] / kRecCap] = make_uint2((unsigned)cnt[q], __float_as_uint(lost[q]));
+    for (int j = 0; j < kSub; ++j)
+        if (arow0 + 16 * j < na)
+            rec_info[((long)blockIdx.y * na + arow0 + 16 * j) * kLanesPerRow + g].x = (unsigned)s_cnt[j][threadIdx.x];
+#if defined(LF_SCREEN_ABLATE_EPILOGUE) || defined(LF_SCREEN_ABLATE_NEAR)
+    if (thr[0] + thr[1] + thr[2] + thr[3] == 12345.f) rec_info[0].x = 1u;
+#endif
 }
 
 // 16 lanes per a row: the survivors of the screen are re-scored as f32 dot products (each lane 8 elements as an fma
@@ -436,8 +522,8 @@ __global__ __launch_bounds__(256) void match_verify(const float *__restrict__ a,
 
     // the query's second-largest screened similarity
     float b1 = -INFINITY, b2 = -INFINITY, lost = -INFINITY;
-    for (int k = 0; k < 2 * splits; ++k) {
-        const long stream = ((long)(k >> 1) * na + i) * 2 + (k & 1);
+    for (int k = 0; k < kLanesPerRow * splits; ++k) {
+        const long stream = ((long)(k / kLanesPerRow) * na + i) * kLanesPerRow + (k % kLanesPerRow);
         const uint2 info = rec_info[stream];
         int c = (int)info.x;
         if (c > kRecCap) lost = fmaxf(lost, __uint_as_float(info.y));
@@ -460,8 +546,8 @@ __global__ __launch_bounds__(256) void match_verify(const float *__restrict__ a,
 
     float e1 = -INFINITY, e2 = -INFINITY;
     int ei = -1;
-    for (int k = 0; k < 2 * splits; ++k) {
-        const long stream = ((long)(k >> 1) * na + i) * 2 + (k & 1);
+    for (int k = 0; k < kLanesPerRow * splits; ++k) {
+        const long stream = ((long)(k / kLanesPerRow) * na + i) * kLanesPerRow + (k % kLanesPerRow);
         int c = (int)rec_info[stream].x;
         c = c < kRecCap ? c : kRecCap;
         for (int j0 = 0; j0 < c; j0 += 16) {
@@ -490,6 +576,7 @@ __global__ __launch_bounds__(256) void match_verify(const float *__restrict__ a,
     if (l == 0) {
         if (over) {                                   // the fallback scan redoes this row (and overwrites what follows)
             const int j = atomicAdd(n_over, 1);
+            atomicAdd(n_over + 1, 1);                     // (the call's total, for lf_mkd_match_overflowed)
             if (j < kOverRows) over_rows[j] = (int)i;
         }
         match[i] = (ei >= 0 && (ratio <= 0.f || e1 * ratio > e2)) ? ei : -1;
@@ -559,8 +646,8 @@ void launch_match_few(const float *a, const unsigned char *b_tiles, long nb, con
                       p_best, p_index, p_second, match, best, second, MatchGate{n_over, rows, 0, kOverRows}, stream);
 }
 
-size_t match_record_bytes(long na, int splits) { return (size_t)splits * na * 2 * kRecCap * sizeof(uint2); }
-size_t match_count_bytes(long na, int splits) { return (size_t)splits * na * 2 * sizeof(uint2); }
+size_t match_record_bytes(long na, int splits) { return (size_t)splits * na * kLanesPerRow * kRecCap * sizeof(uint2); }
+size_t match_count_bytes(long na, int splits) { return (size_t)splits * na * kLanesPerRow * sizeof(uint2); }
 
 void launch_match_screen(const unsigned char *a_tiles, long na, const unsigned char *b_tiles, long nb,
                          const unsigned *excl_lo, const unsigned *excl_hi, int splits, const float *a_norms,

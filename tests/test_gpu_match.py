@@ -205,3 +205,24 @@ def test_match_of_unnormalised_rows(lfp, torch, oracle, scale_a, scale_b):
     assert np.abs(g1 - s1).max() < tol and np.abs(g2 - s2).max() < tol
     diff = np.flatnonzero(got != want)
     assert all(abs(s1[i] - s2[i]) < tol for i in diff) and len(diff) <= 3
+
+
+def test_more_rows_than_one_pass_takes(lfp, torch, oracle):
+    """a goes through the matcher 2^20 rows at a time (bounded scratch); results, exclusion ranges and the optional
+    outputs must line up across the seam."""
+    rng = np.random.default_rng(21)
+    na, nb = (1 << 20) + 777, 384
+    b = unit(rng.normal(size=(nb, 128)))
+    a = unit(b[rng.integers(0, nb, na)] + 0.3 * rng.normal(size=(na, 128)).astype(np.float32) / np.sqrt(128))
+    lo = rng.integers(0, nb - 8, na).astype(np.uint32)
+    hi = lo + rng.integers(0, 8, na).astype(np.uint32)
+    want, s1, s2 = oracle.match(a, b, exclude=(lo, hi))
+    h = lfp.MkdHandle(max_features=64)
+    d_a, d_b = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    d_lo, d_hi = torch.from_numpy(lo.view(np.int32)).cuda(), torch.from_numpy(hi.view(np.int32)).cuda()
+    d_m = torch.empty(na, dtype=torch.int32, device="cuda")
+    d_1, d_2 = torch.empty(na, device="cuda"), torch.empty(na, device="cuda")
+    h.match_device(d_a.data_ptr(), na, d_b.data_ptr(), nb, d_m.data_ptr(), 0.8, d_lo.data_ptr(), d_hi.data_ptr(),
+                   d_1.data_ptr(), d_2.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    compare(d_m.cpu().numpy(), d_1.cpu().numpy(), d_2.cpu().numpy(), want, s1, s2, np.float32(0.8), "two passes over a")
