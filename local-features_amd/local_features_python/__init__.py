@@ -135,6 +135,7 @@ class LocalFeatures:
             self._inner.match_device(d_a.data_ptr(), len(a), d_b.data_ptr(), len(b), d_m.data_ptr(), 0.0, None, None,
                                      d_1.data_ptr(), d_2.data_ptr(), s.cuda_stream)
             s.synchronize()
+            self._inner.synchronize()       # (torch's default stream is handle 0 = "the library's own stream" to the ABI)
             keep = (1.0 - d_1) < (1.0 - d_2) * factor
             m, keep = d_m.cpu().numpy(), keep.cpu().numpy()
         return [(int(i), int(m[i])) for i in np.flatnonzero(keep)]

@@ -129,9 +129,13 @@ def gpu_match_fn(handle):
         lo, hi = lo.contiguous(), hi.contiguous()
         out = torch.empty((a.shape[0],), dtype=torch.int32, device=a.device)
         if a.shape[0]:
+            # torch's default stream is handle 0, which the ABI reads as "the library's own (non-blocking) stream": what
+            # produced a / b must be complete before, and the library's stream drained after
+            torch.cuda.current_stream().synchronize()
             handle.match_device(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], out.data_ptr(), ratio,
                                 lo.data_ptr(), hi.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
             torch.cuda.current_stream().synchronize()
+            handle.synchronize()
         return out
     return fn
 
