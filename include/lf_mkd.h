@@ -251,14 +251,19 @@ int lf_mkd_stream_frame(lf_mkd *h, void *stream);
  * (examples/webcam/src/main.rs:261-265).  d_exclude_lo / d_exclude_hi (may both be NULL): b rows [lo[i], hi[i]) are not candidates for
  * a row i -- the cross-image form of BASELINE configs[3], where b is the all-gathered descriptor set and a row
  * must not match its own image.  nb must be at least 2 (the reference indexes the second-to-last candidate).
- * Two passes: every pair is screened on the matrix cores with the f16 roundings of both sides (error bounded by
- * ~1e-3 |a||b|, from the rows' norms), every candidate within that bound of a row's second best is re-scored as an f32
- * dot product, and the decision is taken on the re-scored values: the result is that of an exhaustive f32 scan, and
- * decisions can differ from the reference's only where two similarities, or best*ratio and second, agree to ~1e-7.
- * A row with more than 64 such candidates in one lane's share of b (thousands of near-duplicates of its best match)
- * is redone by a full scan on f16 hi+lo splits (~2^-21 relative) -- inside the same call, decided on the device.
- * Elements must be finite and below 65504 in magnitude (f16 range).  ~5e12 pairs/s on an MI355X for unit-norm
- * descriptors; LF_MKD_MATCH=scan in the environment selects the full hi+lo scan alone (~1.7e12 pairs/s).
+ * Similarities come from the matrix cores in one of two forms, both within ~1e-7 of an f32 dot product, so that decisions
+ * can differ from the reference's only where two similarities, or best*ratio and second, agree to that level:
+ *   scan    -- every pair from f16 hi+lo splits of both sides (three MFMA terms; ~2^-21 relative for rows of unit norm or
+ *              larger -- the lo parts of much smaller elements fall below the f16 grid); ~1.7e12 pairs/s on an MI355X;
+ *              used for small problems (the reference's 2000 x 2000 takes 0.06 ms);
+ *   screen  -- two passes, for na >= 16384 and na * nb >= 2^29: every pair is screened with the f16 roundings of both sides
+ *              (one term; error bounded by ~1e-3 |a||b|, from the rows' norms), every candidate within that bound of a row's
+ *              second best is re-scored as an f32 dot product, and the decision is taken on the re-scored values, i.e. the
+ *              result of an exhaustive f32 scan; ~5.9e12 pairs/s.  A row with more than 64 such candidates in one lane's
+ *              share of b (hundreds of near-duplicates of its best match) is redone by the scan form inside the same call,
+ *              decided on the device.
+ * LF_MKD_MATCH=scan or =screen in the environment forces a form.  Elements must be finite and below 65504 in magnitude
+ * (f16 range).
  * Device pointers, asynchronous on `stream`. */
 int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d_b, uint64_t nb,
                         const uint32_t *d_exclude_lo, const uint32_t *d_exclude_hi, float ratio,

@@ -921,10 +921,14 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
     if (na > 0x7FFFFFFFull || nb > 0x7FFFFFFFull) return fail(h, LF_MKD_ERR_BAD_ARG, "match: more than 2^31 rows");
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
-    static const bool three_term_only = [] {
-        const char *e = getenv("LF_MKD_MATCH");            // "scan": the three-term scan alone (the round-1 form)
-        return e && e[0] == 's';
-    }();
+    // Which form: the two passes win once the scan would take about a millisecond and a has enough rows to fill the chip
+    // without splitting b many ways (every b split starts its candidate lists from nothing); below that -- the reference's
+    // own 2000 x 2000 included -- the three-term scan alone is faster.  LF_MKD_MATCH=scan / =screen in the environment
+    // force one form (A/B runs, tests).
+    const char *form = getenv("LF_MKD_MATCH");
+    const bool three_term_only = form && form[0] == 's' && form[1] == 'c' && form[2] == 'a'
+                                     ? true
+                                     : (form && form[0] == 's' ? false : !(na >= 16384 && na * nb >= (1ull << 29)));
     // a goes through in chunks, so that the per-row scratch (2 KiB of candidate records per a row and b split) stays bounded
     const uint64_t chunk = three_term_only ? na : std::min<uint64_t>(na, kMatchChunk);
     const int splits = match_splits(long(chunk), long(nb), h->num_cus);

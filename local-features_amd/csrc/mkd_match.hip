@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void match_verify(const float *__restrict__ a,
     }
     // (b2 is the second largest of the records that survive; had a lost one been larger, `over` says so)
     const float keep_from = b2 - margin;
-    const bool over = lost >= keep_from;
+    const bool over = lost > -INFINITY && lost >= keep_from;
 
     float e1 = -INFINITY, e2 = -INFINITY;
     int ei = -1;

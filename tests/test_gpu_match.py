@@ -8,6 +8,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["scan", "screen"])
+def form(request, monkeypatch):
+    """Every test runs on both forms of the matcher (lf_mkd.h): the library picks by problem size, LF_MKD_MATCH forces."""
+    monkeypatch.setenv("LF_MKD_MATCH", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def lfp():
     import local_features_python as m
@@ -160,7 +167,13 @@ def run_device(lfp, torch, a, b, ratio=0.8, overflowed=None):
     return d_m.cpu().numpy(), d_1.cpu().numpy(), d_2.cpu().numpy()
 
 
-def test_crowded_candidates_take_the_full_scan(lfp, torch, oracle):
+def test_crowded_candidates_take_the_full_scan(lfp, torch, oracle, form):
+    if form != "screen":
+        pytest.skip("the candidate lists belong to the screen form")
+    _crowded(lfp, torch, oracle)
+
+
+def _crowded(lfp, torch, oracle):
     """The screening pass keeps at most 64 candidates per lane's share of b; hundreds of near-duplicates of a row's best
     match (a static scene seen in every frame) overflow that, and such rows must be redone by the full-precision scan --
     alone when they are few, everybody when they are many -- with the oracle's answers either way."""
@@ -192,9 +205,11 @@ def test_crowded_candidates_take_the_full_scan(lfp, torch, oracle):
 
 
 @pytest.mark.parametrize("scale_a,scale_b", [(1e-3, 1.0), (3e-5, 2e-4), (50.0, 0.01), (300.0, 120.0)])
-def test_match_of_unnormalised_rows(lfp, torch, oracle, scale_a, scale_b):
+def test_match_of_unnormalised_rows(lfp, torch, oracle, scale_a, scale_b, form):
     """The screening margin is derived from the rows' norms, not assumed: scaled inputs (f16 subnormals included) decide
-    as the oracle does."""
+    as the oracle does.  (The scan form is specified for rows of unit norm or larger, lf_mkd.h.)"""
+    if form == "scan" and min(scale_a, scale_b) < 1:
+        pytest.skip("scan form: rows of unit norm or larger")
     a, b = descriptor_sets(1500, 3000, 11)
     rng = np.random.default_rng(12)
     a = (a * scale_a * rng.uniform(0.5, 2.0, (len(a), 1))).astype(np.float32)
@@ -226,3 +241,15 @@ def test_more_rows_than_one_pass_takes(lfp, torch, oracle):
                    d_1.data_ptr(), d_2.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     compare(d_m.cpu().numpy(), d_1.cpu().numpy(), d_2.cpu().numpy(), want, s1, s2, np.float32(0.8), "two passes over a")
+
+
+def test_the_library_picks_a_form_by_size(lfp, torch, oracle, form, monkeypatch):
+    """Without LF_MKD_MATCH: a problem below the threshold (scan) and one above it (screen) both decide as the oracle."""
+    if form != "screen":
+        pytest.skip("one run is enough")
+    monkeypatch.delenv("LF_MKD_MATCH")
+    for na, nb in ((3000, 5000), (16384, 32768)):
+        a, b = descriptor_sets(na, nb, na ^ nb)
+        want, s1, s2 = oracle.match(a, b)
+        got, g1, g2 = run_device(lfp, torch, a, b)
+        compare(got, g1, g2, want, s1, s2, np.float32(0.8), (na, nb))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Matcher throughput: similarities per second and the equivalent dense f16 MFMA rate (3 MFMAs per product term set).
-Development aid; bench.py is the contract for the headline metric."""
+"""Matcher throughput: pairs per second and the f16 MFMA rate of the screening pass (one 256-flop term per pair; with
+LF_MKD_MATCH=scan the three-term scan, 768 flop per pair).  Development aid; bench.py is the contract for the headline metric."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "local-features_amd"))
@@ -26,5 +26,6 @@ for na, nb in ((2000, 2000), (10000, 10000), (65536, 65536), (65536, 1 << 20), (
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / it
     sims = na * nb / (ms * 1e-3)
-    print(f"{na} x {nb}: {ms:.3f} ms  {sims/1e12:.2f} T similarities/s  = {sims*128*2*3/1e15:.2f} PFLOP/s of f16 MFMA "
-          f"({sims*128*2*3/2.5e15*100:.0f} % of 2.5 PF dense)", flush=True)
+    terms = 3 if os.environ.get("LF_MKD_MATCH", "")[:1] == "s" else 1
+    print(f"{na} x {nb}: {ms:.3f} ms  {sims/1e12:.2f} T pairs/s  = {sims*128*2*terms/1e15:.2f} PFLOP/s of f16 MFMA "
+          f"({sims*128*2*terms/2.5e15*100:.0f} % of 2.5 PF dense), rows redone by the full scan: {h.match_overflowed(s)}", flush=True)
