@@ -32,6 +32,8 @@ sys.path.insert(0, os.path.join(ROOT, "local-features_amd"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_DESC = 4608          # 4096 B patch read + 512 B descriptor write
+FLOP_PER_DESC = 2 * 1024 * 238 + 2 * 238 * 128   # pooling (238 sums over 1024 pixels) + whitening, as f32 multiply-adds
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
 
 
 def host_cores():
@@ -275,6 +277,11 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
     run()                                                               # warm: the first call allocates the scratch
     res["match_ms"] = timed(run)
     res["rows_redone_by_full_scan"] = int(hm.match_overflowed(s))
+    # the match stage is matrix-core work: one 128-long f16 dot product per pair in the screening pass
+    tf = 2.0 * 128 * float(n) * n * world / (res["match_ms"] * 1e-3) / 1e12          # per GPU
+    res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": tf / MFMA_F16_PEAK_TFLOPS, "flop_per_pair": 256, "traffic": None,
+                       "what": "per GPU, whole match call (split + screen + verify) on its clock"}
     res["similarities_per_s"] = float(n) * n * world * world / (res["match_ms"] * 1e-3)
     # accepted matches point outside the query's own image, and every best similarity is a valid cosine
     acc = m >= 0
@@ -449,7 +456,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mkd_pool", "kernel_ms": kern_s * 1e3,
-                         "algorithmic_bytes_per_launch": BYTES_PER_DESC * n},
+                         "algorithmic_bytes_per_launch": BYTES_PER_DESC * n,
+                         # beside it, the arithmetic view (informative): the path's f32 arithmetic is a
+                         # [n x 1024] x [1024 x 238] pooling product + the 238 x 128 whitening; the matrix cores have no
+                         # f32-input rate above 157.3 TFLOP/s (MI355X_MICROARCH.md), the kernel buys its rate with f16 splits
+                         "f32_matrix_view": {"flop_per_descriptor": FLOP_PER_DESC,
+                                             "achieved": FLOP_PER_DESC * n / kern_s / 1e12, "peak": 157.3,
+                                             "unit": "TFLOP/s", "frac": FLOP_PER_DESC * n / kern_s / 1e12 / 157.3}},
             "match_stage": stage,
         }
         if world == 1 and not args.no_extras:
