@@ -49,27 +49,39 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("LF_BENCH_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(n_sample, seed):
-    """Oracle (oracle/mkd_oracle.c) on the host cores; the only place bench.py touches oracle/."""
+def cpu_baseline(seconds, seed):
+    """The CPU legs, the only place bench.py touches oracle/: the CPU-organised port of the path (oracle/mkd_cpu_fast.c: one
+    sine / cosine per pixel, pooling as register-blocked AVX2 dot products) on the host cores for about `seconds`, one thread
+    beside it, and the shader-structured oracle proper (the parity checker) for comparison."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle import MkdOracle
     cores = host_cores()
     o = MkdOracle(os.path.join(ROOT, "local-features_amd", "models", "mkd", "concat-pca-liberty.safetensors"))
-    p = np.random.default_rng(seed).random((n_sample, 32, 32), dtype=np.float32)
-    o.describe_patches(p[:256], nthreads=cores)                    # warm
+    pool = np.random.default_rng(seed).random((65536, 32, 32), dtype=np.float32)      # 256 MiB, swept repeatedly
+    o.describe_patches_fast(pool[:4096], nthreads=cores)                              # warm, calibrate
     t0 = time.perf_counter()
-    o.describe_patches(p, nthreads=cores)
+    o.describe_patches_fast(pool[:16384], nthreads=cores)
+    rate = 16384 / (time.perf_counter() - t0)
+    sweeps = max(1, int(round(seconds * rate / len(pool))))
+    t0 = time.perf_counter()
+    for _ in range(sweeps):
+        o.describe_patches_fast(pool, nthreads=cores)
     dt = time.perf_counter() - t0
-    # one thread beside it (SURVEY 8d asks for both), on a sample sized for ~2 s
-    n1 = max(256, min(n_sample, int(2.0 * n_sample / dt / max(cores, 1))))
+    n = sweeps * len(pool)
+    n1 = max(1024, min(len(pool), int(2.0 * n / dt / max(cores, 1))))                 # one thread, ~2 s
     t1 = time.perf_counter()
-    o.describe_patches(p[:n1], nthreads=1)
+    o.describe_patches_fast(pool[:n1], nthreads=1)
     dt1 = time.perf_counter() - t1
-    return {"value": n_sample / dt, "unit": "descriptors/s", "cores": cores, "kind": "port",
-            "single_thread_value": n1 / dt1,
-            "sample": f"{n_sample} uniform-random 32x32 patches, {cores} pthreads, {dt:.1f} s "
-                      f"(single thread: {n1} patches, {dt1:.1f} s); "
+    n2 = max(1024, min(len(pool), int(n / dt / 6)))                                   # the oracle proper, ~2 s on all cores
+    t2 = time.perf_counter()
+    o.describe_patches(pool[:n2], nthreads=cores)
+    dt2 = time.perf_counter() - t2
+    return {"value": n / dt, "unit": "descriptors/s", "cores": cores, "kind": "port",
+            "single_thread_value": n1 / dt1, "shader_structured_oracle_value": n2 / dt2,
+            "sample": f"{n} uniform-random 32x32 patches ({sweeps} sweeps of {len(pool)}), {cores} pthreads, {dt:.1f} s, "
+                      f"oracle/mkd_cpu_fast.c (AVX2 + FMA, -march=x86-64-v3; single thread: {n1} patches, {dt1:.1f} s); "
+                      f"the parity oracle oracle/mkd_oracle.c on the same cores: {n2} patches, {dt2:.1f} s; "
                       "LUTs and whitening matrix built once (the reference rebuilds them per patch)"}
 
 
@@ -319,7 +331,7 @@ def main():
     ap.add_argument("--patches", type=int, default=1 << 20, help="patches per GPU per step")
     ap.add_argument("--angle", choices=["shader", "exact", "exact_zero"], default="shader")
     ap.add_argument("--pool", choices=["f32", "f16x3"], default=os.environ.get("LF_MKD_POOL", "f16x3"))
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="patches for the CPU baseline (0: skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="seconds of CPU work for the CPU baseline (default ~12; 0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary pipeline figures")
     ap.add_argument("--no-match", action="store_true", help="skip the all-gather + cross-image match stage")
     ap.add_argument("--kpts-per-image", type=int, default=8192, help="descriptors per image in the match stage "
@@ -473,13 +485,8 @@ def main():
             except Exception as e:       # secondary figures must never cost the headline
                 line["pipelines"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1:
-            ns = args.cpu_sample
-            if ns < 0:
-                ns = 131072
-            if ns > 0:
-                cb = cpu_baseline(8192, 1)          # calibrate: aim at ~15 s of CPU work
-                ns = int(min(max(cb["value"] * 15, 8192), ns * 16))
-                line["cpu_baseline"] = cpu_baseline(ns, 0x4D4B44)
+            if args.cpu_sample != 0:                                  # seconds of CPU work (default about 12; 0: skip)
+                line["cpu_baseline"] = cpu_baseline(12.0 if args.cpu_sample < 0 else float(args.cpu_sample), 0x4D4B44)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -47,6 +47,7 @@ class MkdOracle:
         L.mkd_oracle_atan2_shader.argtypes = [ctypes.c_float, ctypes.c_float]
         L.mkd_oracle_describe_patches.argtypes = [
             ctypes.c_void_p, _fp, ctypes.c_long, _fp, _fp, ctypes.c_int, ctypes.c_int]
+        L.mkd_cpu_fast_describe_patches.argtypes = [ctypes.c_void_p, _fp, ctypes.c_long, _fp, ctypes.c_int, ctypes.c_int]
         L.mkd_oracle_sample_patches.argtypes = [
             _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_long, ctypes.c_float, _fp]
         L.mkd_oracle_build_pyramid.argtypes = [_fp, ctypes.c_int, ctypes.c_int, _fp]
@@ -119,6 +120,15 @@ class MkdOracle:
             self._consts.ctypes.data_as(ctypes.c_void_p), _ptr(p), n, _ptr(desc),
             _ptr(raw) if want_raw else None, atan_mode, nthreads)
         return (desc, raw) if want_raw else desc
+
+    def describe_patches_fast(self, patches, atan_mode=ATAN_SHADER, nthreads=1):
+        """The CPU-organised port (mkd_cpu_fast.c): what bench.py times as cpu_baseline.  Not a parity reference; held to
+        the oracle by tests/test_oracle.py."""
+        p = _f32(patches).reshape(-1, 32, 32)
+        desc = np.zeros((p.shape[0], 128), np.float32)
+        self.L.mkd_cpu_fast_describe_patches(self._consts.ctypes.data_as(ctypes.c_void_p), _ptr(p), p.shape[0], _ptr(desc),
+                                             atan_mode, nthreads)
+        return desc
 
     def quirk_pixels(self, patches, tol=2e-7):
         """Per patch: pixels with gy != 0 and |gx| <= tol, i.e. on the x == 0 discontinuity of atan2.glsl."""

@@ -245,3 +245,21 @@ def test_matcher_restates_match_features(oracle):
     mx = oracle.match(a, b, exclude=(lo, hi), nthreads=3)[0]
     assert (mx[mx >= 0] >= 350).all()
     assert np.array_equal(oracle.match(a, b, nthreads=1)[0], m)
+
+
+def test_cpu_baseline_port_agrees_with_the_oracle(oracle):
+    """oracle/mkd_cpu_fast.c (what bench.py times as cpu_baseline) is the same arithmetic organised for a CPU: it must give
+    the oracle's descriptors (contracted-blur reading) to rounding, in both angle modes, quirk pixels included, and for any
+    thread count."""
+    from oracle import ATAN_LIBM, ATAN_SHADER, BLUR_CONTRACT
+    rng = np.random.default_rng(31)
+    flat = np.full((3, 32, 32), 0.25, np.float32)
+    flat[1, 10:20, 5:25] = 0.75                                  # exact gx == 0 / null gradients: the shader quirk
+    flat[2, :, 16:] = 0.5
+    smooth = rng.random((200, 8, 8)).astype(np.float32).repeat(4, 1).repeat(4, 2)
+    p = np.concatenate([rng.random((1500, 32, 32), dtype=np.float32), smooth, flat[1:]])
+    for mode in (ATAN_SHADER, ATAN_LIBM):
+        want = oracle.describe_patches(p, atan_mode=mode | BLUR_CONTRACT, nthreads=8)
+        got = oracle.describe_patches_fast(p, atan_mode=mode, nthreads=3)
+        assert rel_l2(got, want).max() < 2e-5, (mode, rel_l2(got, want).max())
+        assert np.array_equal(got, oracle.describe_patches_fast(p, atan_mode=mode, nthreads=1))
