@@ -735,13 +735,33 @@ int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height
     if (dropped_blobs) *dropped_blobs = 0;
     if (dropped_features) *dropped_features = 0;
     if (max_out && (!keypoints || !descriptors)) return fail(h, LF_MKD_ERR_BAD_ARG, "detect: null output pointer");
-    if (int rc = lf_mkd_set_image(h, image, width, height)) return rc;
-    if (h->n_frames != 1) return fail(h, LF_MKD_ERR_BAD_ARG, "detect: one frame at a time");
+    if (!image) return fail(h, LF_MKD_ERR_BAD_ARG, "detect: null image");
+    if (!h->d_image || !h->d_pyr || width < 2 || height < 2 || width > h->params.max_image_width ||
+        height > h->params.max_image_height)
+        return fail(h, LF_MKD_ERR_BAD_ARG, "detect: image exceeds max_image_width/height given at creation");
+    LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = h->stream;
+    // lf_mkd_set_image without its synchronisation, and -- once the a-trous stack exists, i.e. from the second call on --
+    // with pyramid levels >= 1 (read by the sampler only) built on the side stream beside the a-trous passes and the scan
+    LF_HIP(h, hipMemcpyAsync(h->d_image, image, size_t(width) * height * 4, hipMemcpyHostToDevice, s));
+    describe_pyramid(width, height, h->pd);
+    const bool share = h->d_coarse != nullptr && h->pd.levels >= 2;
+    if (share)
+        if (int rc = ensure_side_stream(h, 2)) return rc;
+    launch_build_pyramid(h->d_image, long(width) * height, h->d_pyr, h->pyr_stride, h->d_tmp_a, h->d_tmp_b, h->pd, 1,
+                         share ? h->d_coarse : nullptr, h->coarse_stride, s, share ? h->side_stream : nullptr,
+                         share ? h->side_events[0] : nullptr, share ? h->side_events[1] : nullptr);
+    LF_HIP(h, hipGetLastError());
+    h->coarse_l1_valid = share;
+    h->have_image = true;
+    h->coarse_valid = false;
+    h->n_frames = 1;
     // detect graph: extrema, at most max_extrema of them (mod.rs:625-633)
     if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, h->max_extrema, sizeof(lf_mkd_extremum))) return rc;
     uint64_t n_ext = 0;
-    if (int rc = detect_extrema_device(h, h->d_det_extrema, nullptr, h->max_extrema, &n_ext, dropped_blobs, s)) return rc;
+    const int rc_ext = detect_extrema_device(h, h->d_det_extrema, nullptr, h->max_extrema, &n_ext, dropped_blobs, s);
+    if (share) LF_HIP(h, hipStreamWaitEvent(s, h->side_events[1], 0));   // whatever follows on s sees the whole pyramid
+    if (rc_ext) return rc_ext;
     // host blob filter of detect_top_n, on the device
     const float *d_sel = h->d_det_extrema;
     if (top_n && n_ext) {
@@ -861,9 +881,15 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
     LF_HIP(h, hipStreamSynchronize(h->stream));
 
     hipStream_t s = h->stream;
+    // the detector needs pyramid level 0 and a-trous layer 1 only: the other levels (read by the sampler at the very end)
+    // are a branch of the graph beside the a-trous stack, the scan, the selection and the orientation
+    const bool fork = h->pd.levels >= 2;
+    if (fork)
+        if (int rc = ensure_side_stream(h, 2)) return rc;
     LF_HIP(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     launch_build_pyramid(d_image, long(width) * height, h->d_pyr, h->pyr_stride, h->d_tmp_a, h->d_tmp_b, h->pd, 1,
-                         h->pd.levels >= 2 ? h->d_coarse : nullptr, h->coarse_stride, s);
+                         h->pd.levels >= 2 ? h->d_coarse : nullptr, h->coarse_stride, s, fork ? h->side_stream : nullptr,
+                         fork ? h->side_events[0] : nullptr, fork ? h->side_events[1] : nullptr);
     launch_build_coarse_stack(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride,
                               h->d_tmp_a, h->n_layers, h->pd.levels >= 2 ? 1 : 0, int(width), int(height), 1, s);
     launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride,
@@ -880,6 +906,7 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
     launch_orient(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride, h->n_layers,
                   int(width), int(height), d_sel, nullptr, long(cap), n_sel, h->d_angles, h->d_counts, h->d_orient_sums,
                   reinterpret_cast<float *>(d_keypoints), nullptr, max_out, cnt + 3, s);
+    if (fork) (void)hipStreamWaitEvent(s, h->side_events[1], 0);
     launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr,
                           long(max_out), cnt + 3, h->params.patch_scale_factor, h->d_stream_patches, s);
     launch_describe(h->d_stream_patches, long(max_out), cnt + 3, h->dc, h->params.angle_mode, h->params.pool_mode,

@@ -43,9 +43,12 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
 void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                            const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
                            float *patches, hipStream_t stream, bool beside_describe = false);
+// rest_stream (nullable): levels >= 1 are built there -- after `fork`, recorded on `stream` once level 0 and a-trous layer 1
+// exist -- and `join` is recorded behind them; the caller waits for `join` before it samples patches
 void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,
                           float *tmp_b, const PyramidDesc &pd, int frames, float *layer1, long layer1_stride,
-                          hipStream_t stream);
+                          hipStream_t stream, hipStream_t rest_stream = nullptr, hipEvent_t fork = nullptr,
+                          hipEvent_t join = nullptr);
 
 // a-trous layers 1 .. n_layers-1 over layer0 (= pyramid level 0); tmp holds frames x w x h floats
 void launch_build_coarse_stack(const float *layer0, long layer0_stride, float *coarse, long coarse_stride,

@@ -523,7 +523,7 @@ static void launch_swt(const float *in, long in_stride, float *out, long out_str
 // of tmp_b: it is layer 1 of the stack orientation and the detector read, so they need not build it again.
 void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,
                           float *tmp_b, const PyramidDesc &pd, int frames, float *layer1, long layer1_stride,
-                          hipStream_t stream) {
+                          hipStream_t stream, hipStream_t rest_stream, hipEvent_t fork, hipEvent_t join) {
     const int w = pd.w[0], h = pd.h[0];
     const long ts = (long)w * h;
     const dim3 blk(32, 8);
@@ -536,6 +536,13 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     float *l1 = layer1 ? layer1 : tmp_b;
     const long l1s = layer1 ? layer1_stride : ts;
     launch_swt(pyr + pd.offset[0], pyr_stride, l1, l1s, w, h, 1, frames, stream);
+    // Levels >= 1 are only read by the patch sampler: a caller whose next steps need level 0 and layer 1 alone (the
+    // detector) can have them built on `rest_stream` beside those steps and wait for `join` before it samples.
+    if (rest_stream) {
+        (void)hipEventRecord(fork, stream);
+        (void)hipStreamWaitEvent(rest_stream, fork, 0);
+        stream = rest_stream;
+    }
     hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)l1, pyr + pd.offset[1],
                        l1s, pyr_stride, w, h, pd.w[1], pd.h[1]);
     // levels >= 2: binomial H at the resolution of level l-1, then V with 2x decimation; the small levels in one launch
@@ -546,6 +553,7 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
                            dim3(256), 0, stream, (const float *)(pyr + pd.offset[l - 1]), pyr + pd.offset[l], pyr_stride,
                            pyr_stride, pd.w[l - 1], pd.h[l - 1], pd.w[l], pd.h[l]);
     if (l0 < pd.levels) hipLaunchKernelGGL(pyr_tail, dim3(frames), dim3(1024), 0, stream, pyr, pyr_stride, pd, l0);
+    if (rest_stream) (void)hipEventRecord(join, rest_stream);
 }
 
 // Layers 1 .. n_layers-1 of the a-trous stack (mod.rs:1093-1130): layer l+1 = [1 4 6 4 1]/16 H then V over layer l
