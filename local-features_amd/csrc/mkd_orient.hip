@@ -159,9 +159,10 @@ __global__ __launch_bounds__(256) void orient_peaks(const float *__restrict__ la
     }
 }
 
-// Ordered compaction: keypoint list = for each extremum in index order, its peaks in bin order.  One workgroup
-// walks the extrema 1024 at a time with a running offset (n is a few thousand per frame; the scan is not the
-// cost).  totals[0] = keypoints written, totals[1] = keypoints dropped because max_out was reached.
+// Ordered compaction: keypoint list = for each extremum in index order, its peaks in bin order.  A workgroup takes 1024
+// extrema; its base is the sum of the counts before them, which it adds up itself (n is a few thousand per frame: a few
+// loads per thread, cheaper than a launch that scans).  The last workgroup leaves totals[0] = keypoints written,
+// totals[1] = keypoints dropped because max_out was reached.
 __global__ __launch_bounds__(1024) void orient_compact(const float *__restrict__ extrema,
                                                        const unsigned *__restrict__ frame_of,
                                                        const float *__restrict__ angles,
@@ -170,46 +171,50 @@ __global__ __launch_bounds__(1024) void orient_compact(const float *__restrict__
                                                        float *__restrict__ kps /*[max_out][5]*/,
                                                        unsigned *__restrict__ frame_of_kp, unsigned long long max_out,
                                                        unsigned long long *__restrict__ totals) {
-    __shared__ unsigned wave_sum[16];
+    __shared__ unsigned wave_sum[16], wave_base[16];
     const long n = n_dev ? (long)*n_dev : n_host;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long base = 0;
-    for (long chunk = 0; chunk < n; chunk += 1024) {
-        const long i = chunk + threadIdx.x;
-        const unsigned c = i < n ? counts[i] : 0u;
-        unsigned incl = c;
+    const long chunk = (long)blockIdx.x * 1024;
+    unsigned mine = 0;
+    for (long k = threadIdx.x; k < chunk && k < n; k += 1024) mine += counts[k];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63) wave_sum[wave] = incl;
-        __syncthreads();
-        unsigned before = 0, all = 0;
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0) wave_base[wave] = mine;
+    const long i = chunk + threadIdx.x;
+    const unsigned c = i < n ? counts[i] : 0u;
+    unsigned incl = c;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const unsigned t = wave_sum[v];
-            before += v < wave ? t : 0u;
-            all += t;
-        }
-        const unsigned long long first = base + before + incl - c;
-        for (unsigned j = 0; j < c; ++j) {
-            const unsigned long long o = first + j;
-            if (o < max_out) {
-                kps[o * 5 + 0] = extrema[i * 4 + 0];
-                kps[o * 5 + 1] = extrema[i * 4 + 1];
-                kps[o * 5 + 2] = extrema[i * 4 + 2];
-                kps[o * 5 + 3] = angles[i * kOriMaxPeaks + j];
-                kps[o * 5 + 4] = extrema[i * 4 + 3];
-                if (frame_of_kp) frame_of_kp[o] = frame_of ? frame_of[i] : 0u;
-            }
-        }
-        base += all;
-        __syncthreads();
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
     }
-    if (threadIdx.x == 0) {
-        totals[0] = base < max_out ? base : max_out;
-        totals[1] = base < max_out ? 0ull : base - max_out;
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    unsigned before = 0, all = 0;
+    unsigned long long base = 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const unsigned t = wave_sum[v];
+        before += v < wave ? t : 0u;
+        all += t;
+        base += wave_base[v];
+    }
+    const unsigned long long first = base + before + incl - c;
+    for (unsigned j = 0; j < c; ++j) {
+        const unsigned long long o = first + j;
+        if (o < max_out) {
+            kps[o * 5 + 0] = extrema[i * 4 + 0];
+            kps[o * 5 + 1] = extrema[i * 4 + 1];
+            kps[o * 5 + 2] = extrema[i * 4 + 2];
+            kps[o * 5 + 3] = angles[i * kOriMaxPeaks + j];
+            kps[o * 5 + 4] = extrema[i * 4 + 3];
+            if (frame_of_kp) frame_of_kp[o] = frame_of ? frame_of[i] : 0u;
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const unsigned long long total = base + all;
+        totals[0] = total < max_out ? total : max_out;
+        totals[1] = total < max_out ? 0ull : total - max_out;
     }
 }
 
@@ -280,9 +285,10 @@ void launch_orient(const float *layer0, long layer0_stride, const float *coarse,
         hipLaunchKernelGGL(orient_peaks, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, layer0, layer0_stride,
                            coarse, coarse_stride, layer_stride, n_layers, w, h, extrema, frame_of, n, n_dev, angles,
                            counts);
-    if (n <= 8192 || !sums) {   // a few thousand extrema (one frame): one workgroup walks them
-        hipLaunchKernelGGL(orient_compact, dim3(1), dim3(1024), 0, stream, extrema, frame_of, (const float *)angles,
-                           (const unsigned *)counts, n, n_dev, kps, frame_of_kp, max_out, totals);
+    if (n <= 8192 || !sums) {   // a few thousand extrema (one frame): every workgroup adds up the counts before its own
+        const long nbc = n > 0 ? (n + 1023) / 1024 : 1;
+        hipLaunchKernelGGL(orient_compact, dim3((unsigned)nbc), dim3(1024), 0, stream, extrema, frame_of,
+                           (const float *)angles, (const unsigned *)counts, n, n_dev, kps, frame_of_kp, max_out, totals);
         return;
     }
     const long nb = (n + 1023) / 1024;

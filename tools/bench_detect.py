@@ -110,10 +110,11 @@ def run_batch(w, h, top_n, frames, tag, sigma=1.8):
           f"{dt/frames*1e3:.4f} ms/frame, {m/dt/1e6:.1f} M desc/s (dropped blobs {db}, features {df})", flush=True)
 
 
-run_batch(640, 480, 1400, 256, "configs[2] batched")
-run(3840, 2160, 6000, 20, "configs[4]")
-run_graph(3840, 2160, 6000, 20, "configs[4]")
-run_graph(1920, 1080, 7000, 20, "configs[1]-sized")
-run_graph(640, 480, 1400, 20, "configs[2]-sized frame", sigma=1.8)
-run(1920, 1080, 7000, 20, "configs[1]-sized")
-run(640, 480, 1400, 20, "configs[2]-sized frame", sigma=1.8)
+if __name__ == "__main__":
+    run_batch(640, 480, 1400, 256, "configs[2] batched")
+    run(3840, 2160, 6000, 20, "configs[4]")
+    run_graph(3840, 2160, 6000, 20, "configs[4]")
+    run_graph(1920, 1080, 7000, 20, "configs[1]-sized")
+    run_graph(640, 480, 1400, 20, "configs[2]-sized frame", sigma=1.8)
+    run(1920, 1080, 7000, 20, "configs[1]-sized")
+    run(640, 480, 1400, 20, "configs[2]-sized frame", sigma=1.8)
