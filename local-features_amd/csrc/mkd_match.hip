@@ -2,22 +2,23 @@
 // Reference semantics: examples/match_images/src/main.rs:8-27 -- for every row of a: similarity = dot product
 // with every row of b, best and second best, accept if best * ratio > second.
 //
-// The similarity matrix is a GEMM (K = 128) and lives on the matrix cores: S^T tile = b tile (32 rows) x a tile
-// (32 columns) by v_mfma_f32_32x32x16_f16.  With b on the M side, a lane of the accumulator tile holds ONE a
-// column and 16 b rows, so the running best / second best of an a row is an in-register reduction; lanes never
-// exchange anything until the very end.  f32 accuracy comes from the same three-term f16 split as the pooling
-// kernel (hi*hi + lo*hi + hi*lo, f32 accumulate, ~2^-21 relative): both sides are split once by `match_split`
-// into MFMA operand order, so the hot loop only moves fragments.
+// The similarity matrix is a GEMM (K = 128) and lives on the matrix cores, b on the M side: a lane of an accumulator
+// tile then holds ONE a column and a few b rows, so the running best / second best of an a row is an in-register
+// reduction.  Both sides are split once by `match_split` into f16 hi / lo MFMA operand tiles, so the hot loops only move
+// fragments.  Two forms (lf_mkd.h), chosen by problem size in lf_mkd_match_device:
 //
-// Two passes (the default): SCREEN with the hi*hi term alone (a third of the matrix work), which is within a known
-// margin of the true similarity, recording every candidate that could still be among the two best; VERIFY re-scores the
-// few survivors in f32 and decides.  The result is that of an exact scan (see `screen_margin`); a query whose record list
-// overflows sends the call to the three-term scan below, gated on the device (no host round trip).
+//   SCAN (`match_scan` + `match_merge`): every pair from three terms, hi*hi + lo*hi + hi*lo (f32 accumulate, ~2^-21
+//   relative), v_mfma_f32_32x32x16_f16.  Workgroup = 8 waves x 64 a rows resident in registers (2 x 64 VGPRs of fragments
+//   per wave); b streams through LDS in 32-row tiles (16 KiB, LDS-DMA, double buffered), each tile read once per
+//   workgroup; grid = (a blocks, b splits): a split scans one contiguous range of b tiles and writes partial (best,
+//   index, second) per a row; `match_merge` folds the partials and applies the ratio test.
 //
-//   workgroup = 8 waves x 64 a rows = 512 a rows, resident in registers (2 x 64 VGPRs of fragments per wave);
-//   b streams through LDS in 32-row tiles (16 KiB, LDS-DMA, double buffered), each tile read once per workgroup;
-//   grid = (a blocks, b splits): a split scans one contiguous range of b tiles and writes partial
-//   (best, index, second) per a row; `match_merge` folds the partials and applies the ratio test.
+//   SCREEN + VERIFY (`match_screen`, `match_verify`): every pair from the hi*hi term alone (a third of the matrix work,
+//   v_mfma_f32_16x16x32_f16), which is within a margin derived from the rows' norms of the true similarity; every
+//   candidate that could still be among an a row's two best is recorded, the few survivors are re-scored in f32 and the
+//   decision taken on those values -- the result of an exhaustive f32 scan (see `screen_margin`).  An a row whose record
+//   ring lost something verify needed is redone by the scan, alone (`match_split_rows`) or with everybody, gated on the
+//   device (`MatchGate`: no host round trip).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
