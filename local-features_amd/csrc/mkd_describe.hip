@@ -572,7 +572,7 @@ __device__ __forceinline__ void finish_descriptors(const f32x4 (&acc_row)[kAccTi
 #ifdef LF_PHASE_TIMING   // timing-only build (tools/phase_timing.py): per-wave wall clock of the phases of a patch row,
                          // left by workgroup 0 in out[wave * 128 + phase]
 #define LF_PT(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
-                      pt[i] += t_ - pt_prev; pt_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+                      phase_clk[i] += t_ - phase_prev; phase_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define LF_PT(i) do { } while (0)
 #endif
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
     }
     unsigned par = 0;  // LUT row buffer holding the row about to be consumed
 #ifdef LF_PHASE_TIMING
-    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_prev = __builtin_readcyclecounter();
+    unsigned long long phase_clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, phase_prev = __builtin_readcyclecounter();
 #endif
 
     for (; batch < nbatch; batch += gridDim.x) {
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
 #ifdef LF_PHASE_TIMING
     __syncthreads();
     if (blockIdx.x == 0 && lane == 0)
-        for (int i = 0; i < 8; ++i) out[wave * 128 + i] = (float)pt[i];
+        for (int i = 0; i < 8; ++i) out[wave * 128 + i] = (float)phase_clk[i];
 #endif
 }
 

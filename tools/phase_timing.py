@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "local-features_amd"))
 import torch
 import local_features_python as lfp
 
-NAMES = ["sync wait", "blur", "gradient+direction", "m stream", "abs family", "rel family", "epilogue", "loop"]
+NAMES = ["sync wait", "blur", "gradient+direction", "m stream", "harmonics (cos / sin streams)", "(unused stamp)", "epilogue", "loop"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 p = torch.rand((n, 32, 32), device="cuda")
 out = torch.empty((n, 128), device="cuda")
@@ -26,4 +26,4 @@ for angle in (lfp.ANGLE_SHADER, lfp.ANGLE_EXACT_ZERO):
     tot = t.sum(axis=1)
     print(f"angle={angle}: {dt*1e3:.3f} ms; cycles per wave {tot.mean():.3e} (= {tot.mean()/dt/1e6:.1f} MHz counter)")
     for i, name in enumerate(NAMES):
-        print(f"  {name:20s} {t[:, i].mean() / tot.mean() * 100:5.1f} %   per wave: " + " ".join(f"{v/1e3:8.0f}k" for v in t[:, i]))
+        print(f"  {name:30s} {t[:, i].mean() / tot.mean() * 100:5.1f} %   per wave: " + " ".join(f"{v/1e3:8.0f}k" for v in t[:, i]))
