@@ -187,6 +187,76 @@ __device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 r2,
     }
 }
 
+// The same for the lane's four pixel pairs at once, written step by step across the pairs: the polynomial chains of a
+// pair are serial (each packed fma waits for the one before it, and hipcc pads back-to-back dependent packed operations
+// with s_nop), the four pairs are independent -- in this order every instruction has three others between it and the one
+// it depends on.  Same operations on the same values as gradient_direction: bit-identical.
+template <int ANGLE>
+__device__ __forceinline__ void gradient_direction4(const f32x2 (&gx)[4], const f32x2 (&gy)[4], const f32x2 (&r2)[4],
+                                                    f32x2 (&ct)[4], f32x2 (&st)[4]) {
+    if (ANGLE != LF_ANGLE_SHADER) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gradient_direction<ANGLE>(gx[e], gy[e], r2[e], ct[e], st[e]);
+        return;
+    }
+    f32x2 a[4], s[4], p[4], p2[4], sn[4], cs[4];
+    bool sw0[4], sw1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ax0 = fabsf(gx[e].x), ay0 = fabsf(gy[e].x), ax1 = fabsf(gx[e].y), ay1 = fabsf(gy[e].y);
+        sw0[e] = ax0 < ay0;
+        sw1[e] = ax1 < ay1;
+        const f32x2 mn = {__builtin_fminf(ax0, ay0), __builtin_fminf(ax1, ay1)};
+        const f32x2 mx = {__builtin_fmaxf(ax0, ay0), __builtin_fmaxf(ax1, ay1)};
+        a[e] = mn * f32x2{__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = a[e] * a[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[e] = pk_fma(s[e], pk_set(-0.0117212f), pk_set(0.05265332f));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[e] = pk_fma(s[e], p[e], pk_set(-0.11643287f));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[e] = pk_fma(s[e], p[e], pk_set(0.19354346f));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[e] = pk_fma(s[e], p[e], pk_set(-0.33262347f));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[e] = pk_fma(s[e], p[e], pk_set(0.99997726f));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[e] = a[e] * p[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p2[e] = p[e] * p[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sn[e] = pk_fma(p2[e], pk_set(-0.000195038549f), pk_set(0.0083320355f));
+        cs[e] = pk_fma(p2[e], pk_set(-0.00135857589f), pk_set(0.0416550152f));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sn[e] = pk_fma(p2[e], sn[e], pk_set(-0.166666508f));
+        cs[e] = pk_fma(p2[e], cs[e], pk_set(-0.499998569f));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sn[e] = pk_fma(p2[e], sn[e], pk_set(1.f));
+        cs[e] = pk_fma(p2[e], cs[e], pk_set(1.f));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sn[e] = p[e] * sn[e];
+    const unsigned sgn = 0x80000000u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float cr0 = __uint_as_float(__float_as_uint(sw0[e] ? sn[e].x : cs[e].x) | (__float_as_uint(gx[e].x) & sgn));
+        float cr1 = __uint_as_float(__float_as_uint(sw1[e] ? sn[e].y : cs[e].y) | (__float_as_uint(gx[e].y) & sgn));
+        float sr0 = __uint_as_float(__float_as_uint(sw0[e] ? cs[e].x : sn[e].x) | (~__float_as_uint(gy[e].x) & sgn));
+        float sr1 = __uint_as_float(__float_as_uint(sw1[e] ? cs[e].y : sn[e].y) | (~__float_as_uint(gy[e].y) & sgn));
+        if (gx[e].x == 0.f) { cr0 = 1.f; sr0 = 0.f; }
+        if (gx[e].y == 0.f) { cr1 = 1.f; sr1 = 0.f; }
+        ct[e] = f32x2{cr0, cr1};
+        st[e] = f32x2{sr0, sr1};
+    }
+}
+
 // ---- B fragments (LUT) and A fragments (streams) -------------------------------------------------
 // One unique LUT tile = two 1 KiB pieces: f32: pixels 0-3 / 4-7 of the lane's segment (K = 4 MFMAs);
 // f16: hi / lo halves of all 8 pixels (K = 32 MFMAs).  16 B per lane either way.
@@ -225,16 +295,42 @@ template <> struct AFrag<LF_POOL_F16X3> {
         for (int e = 0; e < 4; ++e) { hi[e] = __float_as_uint(a[e].x); lo[e] = __float_as_uint(a[e].y); }
         return;
 #endif
+        // (written step by step across the four pairs: conversion, residuals, conversion are each one dependent on the
+        // other; across the pairs they are not)
         float one = 1.f;
         asm("" : "+v"(one));
+        float r0[4], r1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hi[e] = pack_rtz(a[e].x, a[e].y);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const unsigned h = pack_rtz(a[e].x, a[e].y);
-            const float h0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xffffu));
-            const float h1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(h >> 16));
-            hi[e] = h;
-            lo[e] = pack_rtz(__builtin_fmaf(a[e].x, one, -h0), __builtin_fmaf(a[e].y, one, -h1));
+            const float h0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(hi[e] & 0xffffu));
+            const float h1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(hi[e] >> 16));
+            r0[e] = __builtin_fmaf(a[e].x, one, -h0);
+            r1[e] = __builtin_fmaf(a[e].y, one, -h1);
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lo[e] = pack_rtz(r0[e], r1[e]);
+    }
+    // two streams at once (the cos and sin streams of a harmonic): twice as many independent operations per step
+    __device__ __forceinline__ static void set2(AFrag &x, const f32x2 (&a)[4], AFrag &y, const f32x2 (&b)[4]) {
+#ifdef LF_ABLATE_SPLIT
+        x.set(a); y.set(b); return;
+#endif
+        float one = 1.f;
+        asm("" : "+v"(one));
+        float ra0[4], ra1[4], rb0[4], rb1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x.hi[e] = pack_rtz(a[e].x, a[e].y); y.hi[e] = pack_rtz(b[e].x, b[e].y); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ra0[e] = __builtin_fmaf(a[e].x, one, -(float)__builtin_bit_cast(_Float16, (unsigned short)(x.hi[e] & 0xffffu)));
+            ra1[e] = __builtin_fmaf(a[e].y, one, -(float)__builtin_bit_cast(_Float16, (unsigned short)(x.hi[e] >> 16)));
+            rb0[e] = __builtin_fmaf(b[e].x, one, -(float)__builtin_bit_cast(_Float16, (unsigned short)(y.hi[e] & 0xffffu)));
+            rb1[e] = __builtin_fmaf(b[e].y, one, -(float)__builtin_bit_cast(_Float16, (unsigned short)(y.hi[e] >> 16)));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x.lo[e] = pack_rtz(ra0[e], ra1[e]); y.lo[e] = pack_rtz(rb0[e], rb1[e]); }
     }
 };
 
@@ -331,8 +427,12 @@ __device__ __forceinline__ void pool_harmonics(const f32x2 (&m)[4], const f32x2 
     for (int e = 0; e < 4; ++e) { pk[e] = m[e] * c1[e]; qk[e] = m[e] * s1[e]; tc[e] = c1[e] + c1[e]; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        ac.set(pk);
-        as.set(qk);
+        if constexpr (POOL == LF_POOL_F16X3) {
+            AFrag<POOL>::set2(ac, pk, as, qk);
+        } else {
+            ac.set(pk);
+            as.set(qk);
+        }
         if (k < 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -698,21 +798,25 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
             LF_PT(1);
 
             f32x2 m[4], c1[4], s1[4];
+            {
+                f32x2 gx[4], gy[4], r2n[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {  // patch_gradients.glsl:94-100, two pixels at a time
-                const int x = 2 * e;
-                const f32x2 left = {x == 0 ? cur_l : cur[x - 1], cur[x]};
-                const f32x2 right = {cur[x + 1], x == 6 ? cur_r : cur[x + 2]};
-                const f32x2 gx = left - right;                                   // left - right
-                const f32x2 gy = f32x2{nxt[x], nxt[x + 1]} - f32x2{prv[x], prv[x + 1]};   // down - up
-                const f32x2 r2n = pk_fma(gy, gy, gx * gx);
-                const f32x2 r2 = r2n + pk_set(1e-8f);
-                m[e] = f32x2{__builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(r2.x)),
-                             __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(r2.y))};
+                for (int e = 0; e < 4; ++e) {  // patch_gradients.glsl:94-100, two pixels at a time
+                    const int x = 2 * e;
+                    const f32x2 left = {x == 0 ? cur_l : cur[x - 1], cur[x]};
+                    const f32x2 right = {cur[x + 1], x == 6 ? cur_r : cur[x + 2]};
+                    gx[e] = left - right;                                               // left - right
+                    gy[e] = f32x2{nxt[x], nxt[x + 1]} - f32x2{prv[x], prv[x + 1]};      // down - up
+                    r2n[e] = pk_fma(gy[e], gy[e], gx[e] * gx[e]);
+                    const f32x2 r2 = r2n[e] + pk_set(1e-8f);
+                    m[e] = f32x2{__builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(r2.x)),
+                                 __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(r2.y))};
+                }
 #ifdef LF_ABLATE_FRONT
-                c1[e] = gx; s1[e] = gy;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { c1[e] = gx[e]; s1[e] = gy[e]; }
 #else
-                gradient_direction<ANGLE>(gx, gy, r2n, c1[e], s1[e]);
+                gradient_direction4<ANGLE>(gx, gy, r2n, c1, s1);
 #endif
             }
 #pragma unroll
