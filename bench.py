@@ -232,9 +232,12 @@ def pipeline_extras(lfp, torch, device):
     return out
 
 
-def launch_ranks(n):
+def launch_ranks(n, limit_s=None):
     """`bench.py --gpus N` without a launcher's environment: start the N ranks here, as children of a parent that never
-    touches the GPU (a process that has initialised HIP must not be replaced or forked), and pass on their exit code."""
+    touches the GPU (a process that has initialised HIP must not be replaced or forked), and pass on their exit code.
+    The children get a wall-clock limit (LF_BENCH_LAUNCH_LIMIT_S, default 1500 s): a rank stuck in a collective its peers
+    never entered is killed with its whole process group and the parent exits non-zero -- it never re-launches."""
+    import signal
     import socket
     import subprocess
     sock = socket.socket()
@@ -244,7 +247,24 @@ def launch_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    return subprocess.call(cmd, env=env)
+    if limit_s is None:
+        limit_s = float(os.environ.get("LF_BENCH_LAUNCH_LIMIT_S", "1500"))
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)      # its own process group: exactly what we may kill
+    try:
+        return child.wait(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write(f"bench.py: the {n} ranks did not finish within {limit_s:.0f} s; killing them\n")
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(child.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
 
 
 def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehearsal, gathered, out, n):
@@ -357,6 +377,9 @@ def main():
     if rehearsal:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    # Everything below runs on ONE explicit stream: the ABI reads stream handle 0 (which is what torch's default stream
+    # reports) as "the library's own stream", which is not ordered with torch's work.
+    torch.cuda.set_stream(torch.cuda.Stream())
     dist = None
     if world > 1:
         import torch.distributed as dist

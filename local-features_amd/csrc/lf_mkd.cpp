@@ -355,10 +355,12 @@ int grow(lf_mkd *h, T **p, uint64_t *cap, uint64_t want, size_t elem_bytes) {
 
 // scratch of the long-list top-n selection; its histograms are zero between uses (the selection's last launch leaves them
 // so), which a fresh allocation has to establish once
-int grow_topk_work(lf_mkd *h, uint64_t n_cap) {
+// (zeroed on the stream the selection will run on, outside any capture: the consumers' streams are non-blocking, i.e. not
+// ordered with the null stream)
+int grow_topk_work(lf_mkd *h, uint64_t n_cap, hipStream_t s) {
     const uint64_t before = h->topk_work_cap;
     if (int rc = grow(h, &h->d_topk_work, &h->topk_work_cap, topk_work_words(n_cap), 4)) return rc;
-    if (h->topk_work_cap != before) LF_HIP(h, hipMemset(h->d_topk_work, 0, topk_work_words(n_cap) * 4));
+    if (h->topk_work_cap != before) LF_HIP(h, hipMemsetAsync(h->d_topk_work, 0, topk_work_words(n_cap) * 4, s));
     return LF_MKD_OK;
 }
 
@@ -724,7 +726,7 @@ int lf_mkd_filter_extrema_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, ui
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     if (!h->d_sel_count) LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_sel_count), 4 * h->max_frames));
-    if (int rc = grow_topk_work(h, n)) return rc;
+    if (int rc = grow_topk_work(h, n, s)) return rc;
     launch_topk_filter(reinterpret_cast<const float *>(d_extrema), nullptr, nullptr, n, 1, 0xFFFFFFFFu, top_n, min_size,
                        reinterpret_cast<float *>(d_out), d_index, h->d_sel_count, nullptr, n, h->d_topk_work, s);
     LF_HIP(h, hipGetLastError());
@@ -881,7 +883,7 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
     const uint64_t cap = top_n ? top_n : h->max_extrema;   // extrema that can reach orientation
     if (top_n) {
         if (int rc = grow(h, &h->d_det_selected, &h->det_sel_cap, top_n, sizeof(lf_mkd_extremum))) return rc;
-        if (int rc = grow_topk_work(h, h->max_extrema)) return rc;
+        if (int rc = grow_topk_work(h, h->max_extrema, h->stream)) return rc;
     }
     if (int rc = ensure_orient_scratch(h, cap, false, 0)) return rc;
     if (int rc = grow(h, &h->d_stream_patches, &h->stream_patch_cap, max_out * kPx, sizeof(float))) return rc;
@@ -975,6 +977,8 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
     float *p_best = h->d_match_part, *p_second = p_best + uint64_t(splits) * chunk;
     int *p_index = reinterpret_cast<int *>(p_second + uint64_t(splits) * chunk);
     if (three_term_only) {
+        // lf_mkd_match_overflowed reports on the LATEST call: this form redoes nothing
+        if (h->d_match_misc) LF_HIP(h, hipMemsetAsync(h->d_match_misc + 2, 0, sizeof(unsigned), s));
         launch_match_split(d_a, long(na), h->d_match_a, nullptr, nullptr, s);
         launch_match_split(d_b, long(nb), h->d_match_b, nullptr, nullptr, s);
         launch_match(h->d_match_a, long(na), h->d_match_b, long(nb), d_exclude_lo, d_exclude_hi, ratio, splits, p_best,

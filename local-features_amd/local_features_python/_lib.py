@@ -243,55 +243,72 @@ class MkdHandle:
         return out
 
     # --- device-pointer entry points ---------------------------------------------------------
+    # `stream`: a HIP stream handle (e.g. torch.cuda.Stream().cuda_stream) on which the work is enqueued, in order with
+    # whatever the caller has enqueued there.  None / 0 selects the handle's OWN non-blocking stream (lf_mkd.h), which is
+    # NOT ordered with torch's streams -- and 0 is also what torch's default stream reports as its handle.  So that the
+    # default is safe for torch callers, a call without a stream first waits for the device (the inputs a torch kernel is
+    # still producing are complete) and returns only when its own work is done: synchronous, like the host-pointer
+    # entry points.  Callers that want asynchrony pass a real stream.
+    def _device_call(self, stream, fn, what):
+        own = not stream
+        if own:
+            import sys
+            t = sys.modules.get("torch")
+            if t is not None and t.cuda.is_available() and t.cuda.is_initialized():
+                t.cuda.synchronize()
+        self._check(fn(None if own else stream), what)
+        if own:
+            self.synchronize()
+
     def describe_patches_device(self, d_patches, n, d_out, stream=None):
-        self._check(self.L.lf_mkd_describe_patches_device(self._h, d_patches, n, d_out, stream),
-                    "lf_mkd_describe_patches_device")
+        self._device_call(stream, lambda s: self.L.lf_mkd_describe_patches_device(self._h, d_patches, n, d_out, s),
+                          "lf_mkd_describe_patches_device")
 
     def raw_descriptors_device(self, d_patches, n, d_raw, stream=None):
-        self._check(self.L.lf_mkd_raw_descriptors_device(self._h, d_patches, n, d_raw, stream),
-                    "lf_mkd_raw_descriptors_device")
+        self._device_call(stream, lambda s: self.L.lf_mkd_raw_descriptors_device(self._h, d_patches, n, d_raw, s),
+                          "lf_mkd_raw_descriptors_device")
 
     def set_image_device(self, d_image, width, height, stream=None):
-        self._check(self.L.lf_mkd_set_image_device(self._h, d_image, width, height, stream),
-                    "lf_mkd_set_image_device")
+        self._device_call(stream, lambda s: self.L.lf_mkd_set_image_device(self._h, d_image, width, height, s),
+                          "lf_mkd_set_image_device")
 
     def set_images_device(self, d_images, n_frames, width, height, stream=None):
-        self._check(self.L.lf_mkd_set_images_device(self._h, d_images, n_frames, width, height, stream),
-                    "lf_mkd_set_images_device")
+        self._device_call(stream, lambda s: self.L.lf_mkd_set_images_device(self._h, d_images, n_frames, width, height, s),
+                          "lf_mkd_set_images_device")
 
     def describe_keypoints_frames_device(self, d_kps, d_frame_of_kp, n, d_out, stream=None):
-        self._check(self.L.lf_mkd_describe_keypoints_frames_device(self._h, d_kps, d_frame_of_kp, n, d_out, stream),
-                    "lf_mkd_describe_keypoints_frames_device")
+        self._device_call(stream, lambda s: self.L.lf_mkd_describe_keypoints_frames_device(self._h, d_kps, d_frame_of_kp, n,
+                                                                                         d_out, s),
+                          "lf_mkd_describe_keypoints_frames_device")
 
     def describe_keypoints_device(self, d_kps, n, d_out, stream=None):
-        self._check(self.L.lf_mkd_describe_keypoints_device(self._h, d_kps, n, d_out, stream),
-                    "lf_mkd_describe_keypoints_device")
+        self._device_call(stream, lambda s: self.L.lf_mkd_describe_keypoints_device(self._h, d_kps, n, d_out, s),
+                          "lf_mkd_describe_keypoints_device")
 
     def orient_keypoints_device(self, d_extrema, d_frame_of_extremum, n, d_out, d_frame_of_kp, max_out, stream=None):
         """Returns (written, dropped); waits for the stream (the count comes back to the host)."""
         m, dropped = ctypes.c_uint64(), ctypes.c_uint64()
-        self._check(self.L.lf_mkd_orient_keypoints_device(self._h, d_extrema, d_frame_of_extremum, n, d_out,
-                                                          d_frame_of_kp, max_out, ctypes.byref(m),
-                                                          ctypes.byref(dropped), stream),
-                    "lf_mkd_orient_keypoints_device")
+        self._device_call(stream, lambda s: self.L.lf_mkd_orient_keypoints_device(
+            self._h, d_extrema, d_frame_of_extremum, n, d_out, d_frame_of_kp, max_out, ctypes.byref(m),
+            ctypes.byref(dropped), s), "lf_mkd_orient_keypoints_device")
         return m.value, dropped.value
 
     def detect_extrema_device(self, d_out, d_frame_of, max_out, stream=None):
         m, dropped = ctypes.c_uint64(), ctypes.c_uint64()
-        self._check(self.L.lf_mkd_detect_extrema_device(self._h, d_out, d_frame_of, max_out, ctypes.byref(m),
-                                                        ctypes.byref(dropped), stream), "lf_mkd_detect_extrema_device")
+        self._device_call(stream, lambda s: self.L.lf_mkd_detect_extrema_device(
+            self._h, d_out, d_frame_of, max_out, ctypes.byref(m), ctypes.byref(dropped), s), "lf_mkd_detect_extrema_device")
         return m.value, dropped.value
 
     def filter_extrema_device(self, d_extrema, n, top_n, min_size, d_out, d_index=None, stream=None):
         m = ctypes.c_uint64()
-        self._check(self.L.lf_mkd_filter_extrema_device(self._h, d_extrema, n, top_n, min_size, d_out, d_index,
-                                                        ctypes.byref(m), stream), "lf_mkd_filter_extrema_device")
+        self._device_call(stream, lambda s: self.L.lf_mkd_filter_extrema_device(
+            self._h, d_extrema, n, top_n, min_size, d_out, d_index, ctypes.byref(m), s), "lf_mkd_filter_extrema_device")
         return m.value
 
     def match_device(self, d_a, na, d_b, nb, d_match, ratio=0.8, d_exclude_lo=None, d_exclude_hi=None, d_best=None,
                      d_second=None, stream=None):
-        self._check(self.L.lf_mkd_match_device(self._h, d_a, na, d_b, nb, d_exclude_lo, d_exclude_hi, ratio, d_match,
-                                               d_best, d_second, stream), "lf_mkd_match_device")
+        self._device_call(stream, lambda s: self.L.lf_mkd_match_device(
+            self._h, d_a, na, d_b, nb, d_exclude_lo, d_exclude_hi, ratio, d_match, d_best, d_second, s), "lf_mkd_match_device")
 
     def match_overflowed(self, stream=None):
         """Rows of the latest match call that were redone by the full scan (diagnostic; waits for the call)."""
@@ -303,10 +320,9 @@ class MkdHandle:
                              d_descriptors, max_out, stream=None):
         """Batch of frames through the whole pipeline; returns (keypoints written, dropped_blobs, dropped_features)."""
         m, db, df = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
-        self._check(self.L.lf_mkd_detect_frames_device(self._h, d_images, n_frames, width, height, top_n, min_size,
-                                                       d_keypoints, d_frame_of_kp, d_descriptors, max_out,
-                                                       ctypes.byref(m), ctypes.byref(db), ctypes.byref(df), stream),
-                    "lf_mkd_detect_frames_device")
+        self._device_call(stream, lambda s: self.L.lf_mkd_detect_frames_device(
+            self._h, d_images, n_frames, width, height, top_n, min_size, d_keypoints, d_frame_of_kp, d_descriptors, max_out,
+            ctypes.byref(m), ctypes.byref(db), ctypes.byref(df), s), "lf_mkd_detect_frames_device")
         return m.value, db.value, df.value
 
     def stream_create(self, width, height, top_n, min_size, max_out, d_image, d_keypoints, d_descriptors, d_counts):
@@ -315,11 +331,11 @@ class MkdHandle:
                                                 d_descriptors, d_counts), "lf_mkd_stream_create")
 
     def stream_frame(self, stream=None):
-        self._check(self.L.lf_mkd_stream_frame(self._h, stream), "lf_mkd_stream_frame")
+        self._device_call(stream, lambda s: self.L.lf_mkd_stream_frame(self._h, s), "lf_mkd_stream_frame")
 
     def sample_patches_device(self, d_kps, n, d_patches, stream=None):
-        self._check(self.L.lf_mkd_sample_patches_device(self._h, d_kps, n, d_patches, stream),
-                    "lf_mkd_sample_patches_device")
+        self._device_call(stream, lambda s: self.L.lf_mkd_sample_patches_device(self._h, d_kps, n, d_patches, s),
+                          "lf_mkd_sample_patches_device")
 
     def kernel_times(self):
         """(kernel_ms, 0.0, batches) summed since the previous call; needs FLAG_KERNEL_TIMING.

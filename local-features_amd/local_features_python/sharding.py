@@ -64,12 +64,13 @@ def all_gather_descriptors(desc_local, group=None, mode="direct", out=None, coun
     via_host = out.is_cuda and dist.get_backend(group) == "gloo"
     buf = out.cpu() if via_host else out
     if mode == "ring" and len(set(counts)) == 1 and counts[0] > 0:
-        # in place (the shard is already at its offset in the output, as NCCL's all-gather allows); a backend that
-        # refuses aliased buffers gets a copy of the shard instead -- every rank takes the same branch
-        try:
-            dist.all_gather_into_tensor(buf, buf[offs[rank]:offs[rank + 1]], group=group)
-        except (RuntimeError, ValueError):
-            dist.all_gather_into_tensor(buf, buf[offs[rank]:offs[rank + 1]].clone(), group=group)
+        # NCCL / RCCL gathers in place (the shard already sits at its offset in the output); other backends get a copy of
+        # the shard.  Decided from the backend alone, before the collective: every rank takes the same branch, whatever
+        # happens -- a rank that re-issued a collective after an exception would desynchronise the group.
+        mine_in = buf[offs[rank]:offs[rank + 1]]
+        if dist.get_backend(group) != "nccl":
+            mine_in = mine_in.clone()
+        dist.all_gather_into_tensor(buf, mine_in, group=group)
     elif mode in ("direct", "ring"):
         ops = []
         for step in range(1, world):       # peer order staggered by rank: at any step the pairs are disjoint

@@ -58,26 +58,65 @@ def golden(name):
 GATE = 1e-4
 
 
-def settled(oracle, patches, atan_mode, gate=GATE):
-    """(mask of patches on which the reference's two readings of the blur give the same descriptor, the contracted and
-    the uncontracted descriptors).  Unsettled are: patches with a pixel on the shader's gx == 0 discontinuity, and --
-    a second, milder way in which the blur's last bit reaches the descriptor -- patches in which a pixel whose gradient is
-    null up to rounding (a critical point of the blurred patch: its angle is rounding noise, its magnitude still the floor
-    0.01) carries visible weight, i.e. low-contrast patches; told by the two readings themselves differing by more than
-    a quarter of the gate."""
+# every parity helper call leaves one line here; printed at the end of the run (also under -q) and appended to
+# gpurun_out/parity_report.txt, so that a drift in the number of patches set aside is visible from the test log
+PARITY_REPORT = []
+
+
+def _report(line):
+    PARITY_REPORT.append(line)
+    print(line)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_report.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
+def pytest_terminal_summary(terminalreporter):
+    if PARITY_REPORT:
+        terminalreporter.write_sep("-", "parity helpers: patches set aside, and why")
+        for line in PARITY_REPORT:
+            terminalreporter.write_line(line)
+
+
+def settled_detail(oracle, patches, atan_mode, gate=GATE):
+    """(settled mask, contracted descriptors, uncontracted descriptors, mask of patches with a pixel on the shader's
+    gx == 0 discontinuity, mask of patches on which the reference's two readings of the blur differ by more than a quarter
+    of the gate).  Unsettled are: patches with a pixel on the discontinuity, and -- a second, milder way in which the
+    blur's last bit reaches the descriptor -- patches in which a pixel whose gradient is null up to rounding (a critical
+    point of the blurred patch: its angle is rounding noise, its magnitude still the floor 0.01) carries visible weight,
+    i.e. low-contrast patches; told by the two readings themselves differing."""
     from oracle import ATAN_SHADER, BLUR_CONTRACT
     ref_c = oracle.describe_patches(patches, atan_mode=atan_mode | BLUR_CONTRACT, nthreads=8)
     ref_s = oracle.describe_patches(patches, atan_mode=atan_mode, nthreads=8)
-    ok = oracle.quirk_pixels(patches) == 0 if atan_mode == ATAN_SHADER else np.ones(len(patches), bool)
-    return ok & (rel_l2(ref_c, ref_s) < gate / 4), ref_c, ref_s
+    quirk = oracle.quirk_pixels(patches) != 0 if atan_mode == ATAN_SHADER else np.zeros(len(patches), bool)
+    reading = rel_l2(ref_c, ref_s) >= gate / 4
+    return ~quirk & ~reading, ref_c, ref_s, quirk, reading
+
+
+def settled(oracle, patches, atan_mode, gate=GATE):
+    """(mask of patches on which the reference's two readings of the blur give the same descriptor, the contracted and
+    the uncontracted descriptors); see settled_detail."""
+    ok, ref_c, ref_s, _, _ = settled_detail(oracle, patches, atan_mode, gate)
+    return ok, ref_c, ref_s
+
+
+def _aside(quirk, reading):
+    n = len(quirk)
+    return (f"{int((quirk | reading).sum())}/{n} set aside (gx==0 pixel: {int(quirk.sum())}, "
+            f"blur readings differ: {int((reading & ~quirk).sum())})")
 
 
 def assert_patch_parity(oracle, patches, desc, atan_mode, gate=GATE, what="", min_settled=0.97):
     patches = np.asarray(patches, np.float32).reshape(-1, 32, 32)
-    clean, ref_c, ref_s = settled(oracle, patches, atan_mode, gate)
+    clean, ref_c, ref_s, quirk, reading = settled_detail(oracle, patches, atan_mode, gate)
     e_c = rel_l2(desc, ref_c)
-    assert e_c.max(initial=0.0) < gate, (what, "contracted", int(e_c.argmax()), e_c.max())
     e_s = rel_l2(desc, ref_s)
+    _report(f"[patch parity] {what or '-'}: {_aside(quirk, reading)}; worst vs contracted reading (all {len(patches)}) "
+            f"{e_c.max(initial=0.0):.2e}, vs uncontracted (settled) {e_s[clean].max(initial=0.0):.2e}")
+    assert e_c.max(initial=0.0) < gate, (what, "contracted", int(e_c.argmax()), e_c.max())
     assert clean.mean() > min_settled, (what, clean.mean())
     assert e_s[clean].max(initial=0.0) < gate, (what, "uncontracted", e_s[clean].max())
     return max(e_c.max(initial=0.0), e_s[clean].max(initial=0.0))
@@ -95,14 +134,18 @@ def assert_keypoint_parity(oracle, handle, img, kps5, desc, gate=GATE, what="", 
     n = len(kps5)
     d_k = torch.from_numpy(kps5).cuda()
     d_p = torch.empty((n, 32, 32), device="cuda")
+    torch.cuda.synchronize()
     handle.sample_patches_device(d_k.data_ptr(), n, d_p.data_ptr())
     handle.synchronize()
     got_p = d_p.cpu().numpy()
     ref_p = oracle.sample_patches(oracle.build_pyramid(img), w, hgt, kps5[:, :4])
     assert np.abs(got_p - ref_p).max(initial=0.0) < patch_tol, (what, "sampled patches", np.abs(got_p - ref_p).max())
-    assert_patch_parity(oracle, got_p, desc, ATAN_SHADER, gate, what, min_settled)   # describe stage, shared input bits
-    clean_ref, _, ref_s = settled(oracle, ref_p, ATAN_SHADER, gate)
-    clean = settled(oracle, got_p, ATAN_SHADER, gate)[0] & clean_ref
+    assert_patch_parity(oracle, got_p, desc, ATAN_SHADER, gate, what + " (describe stage, GPU-sampled bits)", min_settled)
+    clean_ref, _, ref_s, q_ref, r_ref = settled_detail(oracle, ref_p, ATAN_SHADER, gate)
+    clean_got, _, _, q_got, r_got = settled_detail(oracle, got_p, ATAN_SHADER, gate)
+    clean = clean_got & clean_ref
     e = rel_l2(desc, ref_s)                                                  # end to end
+    _report(f"[keypoint parity] {what or '-'}: end to end {_aside(q_ref | q_got, r_ref | r_got)} (either side's patch); "
+            f"worst settled {e[clean].max(initial=0.0):.2e}")
     assert clean.mean() > min_settled, (what, clean.mean())
     assert e[clean].max(initial=0.0) < gate, (what, "end to end", e[clean].max())

@@ -20,6 +20,10 @@ def _free_port():
     return p
 
 
+def _cat(parts):
+    return np.concatenate(list(parts) or [np.zeros((0, 128), np.float32)])
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, os.path.join(ROOT, "local-features_amd"))
     from local_features_python import sharding
@@ -31,10 +35,9 @@ def _worker(rank, world, port, q):
     mine = sharding.frames_of_rank(len(kp_per_frame), rank, world)
     rng = np.random.default_rng(1234)
     all_desc = [rng.random((k, 128)).astype(np.float32) for k in kp_per_frame]   # same on every rank
-    local = torch.from_numpy(np.concatenate([all_desc[f] for f in mine] or [np.zeros((0, 128), np.float32)]))
+    local = torch.from_numpy(_cat(all_desc[f] for f in mine))
     gathered, counts = sharding.all_gather_descriptors(local)           # "direct": point-to-point, uneven shards
-    expect = np.concatenate([np.concatenate([all_desc[f] for f in sharding.frames_of_rank(7, r, world)])
-                             for r in range(world)])
+    expect = _cat(_cat(all_desc[f] for f in sharding.frames_of_rank(7, r, world)) for r in range(world))
     ok = gathered.shape == (sum(kp_per_frame), 128) and np.array_equal(gathered.numpy(), expect)
     ok = ok and counts == [sum(kp_per_frame[f] for f in sharding.frames_of_rank(7, r, world)) for r in range(world)]
     # the same set into a caller-owned final buffer whose own-rank view already holds the shard (nothing copied locally)
@@ -66,7 +69,7 @@ def _worker(rank, world, port, q):
                             g.normal(size=(kp_per_frame[f], 128))])
         return (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     imgs = [image(f) for f in range(7)]
-    local = torch.from_numpy(np.concatenate([imgs[f] for f in mine]))
+    local = torch.from_numpy(_cat(imgs[f] for f in mine))
     match, gathered2, base = sharding.cross_image_match(local, [len(imgs[f]) for f in mine], engine)
     # single-process answer over the same global order
     order = [f for r in range(world) for f in sharding.frames_of_rank(7, r, world)]
@@ -86,7 +89,7 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_ranks_shard_and_all_gather(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -94,12 +97,14 @@ def test_ranks_shard_and_all_gather(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
+    res = sorted(q.get(timeout=240) for _ in range(world))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _, _ in res)
-    assert [(a, b) for _, _, a, b in res] == {2: [(0, 501), (501, 1001)], 3: [(0, 334), (334, 668), (668, 1001)]}[world]
+    base, extra = divmod(1001, world)
+    want = [(r * base + min(r, extra), r * base + min(r, extra) + base + (1 if r < extra else 0)) for r in range(world)]
+    assert [(a, b) for _, _, a, b in res] == want and want[0][0] == 0 and want[-1][1] == 1001
 
 
 def test_slices_cover_everything():

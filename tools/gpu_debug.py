@@ -12,7 +12,7 @@ p = np.random.default_rng(1).random((n, 32, 32)).astype(np.float32)
 dp = torch.from_numpy(p).cuda()
 for a in (0, 1):
     ref, raw_ref = o.describe_patches(p, atan_mode=ATAN_SHADER if a == 0 else ATAN_LIBM, nthreads=8, want_raw=True)
-    for pm in (0, 1):
+    for pm in (lfp.POOL_F32, lfp.POOL_F16X3):
         h = lfp.MkdHandle(max_features=1024, angle_mode=a, pool_mode=pm)
         raw = torch.empty((n, 238), device="cuda"); out = torch.empty((n, 128), device="cuda")
         for rep in range(3):
