@@ -21,7 +21,7 @@ pub const LF_MKD_POOL_DEFAULT: i32 = 0;
 pub const LF_MKD_POOL_F16X3: i32 = 1;
 pub const LF_MKD_POOL_F32: i32 = 2;
 pub const LF_MKD_FLAG_KERNEL_TIMING: u32 = 1;
-pub const LF_MKD_FLAG_NO_OVERLAP: u32 = 2;
+pub const LF_MKD_FLAG_UNFUSED_KEYPOINTS: u32 = 2;
 pub const LF_MKD_MAX_ANGLES_PER_EXTREMUM: usize = 18;
 
 /// `lf_mkd_params`: BuildTimeParams (lib.rs:54-75) + FeatureDetectParams (lib.rs:34-52) for this path; 0 = default.
@@ -142,6 +142,8 @@ extern "C" {
     pub fn lf_mkd_sample_patches_device(h: *mut lf_mkd, d_kps: *const lf_mkd_keypoint, n: u64, d_patches: *mut f32,
                                         stream: *mut c_void) -> c_int;
     pub fn lf_mkd_get_pyramid_level(h: *mut lf_mkd, level: u32, out: *mut f32, w: *mut u32, hgt: *mut u32) -> c_int;
+    pub fn lf_mkd_get_pyramid_level_apron(h: *mut lf_mkd, level: u32, out: *mut f32, w: *mut u32, hgt: *mut u32,
+                                          apron: *mut u32) -> c_int;
     pub fn lf_mkd_build_constants(mean: *const f32, eigvals: *const f32, eigvecs: *const f32,
                                   gradient_angle: *mut f32, embedding_polar: *mut f32,
                                   embedding_cartesian: *mut f32, w_t: *mut f32) -> c_int;

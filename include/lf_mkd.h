@@ -61,9 +61,11 @@ typedef enum { LF_MKD_POOL_DEFAULT = 0, LF_MKD_POOL_F16X3 = 1, LF_MKD_POOL_F32 =
 /* lf_mkd_params.flags */
 #define LF_MKD_FLAG_KERNEL_TIMING 1u /* bracket every kernel launch with HIP events on its stream;
                                         read the sums with lf_mkd_kernel_times (bench.py's roofline) */
-#define LF_MKD_FLAG_NO_OVERLAP 2u    /* keypoint mode: sample, then describe, on the caller's stream only (by default
-                                        large batches are chunked and the sampler of one chunk runs on a second stream
-                                        beside the describe kernel of the previous one) */
+#define LF_MKD_FLAG_UNFUSED_KEYPOINTS 2u /* keypoint mode as two launches: the sampler writes the 32x32 patches to a staging
+                                        buffer in HBM, the patch kernel reads them back (the verification form: same bits).
+                                        By default patches are sampled inside the describe kernel -- producer waves of each
+                                        workgroup fill its LDS row ring, patch_gradients.glsl:42-70 -- and never touch HBM.
+                                        (LF_MKD_POOL_F32 always takes the two-launch form.) */
 
 /* Mirrors BuildTimeParams (lib.rs:54-75) + FeatureDetectParams (lib.rs:34-52) for this path.
  * Zero-initialise, then set what you need; 0 means "default". */
@@ -299,6 +301,10 @@ int lf_mkd_sample_patches_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64
                                  float *d_patches, void *stream);
 /* Copies pyramid level `level` ((w>>level) x (h>>level) f32) to a host buffer. */
 int lf_mkd_get_pyramid_level(lf_mkd *h, uint32_t level, float *out, uint32_t *w, uint32_t *hgt);
+/* The same level as the sampler addresses it: with its apron of *apron texels on every side (0 for level 0), which holds
+ * what MirroredRepeat addressing (mod.rs:940-943) would fetch there -- (hgt + 2 apron) rows of (w + 2 apron) floats.
+ * Any of out / w / hgt / apron may be NULL. */
+int lf_mkd_get_pyramid_level_apron(lf_mkd *h, uint32_t level, float *out, uint32_t *w, uint32_t *hgt, uint32_t *apron);
 
 /* Host-only verification tap: the constants upload_constant_data (mod.rs:1587-1713) would place in
  * ConstantData (common.glsl:34-40), as this library builds them.  Any output pointer may be NULL.

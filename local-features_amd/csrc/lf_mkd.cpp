@@ -20,7 +20,7 @@ using namespace lfmkd;
 struct lf_mkd {
     lf_mkd_params params{};
     hipStream_t stream = nullptr;
-    hipStream_t side_stream = nullptr;   // keypoint mode: the sampler of chunk i+1 runs here beside the describe of chunk i
+    hipStream_t side_stream = nullptr;   // lf_mkd_detect / the recorded pipeline: pyramid levels >= 1 are built here beside the detector
     std::vector<hipEvent_t> side_events;
     DeviceConsts dc;
     uint64_t batch = 0;         // descriptors per internal batch (multiple of 64)
@@ -107,21 +107,24 @@ long pyramid_levels(uint32_t w, uint32_t h) {  // mod.rs:271-277,372-373
     return std::lround(std::ceil(std::log2(float(std::min(w, h)))));
 }
 
-void describe_pyramid(uint32_t w, uint32_t h, PyramidDesc &pd) {
+// returns the floats one frame's pyramid occupies (level 0 dense, levels >= 1 with their mirrored apron: mkd_device.h)
+long describe_pyramid(uint32_t w, uint32_t h, PyramidDesc &pd) {
     pd.levels = int(std::min<long>(std::max<long>(pyramid_levels(w, h), 1), kMaxPyrLevels));
     long off = 0;
     for (int l = 0; l < pd.levels; ++l) {
         pd.w[l] = std::max<int>(int(w >> l), 1);
         pd.h[l] = std::max<int>(int(h >> l), 1);
-        pd.offset[l] = off;
-        off += long(pd.w[l]) * pd.h[l];
+        pd.apron[l] = l == 0 ? 0 : kPyrApron;
+        pd.pitch[l] = pd.w[l] + 2 * pd.apron[l];
+        pd.offset[l] = off + long(pd.apron[l]) * pd.pitch[l] + pd.apron[l];
+        off += long(pd.pitch[l]) * (pd.h[l] + 2 * pd.apron[l]);
     }
+    return off;
 }
 
 long pyramid_floats(uint32_t w, uint32_t h) {
     PyramidDesc pd{};
-    describe_pyramid(w, h, pd);
-    return pd.offset[pd.levels - 1] + long(pd.w[pd.levels - 1]) * pd.h[pd.levels - 1];
+    return describe_pyramid(w, h, pd);
 }
 
 int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) {
@@ -189,6 +192,12 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     // are allocated on first use: a caller of the device-pointer patch API never needs them)
     LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_totals), 8 * sizeof(unsigned long long)));
     if (params->max_image_width && params->max_image_height) {
+        // the sampler addresses a pyramid level with 32-bit byte offsets from its first texel
+        if (uint64_t(params->max_image_width) * params->max_image_height >= (1ull << 30) ||
+            params->max_image_width >= (1u << 20) || params->max_image_height >= (1u << 20)) {
+            h->err = "max_image_width x max_image_height must stay below 2^30 pixels";
+            return bail(LF_MKD_ERR_BAD_ARG);
+        }
         h->max_frames = params->max_frames ? params->max_frames : 1;
         const size_t px = size_t(params->max_image_width) * params->max_image_height * h->max_frames;
         h->pyr_stride = pyramid_floats(params->max_image_width, params->max_image_height);
@@ -202,13 +211,21 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     return LF_MKD_OK;
 }
 
-// staging for one internal batch: sampled / uploaded patches, descriptors on their way to the host, uploaded keypoints
-int ensure_staging(lf_mkd *h) {
+// staging for one internal batch: sampled / uploaded patches; descriptors on their way to the host and uploaded keypoints
+int ensure_patch_staging(lf_mkd *h) {
     if (h->d_patches) return LF_MKD_OK;
     LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_patches), h->batch * kPx * 4));
+    return LF_MKD_OK;
+}
+int ensure_io_staging(lf_mkd *h) {
+    if (h->d_out) return LF_MKD_OK;
     LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_out), h->batch * kOut * 4));
     LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_kps), h->batch * 5 * 4));
     return LF_MKD_OK;
+}
+int ensure_staging(lf_mkd *h) {
+    if (int rc = ensure_patch_staging(h)) return rc;
+    return ensure_io_staging(h);
 }
 
 // LF_MKD_FLAG_KERNEL_TIMING: an event on the launch stream before and after every describe launch
@@ -227,8 +244,6 @@ int mark(lf_mkd *h, hipStream_t s) {
 }
 
 constexpr uint64_t kMatchChunk = 1 << 20;   // a rows per pass of the two-pass matcher (2 GiB of records at one b split)
-// keypoint mode overlaps sampling and describing for batches of at least kOverlapMin keypoints, kOverlapChunk at a time
-constexpr uint64_t kOverlapMin = 1 << 16, kOverlapChunk = 1 << 15;   // measured: 16 k .. 64 k chunks within 1 %, 128 k loses the gain
 
 int ensure_side_stream(lf_mkd *h, size_t events) {
     if (!h->side_stream) LF_HIP(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
@@ -247,6 +262,32 @@ int run_batch(lf_mkd *h, const float *d_patches, uint64_t n, float *d_out, float
                     d_raw, h->num_cus, s, waves);
     LF_HIP(h, hipGetLastError());
     if (int rc = mark(h, s)) return rc;
+    return LF_MKD_OK;
+}
+
+// Keypoints resident on the device -> descriptors.  The product form is ONE launch: producer waves of the describe kernel
+// sample the patches into its LDS ring (f16x3 pooling).  The f32 verification mode and LF_MKD_FLAG_UNFUSED_KEYPOINTS take
+// the two-launch form through the staging patches in HBM, an internal batch at a time; same sampling arithmetic, same bits.
+bool fused_keypoints(const lf_mkd *h) {
+    return h->params.pool_mode == LF_MKD_POOL_F16X3 && !(h->params.flags & LF_MKD_FLAG_UNFUSED_KEYPOINTS);
+}
+int describe_keypoints_on_device(lf_mkd *h, const float *d_kps, const uint32_t *d_frame_of, uint64_t n, float *d_out,
+                                 hipStream_t s) {
+    if (fused_keypoints(h)) {
+        if (int rc = mark(h, s)) return rc;
+        launch_describe_keypoints(h->d_pyr, h->pyr_stride, h->pd, d_kps, d_frame_of, long(n), nullptr,
+                                  h->params.patch_scale_factor, h->dc, h->params.angle_mode, d_out, h->num_cus, s);
+        LF_HIP(h, hipGetLastError());
+        return mark(h, s);
+    }
+    if (int rc = ensure_patch_staging(h)) return rc;
+    for (uint64_t off = 0; off < n; off += h->batch) {
+        const uint64_t m = std::min<uint64_t>(h->batch, n - off);
+        launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, d_kps + off * 5, d_frame_of ? d_frame_of + off : nullptr, long(m),
+                              nullptr, h->params.patch_scale_factor, h->d_patches, s);
+        LF_HIP(h, hipGetLastError());
+        if (int rc = run_batch(h, h->d_patches, m, d_out + off * kOut, nullptr, s)) return rc;
+    }
     return LF_MKD_OK;
 }
 
@@ -591,40 +632,7 @@ int lf_mkd_describe_keypoints_frames_device(lf_mkd *h, const lf_mkd_keypoint *d_
     if (!d_kps || !d_out) return fail(h, LF_MKD_ERR_BAD_ARG, "describe_keypoints_device: null pointer");
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
-    if (int rc = ensure_staging(h)) return rc;
-    for (uint64_t off = 0; off < n; off += h->batch) {
-        const uint64_t m = std::min<uint64_t>(h->batch, n - off);
-        const lf_mkd_keypoint *kps = d_kps + off;
-        const uint32_t *fo = d_frame_of_kp ? d_frame_of_kp + off : nullptr;
-        float *out = d_out + off * kOut;
-        if (m < kOverlapMin || (h->params.flags & LF_MKD_FLAG_NO_OVERLAP)) {
-            launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(kps), fo, long(m), nullptr,
-                                  h->params.patch_scale_factor, h->d_patches, s);
-            LF_HIP(h, hipGetLastError());
-            if (int rc = run_batch(h, h->d_patches, m, out, nullptr, s)) return rc;
-            continue;
-        }
-        // Large batches: the sampler is bound by the texture-address unit with the vector ALUs mostly idle, the describe
-        // kernel by the vector ALUs and matrix cores with the texture unit idle -- so the two run SIDE BY SIDE on every CU:
-        // the batch goes in chunks, chunk i+1 is sampled on a second stream while chunk i is described in the 4-wave form
-        // of the kernel (one wave per SIMD and 104 KiB of LDS leave the sampler's waves room on the same CU).
-        if (int rc = ensure_side_stream(h, (m + kOverlapChunk - 1) / kOverlapChunk + 1)) return rc;
-        size_t ev = 0;
-        LF_HIP(h, hipEventRecord(h->side_events[ev], s));                   // everything before this call, incl. the pyramid
-        LF_HIP(h, hipStreamWaitEvent(h->side_stream, h->side_events[ev], 0));
-        for (uint64_t c = 0; c < m; c += kOverlapChunk) {
-            const uint64_t mc = std::min<uint64_t>(kOverlapChunk, m - c);
-            launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(kps + c),
-                                  fo ? fo + c : nullptr, long(mc), nullptr, h->params.patch_scale_factor,
-                                  h->d_patches + c * kPx, h->side_stream, true);
-            LF_HIP(h, hipGetLastError());
-            ++ev;
-            LF_HIP(h, hipEventRecord(h->side_events[ev], h->side_stream));
-            LF_HIP(h, hipStreamWaitEvent(s, h->side_events[ev], 0));
-            if (int rc = run_batch(h, h->d_patches + c * kPx, mc, out + c * kOut, nullptr, s, 4)) return rc;
-        }
-    }
-    return LF_MKD_OK;
+    return describe_keypoints_on_device(h, reinterpret_cast<const float *>(d_kps), d_frame_of_kp, n, d_out, s);
 }
 
 int lf_mkd_describe_keypoints_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64_t n, float *d_out,
@@ -638,15 +646,11 @@ int lf_mkd_describe_keypoints(lf_mkd *h, const lf_mkd_keypoint *kps, uint64_t n,
     if (n == 0) return LF_MKD_OK;
     if (!kps || !out) return fail(h, LF_MKD_ERR_BAD_ARG, "describe_keypoints: null pointer");
     LF_HIP(h, hipSetDevice(h->params.device));
-    if (int rc = ensure_staging(h)) return rc;
+    if (int rc = ensure_io_staging(h)) return rc;
     for (uint64_t off = 0; off < n; off += h->batch) {
         const uint64_t m = std::min<uint64_t>(h->batch, n - off);
         LF_HIP(h, hipMemcpyAsync(h->d_kps, kps + off, m * sizeof(lf_mkd_keypoint), hipMemcpyHostToDevice, h->stream));
-        launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, h->d_kps, nullptr, long(m), nullptr,
-                              h->params.patch_scale_factor, h->d_patches, h->stream);
-        LF_HIP(h, hipGetLastError());
-        const int rc = run_batch(h, h->d_patches, m, h->d_out, nullptr, h->stream);
-        if (rc) return rc;
+        if (int rc = describe_keypoints_on_device(h, h->d_kps, nullptr, m, h->d_out, h->stream)) return rc;
         LF_HIP(h, hipMemcpyAsync(out + off * kOut, h->d_out, m * kOut * 4, hipMemcpyDeviceToHost, h->stream));
         LF_HIP(h, hipStreamSynchronize(h->stream));
     }
@@ -886,7 +890,8 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
         if (int rc = grow_topk_work(h, h->max_extrema, h->stream)) return rc;
     }
     if (int rc = ensure_orient_scratch(h, cap, false, 0)) return rc;
-    if (int rc = grow(h, &h->d_stream_patches, &h->stream_patch_cap, max_out * kPx, sizeof(float))) return rc;
+    if (!fused_keypoints(h))
+        if (int rc = grow(h, &h->d_stream_patches, &h->stream_patch_cap, max_out * kPx, sizeof(float))) return rc;
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(d_counts);
     LF_HIP(h, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), h->stream));
     LF_HIP(h, hipStreamSynchronize(h->stream));
@@ -919,10 +924,16 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
                   reinterpret_cast<float *>(d_keypoints), nullptr, max_out, cnt + 3, s);
     // (the join costs ~12 us of queue latency wherever it stands, measured; the branch saves ~40)
     if (fork) (void)hipStreamWaitEvent(s, h->side_events[1], 0);
-    launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr,
-                          long(max_out), cnt + 3, h->params.patch_scale_factor, h->d_stream_patches, s);
-    launch_describe(h->d_stream_patches, long(max_out), cnt + 3, h->dc, h->params.angle_mode, h->params.pool_mode,
-                    d_descriptors, nullptr, h->num_cus, s);
+    if (fused_keypoints(h)) {
+        launch_describe_keypoints(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr,
+                                  long(max_out), cnt + 3, h->params.patch_scale_factor, h->dc, h->params.angle_mode,
+                                  d_descriptors, h->num_cus, s);
+    } else {
+        launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr,
+                              long(max_out), cnt + 3, h->params.patch_scale_factor, h->d_stream_patches, s);
+        launch_describe(h->d_stream_patches, long(max_out), cnt + 3, h->dc, h->params.angle_mode, h->params.pool_mode,
+                        d_descriptors, nullptr, h->num_cus, s);
+    }
     hipError_t e_end = hipStreamEndCapture(s, &h->graph);
     if (e_end != hipSuccess || !h->graph) {
         h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e_end);
@@ -1109,8 +1120,25 @@ int lf_mkd_get_pyramid_level(lf_mkd *h, uint32_t level, float *out, uint32_t *w,
     if (!out) return LF_MKD_OK;
     LF_HIP(h, hipSetDevice(h->params.device));
     LF_HIP(h, hipStreamSynchronize(h->stream));
-    LF_HIP(h, hipMemcpy(out, h->d_pyr + h->pd.offset[level], size_t(h->pd.w[level]) * h->pd.h[level] * 4,
-                        hipMemcpyDeviceToHost));
+    LF_HIP(h, hipMemcpy2D(out, size_t(h->pd.w[level]) * 4, h->d_pyr + h->pd.offset[level], size_t(h->pd.pitch[level]) * 4,
+                          size_t(h->pd.w[level]) * 4, size_t(h->pd.h[level]), hipMemcpyDeviceToHost));
+    return LF_MKD_OK;
+}
+
+int lf_mkd_get_pyramid_level_apron(lf_mkd *h, uint32_t level, float *out, uint32_t *w, uint32_t *hgt, uint32_t *apron) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "get_pyramid_level_apron: call lf_mkd_set_image first");
+    if (level >= uint32_t(h->pd.levels)) return fail(h, LF_MKD_ERR_BAD_ARG, "get_pyramid_level_apron: no such level");
+    const int a = h->pd.apron[level], pw = h->pd.w[level] + 2 * a, ph = h->pd.h[level] + 2 * a;
+    if (w) *w = uint32_t(h->pd.w[level]);
+    if (hgt) *hgt = uint32_t(h->pd.h[level]);
+    if (apron) *apron = uint32_t(a);
+    if (!out) return LF_MKD_OK;
+    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_HIP(h, hipStreamSynchronize(h->stream));
+    const float *src = h->d_pyr + h->pd.offset[level] - long(a) * h->pd.pitch[level] - a;
+    LF_HIP(h, hipMemcpy2D(out, size_t(pw) * 4, src, size_t(h->pd.pitch[level]) * 4, size_t(pw) * 4, size_t(ph),
+                          hipMemcpyDeviceToHost));
     return LF_MKD_OK;
 }
 

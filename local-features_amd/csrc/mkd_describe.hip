@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "mkd_device.h"
+#include "mkd_sample.h"
 
 namespace lfmkd {
 
@@ -52,6 +53,13 @@ constexpr int kRowBytes = kLutPieces * 1024;          // 30720: one LUT row imag
 constexpr int kRingOff = 2 * kRowBytes;              // raw patch rows: [wave 8][slot 6][2 KiB]
 constexpr int kRingSlots = 6;
 // total: kRingOff + waves * kRingSlots * 2048 = 159744 B for 8 waves, 110592 B for 4
+// Keypoint mode (SRC = kSrcKeypoints): the ring of a describe wave is filled by a producer wave of the same workgroup, four
+// patch rows at a time (a group), so it holds 12 rows: the 8 a describe wave reads while a group is being written + that
+// group.  Raw row r of the workgroup's it-th batch lives in slot (8 it + r) mod 12 (32 mod 12 = 8: the numbering simply
+// runs on across batches).  4 describe waves: kRingOff + 4 * 12 * 2048 = 159744 B, plus the level table.
+constexpr int kSrcPatches = 0, kSrcKeypoints = 1;
+constexpr int kRingSlotsKp = 12;
+constexpr int kLevelTableBytes = 5 * kMaxPyrLevels * 4;
 
 __device__ __forceinline__ float lane_fetch(int byte_addr, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
@@ -369,16 +377,17 @@ __device__ __forceinline__ void mma_part(const AFrag<POOL> &a, const BFrag &b, f
 // Blurred row of this lane's segment from the raw-row ring (patch_gradients.glsl:72-92): vertical 5 taps over
 // ring slots s0..s0+4, then horizontal 5 taps with the neighbours fetched from lanes -/+16.
 // Returns the row plus its x-1 / x+8 neighbours.
-__device__ __forceinline__ void blur_row(const unsigned char *ring_lane, int s0, int addr_l, int addr_r, bool has_l,
-                                         bool has_r, float (&out)[8], float &out_l, float &out_r) {
+// slot_of_tap(i): ring slot of the i-th of the five raw rows.
+template <class SlotOfTap>
+__device__ __forceinline__ void blur_row_impl(const unsigned char *ring_lane, SlotOfTap slot_of_tap, int addr_l, int addr_r,
+                                              bool has_l, bool has_r, float (&out)[8], float &out_l, float &out_r) {
     float vb[8];
     {
         const float kk[5] = {kB0, kB1, kB2, kB1, kB0};
         f32x2 v2[4];
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            int sl = s0 + i;
-            sl = sl >= kRingSlots ? sl - kRingSlots : sl;
+            const int sl = slot_of_tap(i);
             const f32x4 lo = *reinterpret_cast<const f32x4 *>(ring_lane + sl * 2048);
             const f32x4 hi = *reinterpret_cast<const f32x4 *>(ring_lane + sl * 2048 + 256);
             const f32x2 r[4] = {{lo[0], lo[1]}, {lo[2], lo[3]}, {hi[0], hi[1]}, {hi[2], hi[3]}};
@@ -409,6 +418,12 @@ __device__ __forceinline__ void blur_row(const unsigned char *ring_lane, int s0,
     const float hl = lane_fetch(addr_l, out[7]), hr = lane_fetch(addr_r, out[0]);
     out_l = has_l ? hl : out[0];
     out_r = has_r ? hr : out[7];
+}
+
+__device__ __forceinline__ void blur_row(const unsigned char *ring_lane, int s0, int addr_l, int addr_r, bool has_l,
+                                         bool has_r, float (&out)[8], float &out_l, float &out_r) {
+    blur_row_impl(ring_lane, [s0](int i) { const int sl = s0 + i; return sl >= kRingSlots ? sl - kRingSlots : sl; }, addr_l,
+                  addr_r, has_l, has_r, out, out_l, out_r);
 }
 
 // Harmonics k = 1..3 of the gradient angle by angle addition, each stream pair against its four LUT tiles.  The 21 matrix
@@ -659,6 +674,210 @@ __device__ __forceinline__ void finish_descriptors(const f32x4 (&acc_row)[kAccTi
     }
 }
 
+// ---- keypoint mode (SRC = kSrcKeypoints) --------------------------------------------------------------------------
+// What the describe kernel is given instead of patches: the pyramids (mkd_pyramid.hip) and the keypoint list.
+struct KpSource {
+    const float *pyr;            // pyramids of the frames, pyr_stride floats apart
+    long pyr_stride;
+    const float *kps;            // [n][5] x, y, size, angle (degrees), response
+    const unsigned *frame_of;    // [n] frame of each keypoint, or null: all on frame 0
+    float psf;                   // patch_scale_factor
+    PyramidDesc pd;
+};
+
+// Batches of a workgroup.  Keypoints arrive ordered by frame, and every XCD has its own L2: workgroups that share an XCD
+// (b, b + 8, ...: dispatch is round-robin over the 8 XCDs -- a matter of speed only, nothing depends on it) walk ONE
+// contiguous eighth of the batches, so that a frame's pyramid is fetched into one L2 instead of eight.
+struct BatchWalk { long cur, end, step; };
+__device__ __forceinline__ BatchWalk kp_batches(long nbatch) {
+    const long g = gridDim.x, b = blockIdx.x;
+    if ((g & 7) == 0 && nbatch > g) {
+        const long chunk = (nbatch + 7) / 8, lo = (b & 7) * chunk, hi = lo + chunk < nbatch ? lo + chunk : nbatch;
+        return BatchWalk{lo + (b >> 3), hi, g >> 3};
+    }
+    return BatchWalk{b, nbatch, g};
+}
+
+__device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// A producer wave: samples the patches of ITS describe wave (wave pw of the workgroup's W describe waves) into that wave's
+// row ring, patch_gradients.glsl:42-70 with the arithmetic of mkd_sample.h.
+// Work unit = a quarter of a row group: rows 4G..4G+3 of patches 4q..4q+3, as eight blocks of 4 rows x 16 pixels -- one
+// block per load instruction, lane = (row r = lane >> 4, column c = lane & 15): a compact footprint of a few cache lines
+// (the texture path's cost is per line touched per instruction: a whole patch row per instruction, which the ring's row
+// order would suggest, costs 7x as much -- tools/micro/gather_patterns.hip).  One quarter per row step of the describe
+// waves: quarter Q = g + 7 is written during step g, i.e. a group is complete one barrier before its first row is read and
+// is written into the slots of rows read for the last time one barrier earlier (ring of 12, see kRingSlotsKp).  Quarters
+// 32..38 are the first seven of the workgroup's NEXT batch; the epilogue of the describe waves is a pause.
+// The taps of a quarter are requested one step BEFORE it is written (two register sets, the step loop unrolled by two):
+// their latency passes beside the previous quarter's arithmetic instead of in front of the barrier.
+// Every barrier of the describe waves has its twin here: 32 row steps + 12 in finish_descriptors per batch.
+// The producers also request the LUT rows of the row loop: an LDS-DMA request stalls its issuer for 60-180 cycles, which a
+// producer can afford, so a describe wave issues no memory instruction between its barriers.
+struct KpTaps { f32x2 top[8], bot[8]; float ax[8], ay[8]; };
+
+// (uniform base) + (unsigned 32-bit lane offset) -> global_load_dwordx2 v, v_off, s[base:base+1]: no 64-bit address arithmetic
+// (the two empty asm statements: see lds_dma16_sv).  Texel addresses are 4-byte aligned only.
+__device__ __forceinline__ f32x2 load2_sv(const unsigned char *uniform_base, unsigned lane_off) {
+    asm("" : "+s"(uniform_base));
+    asm volatile("" : "+v"(lane_off));
+    typedef f32x2 f32x2_a4 __attribute__((aligned(4)));
+    return *reinterpret_cast<const __attribute__((address_space(1))) f32x2_a4 *>(
+        (const __attribute__((address_space(1))) unsigned char *)uniform_base + lane_off);
+}
+
+template <int W>
+__device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable &lt, const long *lvl_offset, long n,
+                                           BatchWalk walk, unsigned char *s_mem, const unsigned char *__restrict__ lut_rows,
+                                           int pw, int lane) {
+    unsigned char *ring = s_mem + kRingOff + pw * (kRingSlotsKp * 2048);
+#ifdef LF_KP_PRODUCER_PRIO
+    __builtin_amdgcn_s_setprio(LF_KP_PRODUCER_PRIO);
+#endif
+    // geometry of a batch's 16 keypoints, one per lane: lanes 0-15 hold set 0, lanes 16-31 set 1 (this batch / the next).
+    // g_xmax / g_ymax: largest first-tap index in the level's allocation (apron included), g_pitch4: row pitch in bytes.
+    float g_ca = 0.f, g_sa = 0.f, g_rem = 0.f, g_cx = 0.f, g_cy = 0.f;
+    int g_xmax = 0, g_ymax = 0, g_pitch4 = 8, g_apron = 0, g_cov = 0;
+    unsigned g_lo = 0, g_hi = 0;
+    auto load_geometry = [&](long batch, int set) {
+        long k = batch * (16 * W) + pw * 16 + (lane & 15);
+        k = k < n ? k : n - 1;
+        const float *kp = ks.kps + k * 5;
+        const KpGeom g = keypoint_geometry(kp[0], kp[1], kp[2], kp[3], ks.psf, lt);
+        // first texel of the level's allocation (apron included): offsets from it are never negative
+        const int a = lt.apron[g.level], pitch = lt.pitch[g.level];
+        const float *a0 = ks.pyr + (ks.frame_of ? (long)ks.frame_of[k] * ks.pyr_stride : 0L) + lvl_offset[g.level] -
+                          (long)a * pitch - a;
+        if ((lane >> 4) == set) {
+            g_ca = g.ca; g_sa = g.sa; g_rem = g.rem; g_cx = g.cx; g_cy = g.cy;
+            g_xmax = lt.w[g.level] + 2 * a - 2; g_ymax = lt.h[g.level] + 2 * a - 2; g_pitch4 = 4 * pitch; g_apron = a;
+            g_cov = g.covered ? 1 : 0;
+            g_lo = (unsigned)(uintptr_t)a0; g_hi = (unsigned)((uintptr_t)a0 >> 32);
+        }
+    };
+    const int r = lane >> 4, c = lane & 15;
+    auto base_of = [&](int src) {
+        return reinterpret_cast<const unsigned char *>((uintptr_t)(unsigned)readlane_i((int)g_lo, src) |
+                                                       ((uintptr_t)(unsigned)readlane_i((int)g_hi, src) << 32));
+    };
+    // requests the taps of a quarter (fetch_covered of mkd_sample.h: indices clamped into the level's allocation)
+    auto request = [&](int quarter, int set, KpTaps &t) {
+#ifdef LF_KP_ABLATE_PRODUCER   // timing-only build: the describe waves alone (their rings hold whatever was there)
+        return;
+#endif
+        const int q = quarter & 3, ly = 4 * (quarter >> 2) + r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int src = 16 * set + 4 * q + i;   // uniform
+            const float ca = readlane_f(g_ca, src), sa = readlane_f(g_sa, src), rem = readlane_f(g_rem, src);
+            const float cx = readlane_f(g_cx, src), cy = readlane_f(g_cy, src);
+            const int xmax = readlane_i(g_xmax, src), ymax = readlane_i(g_ymax, src), pitch4 = readlane_i(g_pitch4, src);
+            const int apron = readlane_i(g_apron, src);
+            const unsigned char *a0 = base_of(src);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const SamplePos p = sample_position(ca, sa, rem, cx, cy, 16 * hh + c, ly);
+                t.ax[2 * i + hh] = p.ax;
+                t.ay[2 * i + hh] = p.ay;
+                const int ix = min(max(p.ix + apron, 0), xmax), iy = min(max(p.iy + apron, 0), ymax);
+                const unsigned off = __umul24((unsigned)iy, (unsigned)pitch4) + 4u * (unsigned)ix;   // both < 2^24: full-rate multiply
+#ifdef LF_KP_ABLATE_TAPS       // timing-only build: everything but the loads of a sample
+                t.top[2 * i + hh] = f32x2{__uint_as_float(off), p.ax};
+                t.bot[2 * i + hh] = f32x2{p.ay, (float)pitch4};
+                continue;
+#endif
+                t.top[2 * i + hh] = load2_sv(a0, off);
+                t.bot[2 * i + hh] = load2_sv(a0, off + (unsigned)pitch4);
+            }
+        }
+    };
+    // blends them and writes the quarter's rows into the ring
+    auto finish = [&](int quarter, int set, int slot0, const KpTaps &t) {
+#ifdef LF_KP_ABLATE_PRODUCER
+        return;
+#endif
+        const int G = quarter >> 2, q = quarter & 3;
+        // (slot0 + 4G) mod 12 is a multiple of 4: the group's four rows sit in consecutive slots.  Ring slot layout:
+        // [half 2][16-byte chunk of the half-row 4][patch 16][4 pixels]; this lane's pixel c (+16) of patch 4q + i
+        unsigned char *dst = ring + ((slot0 + 4 * G) % kRingSlotsKp + r) * 2048 + (c & 3) * 4 + (c >> 2) * 256 + q * 64;
+        int any_uncovered = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            any_uncovered |= 1 - readlane_i(g_cov, 16 * set + 4 * q + i);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int k = 2 * i + hh;
+                *reinterpret_cast<float *>(dst + hh * 1024 + i * 16) =
+                    bilinear_blend(t.top[k].x, t.top[k].y, t.bot[k].x, t.bot[k].y, t.ax[k], t.ay[k]);
+            }
+        }
+        // keypoints whose footprint leaves the apron (centre outside the frame, sizes beyond the pyramid, level 0's border,
+        // non-finite data): rare -- their samples are redone with MirroredRepeat evaluated per tap
+        if (any_uncovered) {
+            const int ly = 4 * G + r;
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+                const int src = 16 * set + 4 * q + i;
+                if (readlane_i(g_cov, src)) continue;
+                const int apron = readlane_i(g_apron, src), pitch = readlane_i(g_pitch4, src) >> 2;
+                const int w = readlane_i(g_xmax, src) + 2 - 2 * apron, h = readlane_i(g_ymax, src) + 2 - 2 * apron;
+                const float *lvl0 = reinterpret_cast<const float *>(base_of(src)) + (long)apron * pitch + apron;
+#pragma unroll 1
+                for (int hh = 0; hh < 2; ++hh) {
+                    const SamplePos p = sample_position(readlane_f(g_ca, src), readlane_f(g_sa, src), readlane_f(g_rem, src),
+                                                        readlane_f(g_cx, src), readlane_f(g_cy, src), 16 * hh + c, ly);
+                    const Taps tm = fetch_mirrored(lvl0, w, h, pitch, p);
+                    *reinterpret_cast<float *>(dst + hh * 1024 + i * 16) =
+                        bilinear_blend(tm.t00, tm.t10, tm.t01, tm.t11, p.ax, p.ay);
+                }
+            }
+        }
+    };
+
+    KpTaps ta, tb;
+    int set = 0, slot0 = 0;
+    load_geometry(walk.cur, 0);
+#pragma unroll 1
+    for (int quarter = 0; quarter < 7; ++quarter) {
+        request(quarter, 0, ta);
+        finish(quarter, 0, 0, ta);
+    }
+    request(7, 0, ta);
+#pragma unroll 1
+    for (long batch = walk.cur; batch < walk.end; batch += walk.step) {
+        const bool more = batch + walk.step < walk.end;
+        if (more) load_geometry(batch + walk.step, set ^ 1);
+        const int slot1 = (slot0 + 8) % kRingSlotsKp;
+        // step g: LUT row g + 1 is requested into the row buffer the describe waves have just left (row g uses buffer g & 1),
+        // then the taps of the quarter step g + 1 will write (vector-memory results return in issue order: the taps, which
+        // have a whole step, queue behind the LUT pieces, not the other way round); then the quarter of THIS step, whose
+        // taps landed during the previous one, is blended and written
+        auto step = [&](int g, KpTaps &cur, KpTaps &nxt) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // ring writes, LUT pieces and taps have landed
+            __syncthreads();
+            if (g < 31) issue_lut_row<W>(lut_rows, g + 1, s_mem + ((g + 1) & 1) * kRowBytes, pw, lane);
+            const int qn = g + 8;    // the quarter of step g + 1
+            if (qn < 32) request(qn, set, nxt);
+            else if (more) request(qn - 32, set ^ 1, nxt);   // (g = 31: quarter 7 of the next batch)
+            __builtin_amdgcn_sched_barrier(0);
+            const int qc = g + 7;
+            if (qc < 32) finish(qc, set, slot0, cur);
+            else if (more) finish(qc - 32, set ^ 1, slot1, cur);
+        };
+#pragma unroll 1
+        for (int g = 0; g < 32; g += 2) {
+            step(g, ta, tb);
+            step(g + 1, tb, ta);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+        for (int e = 0; e < 12; ++e) __syncthreads();   // finish_descriptors: one on entry, one per whitening step
+        set ^= 1;
+        slot0 = slot1;
+    }
+}
+
 }  // namespace
 
 // grid = min(#batches, #CUs) persistent workgroups of 8 waves; a batch is 128 patches (16 per wave).
@@ -677,15 +896,21 @@ __device__ __forceinline__ void finish_descriptors(const f32x4 (&acc_row)[kAccTi
 #define LF_PT(i) do { } while (0)
 #endif
 
-template <int ANGLE, int POOL, int W>
-__global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ patches, long n_host,
-                                                const unsigned long long *__restrict__ n_dev,
-                                                const unsigned char *__restrict__ lut_rows,
-                                                const short *__restrict__ colmap,
-                                                const unsigned char *__restrict__ wfrag,
-                                                const float *__restrict__ bias,
-                                                float *__restrict__ out, float *__restrict__ raw_out) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kRingOff + W * kRingSlots * 2048];
+// SRC = kSrcKeypoints (keypoint mode, f16x3 pooling): the workgroup has 2 W waves.  Waves 0 .. W-1 are the describe waves
+// of the text above; waves W .. 2W-1 are their producers (kp_produce): wave W + i samples the patches of describe wave i from
+// the pyramid straight into its row ring, so a sampled patch never leaves the CU.  `patches` is unused, `ks` says what to
+// sample.  The two kinds of wave sit side by side on every SIMD -- one waits on the texture path while the other computes.
+template <int ANGLE, int POOL, int W, int SRC>
+__global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_pool(
+    const float *__restrict__ patches, long n_host, const unsigned long long *__restrict__ n_dev,
+    const unsigned char *__restrict__ lut_rows, const short *__restrict__ colmap, const unsigned char *__restrict__ wfrag,
+    const float *__restrict__ bias, float *__restrict__ out, float *__restrict__ raw_out,
+    std::conditional_t<SRC == kSrcKeypoints, KpSource, int> ks) {
+    constexpr bool kKp = SRC == kSrcKeypoints;
+    constexpr int kSlots = kKp ? kRingSlotsKp : kRingSlots;
+    static_assert(!kKp || POOL == LF_POOL_F16X3, "keypoint mode pools in f16x3");
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kRingOff + W * kSlots * 2048 +
+                                                                (kKp ? kLevelTableBytes + kMaxPyrLevels * 8 : 0)];
     // number of patches: given by the host, or (graph-captured pipelines) left on the device by the previous stage
     const long n = n_dev ? (long)*n_dev : n_host;
     const int lane = threadIdx.x & 63;
@@ -694,13 +919,40 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
     const int addr_l = ((lane - 16) & 63) * 4, addr_r = ((lane + 16) & 63) * 4;
     const bool has_l = q > 0, has_r = q < 3;
     const long nbatch = (n + 16 * W - 1) / (16 * W);
-    unsigned char *ring = s_mem + kRingOff + wave * (kRingSlots * 2048);
+    unsigned char *ring = s_mem + kRingOff + wave * (kSlots * 2048);
+    BatchWalk walk{(long)blockIdx.x, nbatch, (long)gridDim.x};
+    if constexpr (kKp) {
+        walk = kp_batches(nbatch);
+        if (walk.cur >= walk.end) return;
+        // per-level geometry into LDS (lanes look up different levels: see LevelTable)
+        int *lv = reinterpret_cast<int *>(s_mem + kRingOff + W * kSlots * 2048);
+        long *lv_off = reinterpret_cast<long *>(lv + 5 * kMaxPyrLevels);
+        if (threadIdx.x < kMaxPyrLevels) {
+            const int l = threadIdx.x;
+            int w_ = 0, h_ = 0, pi_ = 0, ap_ = 0;
+            long of_ = 0;
+#pragma unroll
+            for (int j = 0; j < kMaxPyrLevels; ++j)
+                if (j == l) { w_ = ks.pd.w[j]; h_ = ks.pd.h[j]; pi_ = ks.pd.pitch[j]; ap_ = ks.pd.apron[j]; of_ = ks.pd.offset[j]; }
+            lv[l] = w_; lv[kMaxPyrLevels + l] = h_; lv[2 * kMaxPyrLevels + l] = pi_; lv[3 * kMaxPyrLevels + l] = ap_;
+            lv_off[l] = of_;
+        }
+        __syncthreads();
+        if (wave >= W) {
+            const LevelTable lt{ks.pd.levels, lv, lv + kMaxPyrLevels, lv + 2 * kMaxPyrLevels, lv + 3 * kMaxPyrLevels};
+            kp_produce<W>(ks, lt, lv_off, n, walk, s_mem, lut_rows, wave - W, lane);
+            return;
+        }
+#ifdef LF_KP_CONSUMER_PRIO
+        __builtin_amdgcn_s_setprio(LF_KP_CONSUMER_PRIO);
+#endif
+    }
     // DMA writes are lane-linear (lane l -> bytes [16l, 16l+16) of a 1 KiB piece): lane (p, q) moves the 16-B
     // chunk q of its patch's half-row; the reader (p, q) needs chunks 2(q&1), 2(q&1)+1 of half q>>1.
     const unsigned char *ring_lane = ring + (q >> 1) * 1024 + ((2 * (q & 1)) * 16 + p) * 16;
 
-    long batch = blockIdx.x;
-    if (batch >= nbatch) return;
+    long batch = walk.cur;
+    if (batch >= walk.end) return;
     // lanes beyond the last patch recompute it: the wave's base is clamped the same way, so lane offsets stay >= 0
     auto raw_src = [&](const float *pt, long b) {
         const long b0 = b * (16 * W) + wave * 16;
@@ -709,17 +961,20 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
         return RawSrc{reinterpret_cast<const unsigned char *>(pt + wave0 * 1024), (unsigned)(pidx - wave0) * 4096u + 16u * q};
     };
     {
-        const RawSrc src = raw_src(patches, batch);
+        if constexpr (!kKp) {
+            const RawSrc src = raw_src(patches, batch);
 #pragma unroll
-        for (int r = -2; r <= 3; ++r) issue_raw_row(src, r, ring, r + 2);
+            for (int r = -2; r <= 3; ++r) issue_raw_row(src, r, ring, r + 2);
+        }
         issue_lut_row<W>(lut_rows, 0, s_mem, wave, lane);
     }
+    int slot0 = 0;   // keypoint mode: ring slot of raw row 0 of the current batch
     unsigned par = 0;  // LUT row buffer holding the row about to be consumed
 #ifdef LF_PHASE_TIMING
     unsigned long long phase_clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, phase_prev = __builtin_readcyclecounter();
 #endif
 
-    for (; batch < nbatch; batch += gridDim.x) {
+    for (; batch < walk.end; batch += walk.step) {
         // Launder the (uniform) table and buffer pointers once per batch.  Otherwise hipcc hoists one 64-bit per-lane VGPR
         // address per DMA / fragment load / store out of the batch loop and spills them (1.4 KB per lane for the
         // whitening fragments alone).  Spills matter beyond their cost here: scratch loads and stores count on vmcnt
@@ -732,9 +987,10 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
         const short *cm = colmap;
         asm volatile("" : "+s"(wf), "+s"(bs), "+s"(lr), "+s"(o), "+s"(ro), "+s"(cm), "+s"(pt));
         const long base = batch * (16 * W) + wave * 16;
-        const RawSrc src = raw_src(pt, batch);
-        const bool more = batch + gridDim.x < nbatch;
-        const RawSrc src_next = more ? raw_src(pt, batch + gridDim.x) : src;
+        const bool more = batch + walk.step < walk.end;
+        // (keypoint mode: pt is null and these stay unused)
+        const RawSrc src = kKp ? RawSrc{nullptr, 0u} : raw_src(pt, batch);
+        const RawSrc src_next = !kKp && more ? raw_src(pt, batch + walk.step) : src;
 
         f32x4 acc[kAccTiles];
 #pragma unroll
@@ -758,10 +1014,13 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
             LF_PT(0);
             const unsigned char *brow = s_mem + par * kRowBytes + lane * 16;
             // row buffer par ^ 1 is free: next LUT row; during row 31 the f16 epilogue's first whitening step instead
-            if (POOL == LF_POOL_F16X3 ? !kLast : (!kLast || more))
-                issue_lut_row<W>(lr, (g + 1) & 31, s_mem + (par ^ 1) * kRowBytes, wave, lane);
-            else if (POOL == LF_POOL_F16X3)
+            // (keypoint mode: the producer waves request LUT rows 1..31 -- an LDS-DMA request stalls its issuer for 60-180
+            // cycles, which a producer can afford -- so a describe wave issues no memory instruction in the row loop)
+            if (POOL == LF_POOL_F16X3 ? !kLast : (!kLast || more)) {
+                if constexpr (!kKp) issue_lut_row<W>(lr, (g + 1) & 31, s_mem + (par ^ 1) * kRowBytes, wave, lane);
+            } else if (POOL == LF_POOL_F16X3) {
                 issue_w_step<W>(wf, 0, s_mem, wave, lane);
+            }
             par ^= 1;
             BFrag bm[3] = {load_b(brow, 0), load_b(brow, 1), load_b(brow, 2)};   // m-stream fragments
 
@@ -771,15 +1030,29 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
             // Raw row g+4 goes into the slot of row g-2, whose last reader was the blur of the previous iteration: for
             // g >= 1 it is requested here, a whole row before the vmcnt(0) that waits for it (counters: the waves spend
             // 29 % of their time in s_waitcnt and only 2 % of that on LDS), for g == 0 after the first blur below.
-            if (!kFirst && !kLast && g <= 29) issue_raw_row(src, g + 4, ring, s0 == 0 ? kRingSlots - 1 : s0 - 1);
+            if constexpr (!kKp)
+                if (!kFirst && !kLast && g <= 29) issue_raw_row(src, g + 4, ring, s0 == 0 ? kRingSlots - 1 : s0 - 1);
+            // keypoint mode: the five raw rows of hb(y) are rows y-2 .. y+2 clamped to the patch (replicate border), each in
+            // its slot of the producer's ring
+            auto kp_slot = [&](int y, int i) {
+                int r_ = y - 2 + i;
+                r_ = r_ < 0 ? 0 : (r_ > 31 ? 31 : r_);
+                return (slot0 + r_) % kRingSlotsKp;
+            };
             if (kFirst) {  // first blurred row of the batch: rows -2..2 sit in slots 0..4
-                blur_row(ring_lane, 0, addr_l, addr_r, has_l, has_r, cur, cur_l, cur_r);
+                if constexpr (kKp)
+                    blur_row_impl(ring_lane, [&](int i) { return kp_slot(0, i); }, addr_l, addr_r, has_l, has_r, cur, cur_l, cur_r);
+                else
+                    blur_row(ring_lane, 0, addr_l, addr_r, has_l, has_r, cur, cur_l, cur_r);
 #pragma unroll
                 for (int x = 0; x < 8; ++x) prv[x] = cur[x];
             }
             float nxt[8], nxt_l, nxt_r;
             if (!kLast) {  // hb(g+1) from raw rows g-1..g+3 = slots s0..s0+4
-                blur_row(ring_lane, s0, addr_l, addr_r, has_l, has_r, nxt, nxt_l, nxt_r);
+                if constexpr (kKp)
+                    blur_row_impl(ring_lane, [&](int i) { return kp_slot(g + 1, i); }, addr_l, addr_r, has_l, has_r, nxt, nxt_l, nxt_r);
+                else
+                    blur_row(ring_lane, s0, addr_l, addr_r, has_l, has_r, nxt, nxt_l, nxt_r);
             } else {  // row 32 replicates row 31
 #pragma unroll
                 for (int x = 0; x < 8; ++x) nxt[x] = cur[x];
@@ -788,11 +1061,13 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
             }
             // the slot of raw row g-2 is free now (its last reader was the blur above when g == 0)
             asm volatile("" ::: "memory");
-            if (kFirst) {
-                issue_raw_row(src, g + 4, ring, s0 == 0 ? kRingSlots - 1 : s0 - 1);
-            } else if (kLast && more) {
+            if constexpr (!kKp) {
+                if (kFirst) {
+                    issue_raw_row(src, g + 4, ring, s0 == 0 ? kRingSlots - 1 : s0 - 1);
+                } else if (kLast && more) {
 #pragma unroll
-                for (int r = -2; r <= 3; ++r) issue_raw_row(src_next, r, ring, r + 2);  // next batch's first rows
+                    for (int r = -2; r <= 3; ++r) issue_raw_row(src_next, r, ring, r + 2);  // next batch's first rows
+                }
             }
             s0 = s0 == kRingSlots - 1 ? 0 : s0 + 1;
             LF_PT(1);
@@ -858,6 +1133,7 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
         finish_descriptors<POOL, W>(acc, lane, wave, base + p < n, base + p, cm, wf, bs, o, ro, s_mem, lr, more);
 #endif
         LF_PT(6);
+        if constexpr (kKp) slot0 = (slot0 + 8) % kRingSlotsKp;
     }
 #ifdef LF_PHASE_TIMING
     __syncthreads();
@@ -869,6 +1145,11 @@ __global__ __launch_bounds__(64 * W) void mkd_pool(const float *__restrict__ pat
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+// This source is compiled twice (Makefile): as is -- the patch-mode launcher, scheduled with max-ILP -- and with
+// -DLF_DESCRIBE_KP -- the keypoint-mode launcher alone, under hipcc's default scheduling strategy: with max-ILP the two exact
+// angle modes of the keypoint kernel need 259 registers (three spilled, which the counted vmcnt waits of the epilogue
+// forbid), with the default strategy 203-209.
+#ifndef LF_DESCRIBE_KP
 // n_dev != nullptr: the patch count is read on the device (<= n, which then only sizes the grid)
 void launch_describe(const float *patches, long n, const unsigned long long *n_dev, const DeviceConsts &dc,
                      int angle_mode, int pool_mode, float *out, float *raw_out, int num_cus, hipStream_t stream, int waves) {
@@ -887,8 +1168,8 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
     const unsigned char *wf = f16 ? reinterpret_cast<const unsigned char *>(dc.white_a_f16)
                                   : reinterpret_cast<const unsigned char *>(dc.white_a_f32);
 #define LF_LAUNCH_W(A, P, WV)                                                                                          \
-    hipLaunchKernelGGL((mkd_pool<A, P, WV>), dim3(grid), dim3(64 * WV), 0, stream, patches, n, n_dev, lut, \
-                       dc.colmap, wf, dc.white_bias, out, raw_out)
+    hipLaunchKernelGGL((mkd_pool<A, P, WV, kSrcPatches>), dim3(grid), dim3(64 * WV), 0, stream, patches, n, n_dev, lut, \
+                       dc.colmap, wf, dc.white_bias, out, raw_out, 0)
 #define LF_LAUNCH(A, P)            \
     do {                           \
         if (small) LF_LAUNCH_W(A, P, 4); \
@@ -906,5 +1187,28 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
 #undef LF_LAUNCH_W
 #undef LF_LAUNCH
 }
+
+#else   // LF_DESCRIBE_KP
+// Keypoint mode in one launch: 4 describe waves + 4 producer waves per workgroup, 64 keypoints per batch, one workgroup
+// per CU (160 KB of LDS), persistent.
+void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
+                               const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
+                               const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream) {
+    if (n <= 0) return;
+    const long nbatch = (n + 63) / 64;
+    const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);
+    const unsigned char *lut = reinterpret_cast<const unsigned char *>(dc.pool_b_f16);
+    const unsigned char *wf = reinterpret_cast<const unsigned char *>(dc.white_a_f16);
+    KpSource ks;
+    ks.pyr = pyr; ks.pyr_stride = pyr_stride; ks.kps = kps; ks.frame_of = frame_of_kp; ks.psf = psf; ks.pd = pd;
+#define LF_LAUNCH_KP(A)                                                                                                \
+    hipLaunchKernelGGL((mkd_pool<A, LF_POOL_F16X3, 4, kSrcKeypoints>), dim3(grid), dim3(512), 0, stream,                \
+                       (const float *)nullptr, n, n_dev, lut, dc.colmap, wf, dc.white_bias, out, (float *)nullptr, ks)
+    if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH_KP(LF_ANGLE_EXACT);
+    else if (angle_mode == LF_ANGLE_EXACT_ZERO) LF_LAUNCH_KP(LF_ANGLE_EXACT_ZERO);
+    else LF_LAUNCH_KP(LF_ANGLE_SHADER);
+#undef LF_LAUNCH_KP
+}
+#endif  // LF_DESCRIBE_KP
 
 }  // namespace lfmkd

@@ -16,11 +16,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxPyrLevels = 16;
 
-// Patch pyramid: levels packed back to back in one allocation; level l is w[l] x h[l] f32.
+// Patch pyramid: levels packed back to back in one allocation; level l is w[l] x h[l] f32, rows pitch[l] floats apart.
+// Level 0 is dense (pitch = w: the detector and the orientation stage read it as a-trous layer 0).  Levels >= 1, which
+// only the patch sampler reads, carry an APRON of kPyrApron texels on every side, filled with the level's own texels under
+// MirroredRepeat (mod.rs:940-943): a keypoint whose centre lies inside its level reaches at most 22.7 rem + 2 < 48 texels
+// from it (rem < 2), so its whole footprint is addressed without any mirror arithmetic.  offset[l] is texel (0, 0).
+constexpr int kPyrApron = 48;
 struct PyramidDesc {
     int levels;
     int w[kMaxPyrLevels], h[kMaxPyrLevels];
-    long offset[kMaxPyrLevels];  // in floats
+    int pitch[kMaxPyrLevels];    // floats between rows
+    int apron[kMaxPyrLevels];    // mirrored texels around the level (0 for level 0)
+    long offset[kMaxPyrLevels];  // in floats, of texel (0, 0)
 };
 
 // Device copies of HostConsts' device layouts (mkd_consts.hpp).
@@ -42,7 +49,12 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
 // frame_of_kp == nullptr: every keypoint belongs to frame 0
 void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                            const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
-                           float *patches, hipStream_t stream, bool beside_describe = false);
+                           float *patches, hipStream_t stream);
+// keypoint mode in ONE launch (csrc/mkd_describe.hip): patches are sampled by producer waves of the describe workgroup
+// straight into its LDS row ring and never touch HBM.  f16x3 pooling only.
+void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
+                               const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
+                               const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream);
 // rest_stream (nullable): levels >= 1 are built there -- after `fork`, recorded on `stream` once level 0 and a-trous layer 1
 // exist -- and `join` is recorded behind them; the caller waits for `join` before it samples patches
 void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,

@@ -7,57 +7,30 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "mkd_device.h"
+#include "mkd_sample.h"
 
 namespace lfmkd {
 
 // ---------------------------------------------------------------------------------------------
 // Keypoint mode: pyramid and sampling.  Sampler = linear filter, MirroredRepeat (mod.rs:940-943),
-// restated with exact f32 weights; texel centres at i + 0.5.
+// restated with exact f32 weights; texel centres at i + 0.5 (mkd_sample.h).
 // ---------------------------------------------------------------------------------------------
-namespace {
-
-// MirroredRepeat: t = i mod 2n, index = min(t, 2n-1-t).  Branch-free, float reciprocal instead of an integer
-// division (|i| stays far below 2^23, so the float arithmetic is exact up to the +-1 fix-ups).
-__device__ __forceinline__ int mirror_idx(int i, int n) {
-    const int pp = 2 * n;
-    const float q = floorf((float)i * (1.f / (float)pp));
-    int t = i - (int)q * pp;
-    t = t < 0 ? t + pp : t;
-    t = t >= pp ? t - pp : t;
-    const int r = t < n ? t : pp - 1 - t;
-    return r < 0 ? 0 : (r > n - 1 ? n - 1 : r);   // only binding for absurd |i| (non-finite caller data): never out of range
-}
-
-__device__ __forceinline__ float tex_bilinear(const float *__restrict__ img, int w, int h, float u, float v) {
-    const float fu = u - 0.5f, fv = v - 0.5f;
-    const float x0f = floorf(fu), y0f = floorf(fv);
-    const float ax = fu - x0f, ay = fv - y0f;
-    const int x0 = mirror_idx((int)x0f, w), x1 = mirror_idx((int)x0f + 1, w);
-    const int y0 = mirror_idx((int)y0f, h), y1 = mirror_idx((int)y0f + 1, h);
-    const float *r0 = img + y0 * w, *r1 = img + y1 * w;   // a level holds < 2^31 texels
-    const float t00 = r0[x0], t10 = r0[x1];
-    const float t01 = r1[x0], t11 = r1[x1];
-    const float top = t00 * (1.f - ax) + t10 * ax;
-    const float bot = t01 * (1.f - ax) + t11 * ax;
-    return top * (1.f - ay) + bot * ay;
-}
-
-}  // namespace
-
 // All pyramid kernels work on a batch of frames of one size: blockIdx.z = frame, consecutive frames are
 // in_stride / out_stride floats apart.
 // blur.glsl:34-65 (sigma 0.6) and blur_pyramid.glsl horizontal pass share this shape:
 // out = w0 * tex(c) + w1 * (tex(c - off) + tex(c + off)) along one axis.  The bilinear fetch is evaluated exactly as
-// tex_bilinear does, minus the terms that are multiplied by a weight of exactly 0: the centre tap sits on a texel
+// a bilinear fetch (mkd_sample.h) does, minus the terms that are multiplied by a weight of exactly 0: the centre tap sits on a texel
 // centre (both fractions 0), the side taps have fraction 0 across the pass direction.
-__device__ __forceinline__ float sep3_pixel(const float *__restrict__ in, int w, int h, int x, int y, float w0, float w1,
-                                            float off, int vertical) {
+__device__ __forceinline__ float sep3_pixel(const float *__restrict__ in, int w, int h, int pitch, int x, int y, float w0,
+                                            float w1, float off, int vertical) {
 #pragma clang fp contract(off)   // the detector's decisions sit on these values: round like the restatement they are tested against
     const float c = (float)(vertical ? y : x) + 0.5f;
     const int n = vertical ? h : w;
-    const long stride = vertical ? w : 1;
-    const float *line = vertical ? in + x : in + (size_t)y * w;
+    const long stride = vertical ? pitch : 1;
+    const float *line = vertical ? in + x : in + (size_t)y * pitch;
     float side[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -68,7 +41,7 @@ __device__ __forceinline__ float sep3_pixel(const float *__restrict__ in, int w,
         const int i0 = mirror_idx((int)f0, n), i1 = mirror_idx((int)f0 + 1, n);
         side[k] = line[i0 * stride] * (1.f - a) + line[i1 * stride] * a;
     }
-    float s = in[(size_t)y * w + x] * w0;
+    float s = in[(size_t)y * pitch + x] * w0;
     s += (side[0] + side[1]) * w1;
     return s;
 }
@@ -87,7 +60,7 @@ __global__ __launch_bounds__(256) void pyr_sep3_fused(const float *__restrict__ 
     const int y0 = (int)blockIdx.y * 12;
     const int xr = (int)blockIdx.x * 256 + (int)threadIdx.x, x = xr < w ? xr : w - 1;
 #pragma unroll 4
-    for (int m = 0; m < 16; ++m) s_h[m][threadIdx.x] = sep3_pixel(in, w, h, x, mirror_idx(y0 - 2 + m, h), w0, w1, off, 0);
+    for (int m = 0; m < 16; ++m) s_h[m][threadIdx.x] = sep3_pixel(in, w, h, w, x, mirror_idx(y0 - 2 + m, h), w0, w1, off, 0);
     __syncthreads();
 #pragma unroll 4
     for (int k = 0; k < 12; ++k) {
@@ -165,7 +138,7 @@ __global__ __launch_bounds__(256) void pyr_swt_fused(const float *__restrict__ i
 
 // Nearest blit [0,w)x[0,h) -> [0,w/2)x[0,h/2): patch_pyramid.rs:251-285.
 __global__ void pyr_decimate(const float *__restrict__ in, float *__restrict__ out, long in_stride, long out_stride,
-                             int w, int h, int ow, int oh) {
+                             int w, int h, int ow, int oh, int opitch) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= ow || y >= oh) return;
     in += blockIdx.z * in_stride;
@@ -174,13 +147,13 @@ __global__ void pyr_decimate(const float *__restrict__ in, float *__restrict__ o
     int sy = (int)floorf(((float)y + 0.5f) * (float)h / (float)(h / 2));
     sx = sx > w - 1 ? w - 1 : sx;
     sy = sy > h - 1 ? h - 1 : sy;
-    out[(size_t)y * ow + x] = in[(size_t)sy * w + sx];
+    out[(size_t)y * opitch + x] = in[(size_t)sy * w + sx];
 }
 
 // blur_pyramid.glsl:36-49 vertical pass: binomial taps centred on texel (2x, 2y) of the H result.
 __device__ __forceinline__ float down_v_pixel(const float *__restrict__ in, int w, int h, int x, int y) {
 #pragma clang fp contract(off)
-    // taps centred on texel (2x, 2y): same arithmetic as tex_bilinear, zero-weight terms left out (see sep3_pixel)
+    // taps centred on texel (2x, 2y): same arithmetic as a bilinear fetch, zero-weight terms left out (see sep3_pixel)
     const int sx = mirror_idx(2 * x, w);
     const float cy = 2.f * (float)y + 0.5f;
     float side[2];
@@ -204,7 +177,8 @@ __device__ __forceinline__ float down_v_pixel(const float *__restrict__ in, int 
 constexpr int kDownRows = 6;
 
 __global__ __launch_bounds__(256) void pyr_down_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
-                                                      long out_stride, int pw, int ph, int ow, int oh) {
+                                                      long out_stride, int pw, int ph, int ppitch, int ow, int oh,
+                                                      int opitch) {
 #pragma clang fp contract(off)
     __shared__ float s_h[2 * kDownRows + 3][256];
     in += blockIdx.z * in_stride;
@@ -215,7 +189,7 @@ __global__ __launch_bounds__(256) void pyr_down_fused(const float *__restrict__ 
     const int v0 = 2 * y0 - 2;   // virtual row of slot 0
 #pragma unroll 5
     for (int m = 0; m < 2 * kDownRows + 3; ++m)
-        s_h[m][threadIdx.x] = sep3_pixel(in, pw, ph, sx, mirror_idx(v0 + m, ph), 0.375f, 0.3125f, 1.2f, 0);
+        s_h[m][threadIdx.x] = sep3_pixel(in, pw, ph, ppitch, sx, mirror_idx(v0 + m, ph), 0.375f, 0.3125f, 1.2f, 0);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kDownRows; ++k) {
@@ -235,7 +209,7 @@ __global__ __launch_bounds__(256) void pyr_down_fused(const float *__restrict__ 
         }
         float sum = s_h[2 * k + 2][threadIdx.x] * 0.375f;
         sum += (side[0] + side[1]) * 0.3125f;
-        if (xr < ow) out[(size_t)y * ow + xr] = sum;
+        if (xr < ow) out[(size_t)y * opitch + xr] = sum;
     }
 }
 
@@ -252,33 +226,56 @@ __global__ __launch_bounds__(1024) void pyr_tail(float *__restrict__ pyr, long p
         const float *in = base + pd.offset[l - 1];
         for (int i = threadIdx.x; i < pw * ph; i += 1024) {
             const int y = i / pw, x = i - y * pw;
-            s_tmp[i] = sep3_pixel(in, pw, ph, x, y, 0.375f, 0.3125f, 1.2f, 0);
+            s_tmp[i] = sep3_pixel(in, pw, ph, pd.pitch[l - 1], x, y, 0.375f, 0.3125f, 1.2f, 0);
         }
         __syncthreads();
         float *out = base + pd.offset[l];
         for (int i = threadIdx.x; i < ow * oh; i += 1024) {
             const int y = i / ow, x = i - y * ow;
-            out[i] = down_v_pixel(s_tmp, pw, ph, x, y);
+            out[(size_t)y * pd.pitch[l] + x] = down_v_pixel(s_tmp, pw, ph, x, y);
         }
         __threadfence_block();   // level l is the input of level l + 1, read by other threads of this workgroup
         __syncthreads();
     }
 }
 
-constexpr int kSampleBox = 96;   // >= 32 * 2 * sqrt2 + 4: the bounding box of every footprint with rem < 2
+// The apron of levels >= 1 (mkd_device.h): every texel outside the level, up to kPyrApron away, takes the value
+// MirroredRepeat addressing would have fetched for it.  One launch for all levels and frames, after the last level is
+// written: blockIdx.y = level - 1, blockIdx.z = frame; a thread handles one apron texel -- first the bands above and
+// below the level (full padded width), then the bands left and right of its rows.
+__global__ __launch_bounds__(256) void pyr_apron_fill(float *__restrict__ pyr, long pyr_stride, PyramidDesc pd) {
+    const int l = (int)blockIdx.y + 1;
+    const int w = pd.w[l], h = pd.h[l], a = pd.apron[l], pitch = pd.pitch[l];
+    float *lvl0 = pyr + blockIdx.z * pyr_stride + pd.offset[l];
+    const int n_band = 2 * a * pitch, n_side = 2 * a * h;
+    for (int t = (int)(blockIdx.x * 256 + threadIdx.x); t < n_band + n_side; t += (int)gridDim.x * 256) {
+        int x, y;
+        if (t < n_band) {
+            const int r = t / pitch;
+            x = t - r * pitch - a;
+            y = r < a ? r - a : h + (r - a);
+        } else {
+            const int u = t - n_band, r = u / (2 * a), c = u - r * (2 * a);
+            y = r;
+            x = c < a ? c - a : w + (c - a);
+        }
+        lvl0[(long)y * pitch + x] = lvl0[(long)mirror_idx(y, h) * pitch + mirror_idx(x, w)];
+    }
+}
 
-// patch_gradients.glsl:42-70.  One wave per keypoint (4 per block): the per-keypoint scale/level/rotation math is
-// done once per wave instruction, each lane then samples 16 pixels.  The kernel is bound by the number of cache lines
-// its gathers touch (counters: 67 % of wave time waiting on loads, 10 % issuing), so a load instruction covers an
-// 8 x 8 block of the patch -- a compact footprint of ~11 texel rows -- rather than two 32-pixel patch rows along a
-// rotated line (~30 lines); the patch is transposed through LDS so that it still leaves in 256-byte row stores.
+// patch_gradients.glsl:42-70 as a launch of its own: the verification tap (lf_mkd_sample_patches_device) and the sampling
+// stage of the f32 verification mode; the product path samples inside the describe kernel (mkd_describe.hip) with the same
+// arithmetic (mkd_sample.h), bit for bit.  One wave per keypoint (4 per block): the per-keypoint scale/level/rotation math
+// is done once per wave instruction, each lane then samples 16 pixels.  A load instruction covers an 8 x 8 block of the
+// patch -- a compact footprint of ~11 texel rows -- rather than two 32-pixel patch rows along a rotated line (~30 lines:
+// the texture path's cost is per cache line touched, tools/micro/gather_patterns.hip); the patch is transposed through
+// LDS so that it still leaves in 256-byte row stores.
 // frame_of_kp (optional) selects the keypoint's pyramid among the frames of the batch (pyr_stride floats apart).
 __global__ __launch_bounds__(256) void sample_patches(const float *__restrict__ pyr, long pyr_stride, PyramidDesc pd,
                                                       const float *__restrict__ kps /*[n][5]*/,
                                                       const unsigned *__restrict__ frame_of_kp, long n_host,
                                                       const unsigned long long *__restrict__ n_dev, float psf,
                                                       float *__restrict__ patches) {
-    __shared__ int s_mirror[4][2 * kSampleBox];
     __shared__ float s_patch[4][1024];
     const long n = n_dev ? (long)*n_dev : n_host;
     const long k = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -286,79 +283,17 @@ __global__ __launch_bounds__(256) void sample_patches(const float *__restrict__ 
     const int lane = threadIdx.x & 63;
     if (frame_of_kp) pyr += (long)frame_of_kp[k] * pyr_stride;
     const float *kp = kps + k * 5;
-    const float scale = kp[2] * psf / 32.f;
-    const float l2 = log2f(scale);
-    float lvl = floorf(l2);
-    lvl = lvl < 0.f ? 0.f : (lvl > (float)(pd.levels - 1) ? (float)(pd.levels - 1) : lvl);
-    const float rem = exp2f(l2 - lvl);
-    int l = (int)lvl;   // a non-finite size (caller-supplied keypoints) must not index outside the pyramid
-    l = l < 0 ? 0 : (l > pd.levels - 1 ? pd.levels - 1 : l);
-    const float ang = kp[3] * (3.14159265358979323846f / 180.f);
-    const float ca = cosf(ang), sa = sinf(ang);
-    const float inv = 1.f / exp2f(lvl);
-    const float *img = pyr + pd.offset[l];
-    const int w = pd.w[l], h = pd.h[l];
+    const KpGeom g = keypoint_geometry(kp[0], kp[1], kp[2], kp[3], psf, level_table(pd));
+    const float *lvl0 = pyr + pd.offset[g.level];
+    const int w = pd.w[g.level], h = pd.h[g.level], pitch = pd.pitch[g.level], apron = pd.apron[g.level];
     float *tile = s_patch[threadIdx.x >> 6];
     // pixel of this lane in step i: block (i & 3, i >> 2) of 8 x 8 pixels, lane = 8 * row + column inside it
     const int lx0 = lane & 7, ly0 = lane >> 3;
-    // When the rotated patch footprint (half diagonal 16 sqrt2 rem, plus the bilinear neighbour) stays inside the level,
-    // MirroredRepeat is the identity and its index arithmetic is skipped: same texels, same weights.
-    const float reach = 22.7f * rem + 2.f, pcx = kp[0] * inv, pcy = kp[1] * inv;
-    const bool interior = pcx - reach >= 0.f && pcx + reach <= (float)(w - 1) && pcy - reach >= 0.f &&
-                          pcy + reach <= (float)(h - 1);   // uniform over the wave
-    // Otherwise MirroredRepeat is needed, but only for the <= 96 texel columns and rows of the footprint's bounding
-    // box: computed once per keypoint into a small LDS table instead of four times per sample.
-    bool boxed = false;
-    int bx0 = 0, by0 = 0, bw = 2, bh = 2;
-    int *tab = s_mirror[threadIdx.x >> 6];   // [0, 96): columns, [96, 192): row offsets y * w
-    if (!interior) {
-        float xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float cdx = (c & 1) ? 15.f : -16.f, cdy = (c & 2) ? 15.f : -16.f;
-            const float sx = (cdx * ca - cdy * sa) * rem + pcx, sy = (cdx * sa + cdy * ca) * rem + pcy;
-            xlo = fminf(xlo, sx); xhi = fmaxf(xhi, sx);
-            ylo = fminf(ylo, sy); yhi = fmaxf(yhi, sy);
-        }
-        const float bxf = floorf(xlo) - 1.f, byf = floorf(ylo) - 1.f;   // one texel of margin: +1 neighbour, rounding
-        const float bwf = floorf(xhi) + 3.f - bxf, bhf = floorf(yhi) + 3.f - byf;
-        // (comparisons are false for NaN: a non-finite keypoint takes the general path)
-        boxed = bwf >= 1.f && bwf <= (float)kSampleBox && bhf >= 1.f && bhf <= (float)kSampleBox &&
-                fabsf(bxf) < 1e9f && fabsf(byf) < 1e9f;
-        if (boxed) {
-            bx0 = (int)bxf; by0 = (int)byf; bw = (int)bwf; bh = (int)bhf;
-            for (int i = lane; i < bw; i += 64) tab[i] = mirror_idx(bx0 + i, w);
-            for (int i = lane; i < bh; i += 64) tab[kSampleBox + i] = mirror_idx(by0 + i, h) * w;
-            __builtin_amdgcn_wave_barrier();   // written and read by this wave only; LDS keeps a wave's accesses in order
-        }
-    }
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
         const int lx = 8 * (i & 3) + lx0, ly = 8 * (i >> 2) + ly0;
-        const float dx = (float)lx - 16.f, dy = (float)ly - 16.f;
-        const float xx = dx * ca - dy * sa, yy = dx * sa + dy * ca;
-        const float sx = xx * rem + kp[0] * inv, sy = yy * rem + kp[1] * inv;
-        float v;
-        if (interior || boxed) {   // tex_bilinear(img, w, h, sx + 0.5f, sy + 0.5f), texel indices without / from the table
-            const float fu = (sx + 0.5f) - 0.5f, fv = (sy + 0.5f) - 0.5f;
-            const float x0f = floorf(fu), y0f = floorf(fv);
-            const float ax = fu - x0f, ay = fv - y0f;
-            int x0, x1, r0, r1;
-            if (interior) {
-                x0 = (int)x0f; x1 = x0 + 1; r0 = (int)y0f * w; r1 = r0 + w;
-            } else {
-                int ix = (int)x0f - bx0, iy = (int)y0f - by0;
-                ix = ix < 0 ? 0 : (ix > bw - 2 ? bw - 2 : ix);   // never binding (margin); keeps the table reads in range
-                iy = iy < 0 ? 0 : (iy > bh - 2 ? bh - 2 : iy);
-                x0 = tab[ix]; x1 = tab[ix + 1]; r0 = tab[kSampleBox + iy]; r1 = tab[kSampleBox + iy + 1];
-            }
-            const float top = img[r0 + x0] * (1.f - ax) + img[r0 + x1] * ax;
-            const float bot = img[r1 + x0] * (1.f - ax) + img[r1 + x1] * ax;
-            v = top * (1.f - ay) + bot * ay;
-        } else {
-            v = tex_bilinear(img, w, h, sx + 0.5f, sy + 0.5f);
-        }
-        tile[ly * 32 + lx] = v;
+        const SamplePos p = sample_position(g.ca, g.sa, g.rem, g.cx, g.cy, lx, ly);
+        tile[ly * 32 + lx] = sample_level(lvl0, w, h, pitch, apron, g.covered, p);
     }
     __builtin_amdgcn_wave_barrier();
     float *dst = patches + k * 1024 + lane;
@@ -366,145 +301,12 @@ __global__ __launch_bounds__(256) void sample_patches(const float *__restrict__ 
     for (int j = 0; j < 16; ++j) dst[j * 64] = tile[j * 64 + lane];
 }
 
-// The same stage with the texels of INTERIOR footprints staged through LDS.  The gather form above is bound by the
-// texture-address path: 4096 scattered lane-loads per keypoint, ~3500 L1 accesses.  Here the patch is handled in four
-// 16 x 16 pixel quadrants; where the bounding box of a quadrant's footprint (at most 48 x 48 texels for every scale
-// remainder < 2 and every angle) lies inside the pyramid level with room to spare, it is copied into LDS by LDS-DMA --
-// 16 bytes per lane over consecutive addresses, five box rows per request, no registers -- and the four bilinear taps of
-// a sample are two ds_read2_b32.  A quadrant whose box touches the level's border (MirroredRepeat) takes the gather path
-// for its 256 samples.  This form is bound by the instructions it issues, so everything uniform over the wave lives in
-// scalar registers, the copy is five scalar instructions per request, per-lane constants are hoisted out of the sample loop.
-// Arithmetic of a sample (coordinates, floor / fraction, blend) follows the gather form term by term.
-constexpr int kQuadBox = 48;    // texels per box row: >= 15 * 2 * sqrt2 + 5
-constexpr int kQuadRows = 50;   // box rows: ten requests of five
-
-// (uniform base) + (32-bit lane offset): the SGPR-base addressing form, no 64-bit VALU add per request (see the
-// describe kernel's lds_dma16_sv for the two empty asm statements)
-__device__ __forceinline__ void lds_dma16_sv(const unsigned char *uniform_base, unsigned lane_off, void *ldst) {
-    asm("" : "+s"(uniform_base));
-    asm volatile("" : "+v"(lane_off));
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uniform_base + lane_off),
-                                     (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
-}
-
-__global__ __launch_bounds__(256) void sample_patches_lds(const float *__restrict__ pyr, long pyr_stride, PyramidDesc pd,
-                                                          const float *__restrict__ kps /*[n][5]*/,
-                                                          const unsigned *__restrict__ frame_of_kp, long n_host,
-                                                          const unsigned long long *__restrict__ n_dev, float psf,
-                                                          float *__restrict__ patches) {
-    __shared__ __attribute__((aligned(16))) float s_box[4][kQuadRows * kQuadBox];
-    const long n = n_dev ? (long)*n_dev : n_host;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long k = (long)blockIdx.x * 4 + wave;
-    if (k >= n) return;
-    const int lane = threadIdx.x & 63;
-    if (frame_of_kp) pyr += (long)__builtin_amdgcn_readfirstlane((int)frame_of_kp[k]) * pyr_stride;
-    const float *kp = kps + k * 5;
-    const float scale = kp[2] * psf / 32.f;
-    const float l2 = log2f(scale);
-    float lvl = floorf(l2);
-    lvl = lvl < 0.f ? 0.f : (lvl > (float)(pd.levels - 1) ? (float)(pd.levels - 1) : lvl);
-    const float rem = exp2f(l2 - lvl);
-    int l = (int)lvl;   // a non-finite size (caller-supplied keypoints) must not index outside the pyramid
-    l = l < 0 ? 0 : (l > pd.levels - 1 ? pd.levels - 1 : l);
-    l = __builtin_amdgcn_readfirstlane(l);   // uniform, but computed on the vector side: level geometry into scalar registers
-    const float ang = kp[3] * (3.14159265358979323846f / 180.f);
-    const float ca = cosf(ang), sa = sinf(ang);
-    const float inv = 1.f / exp2f(lvl);
-    const float *img = pyr + pd.offset[l];
-    const int w = pd.w[l], h = pd.h[l];
-    const float cx = kp[0] * inv, cy = kp[1] * inv;
-    float *box = s_box[wave];
-    float *dst = patches + k * 1024;
-    // a step samples 4 patch rows x 16 columns of the quadrant
-    const int col = lane & 15, row4 = lane >> 4;
-    const float colf = (float)col - 16.f, row4f = (float)row4 - 16.f;
-    float *dst_lane = dst + row4 * 32 + col;
-    // copy: lane = (row within a group of five, 16-byte chunk within the row)
-    const int sub = lane / 12, chunk = lane - 12 * sub;
-    const unsigned copy_off = ((unsigned)sub * (unsigned)w + 4u * (unsigned)chunk) * 4u;
-    // A quadrant's samples lie within +-ext of its centre in x and in y (half-size 7.5 pixels, rotated, scaled); with the
-    // +1 neighbour and margin either side (rounding of the centre against the samples' own arithmetic) the box is `bsz`
-    // texels wide and high, the same for the four quadrants.
-    const float ext = 7.5f * rem * (fabsf(ca) + fabsf(sa));
-    const float bszf = floorf(2.f * ext) + 6.f;
-    // (comparisons are false for NaN: a non-finite keypoint takes the gather path)
-    const bool finite = bszf >= 6.f && bszf <= (float)kQuadBox && fabsf(cx) < 1e9f && fabsf(cy) < 1e9f;
-    const int bsz = __builtin_amdgcn_readfirstlane(finite ? (int)bszf : kQuadBox);
-    const int n_req = (bsz + 4) / 5, rows = 5 * n_req;   // rows <= kQuadRows
-    const int n_chunk = (bsz + 3) / 4;                   // 16-byte chunks of a box row that are needed
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int px0 = 16 * (q & 1), py0 = 16 * (q >> 1);
-        // centre of the quadrant (pixel offset 7.5 into it), by the samples' expression
-        const float qdx = (float)px0 - 8.5f, qdy = (float)py0 - 8.5f;
-        const float qx = (qdx * ca - qdy * sa) * rem + cx, qy = (qdx * sa + qdy * ca) * rem + cy;
-        const int bx0 = __builtin_amdgcn_readfirstlane(finite ? (int)floorf(qx - ext) : -1) - 2;
-        const int by0 = __builtin_amdgcn_readfirstlane(finite ? (int)floorf(qy - ext) : -1) - 2;
-        if (!(bx0 >= 0 && bx0 + 4 * n_chunk <= w && by0 >= 0 && by0 + rows <= h)) {   // uniform: the gather path
-#pragma unroll 1
-            for (int i = 0; i < 4; ++i) {
-                const int lx = px0 + col, ly = py0 + 4 * i + row4;
-                const float dx = (float)lx - 16.f, dy = (float)ly - 16.f;
-                const float xx = dx * ca - dy * sa, yy = dx * sa + dy * ca;
-                const float sx = xx * rem + kp[0] * inv, sy = yy * rem + kp[1] * inv;
-                dst[ly * 32 + lx] = tex_bilinear(img, w, h, sx + 0.5f, sy + 0.5f);
-            }
-            continue;
-        }
-        // the previous quadrant's LDS reads have returned before its texels are overwritten (LDS-DMA writes do not queue
-        // behind ds_read instructions)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // Inside the level (MirroredRepeat is the identity) with room for full-width rows and whole groups of five:
-        // 12 lanes cover a box row (the LDS pitch is exactly their 192 bytes), one request moves five rows.  Global
-        // addresses are only 4-byte aligned (gfx950 runs in unaligned access mode).
-        if (sub < 5 && chunk < n_chunk) {
-            // (the offset goes through readfirstlane: left to itself hipcc forms part of this address on the vector side)
-            const int first = __builtin_amdgcn_readfirstlane(by0 * w + bx0);   // a level holds < 2^31 texels
-            const unsigned char *src = reinterpret_cast<const unsigned char *>(img + first);   // uniform
-            for (int r = 0; r < n_req; ++r)
-                lds_dma16_sv(src + (long)r * 5 * w * 4, copy_off, box + r * 5 * kQuadBox);
-        }
-        const float a_q = ((float)px0 + colf) * ca, b_q = ((float)px0 + colf) * sa;   // dx ca, dx sa of this lane's column
-        const float bxf = (float)bx0, byf = (float)by0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float dy = row4f + (float)(py0 + 4 * i);
-            const float xx = __builtin_fmaf(-dy, sa, a_q), yy = __builtin_fmaf(dy, ca, b_q);
-            const float sx = __builtin_fmaf(xx, rem, cx), sy = __builtin_fmaf(yy, rem, cy);
-            // tex_bilinear(img, w, h, sx + 0.5f, sy + 0.5f) with the texels read from the box
-            const float fu = (sx + 0.5f) - 0.5f, fv = (sy + 0.5f) - 0.5f;
-            const float x0f = floorf(fu), y0f = floorf(fv);
-            const float ax = fu - x0f, ay = fv - y0f;
-            int ix = (int)(x0f - bxf), iy = (int)(y0f - byf);
-            ix = min(max(ix, 0), bsz - 2);   // never binding (margins); keeps the LDS reads inside what was copied
-            iy = min(max(iy, 0), rows - 2);
-            const float *t = box + __umul24(iy, kQuadBox) + ix;   // 24-bit multiply: full rate
-            const float t00 = t[0], t10 = t[1], t01 = t[kQuadBox], t11 = t[kQuadBox + 1];
-            const float top = t00 * (1.f - ax) + t10 * ax;
-            const float bot = t01 * (1.f - ax) + t11 * ax;
-            dst_lane[(py0 + 4 * i) * 32 + px0] = top * (1.f - ay) + bot * ay;
-        }
-    }
-}
-
 void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                            const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
-                           float *patches, hipStream_t stream, bool beside_describe) {
+                           float *patches, hipStream_t stream) {
     if (n <= 0) return;
-    // The LDS-staged form is 10-30 % faster on its own.  Beside the describe kernel (large batches, lf_mkd.cpp) the
-    // all-gather form is used: it leaves the vector ALUs and the LDS to the describe kernel (19 KiB of LDS per workgroup
-    // against 38, so that two of its workgroups fit next to a describe workgroup on a CU), and the pair is 1.5 % faster.
-    // LF_MKD_SAMPLER=gather / lds forces one form everywhere (A/B timing, and the cross-check in the tests).
-    static const int forced = [] { const char *e = getenv("LF_MKD_SAMPLER"); return e ? (e[0] == 'g' ? 1 : (e[0] == 'l' ? 2 : 0)) : 0; }();
-    const bool gather = forced == 1 || (forced == 0 && beside_describe);
-    if (gather)
-        hipLaunchKernelGGL(sample_patches, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, pyr, pyr_stride, pd, kps,
-                           frame_of_kp, n, n_dev, psf, patches);
-    else
-        hipLaunchKernelGGL(sample_patches_lds, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, pyr, pyr_stride, pd,
-                           kps, frame_of_kp, n, n_dev, psf, patches);
+    hipLaunchKernelGGL(sample_patches, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, pyr, pyr_stride, pd, kps,
+                       frame_of_kp, n, n_dev, psf, patches);
 }
 
 // Builds the pyramids of `frames` frames (image_stride floats apart) into pyr (pyr_stride apart); tmp_a and tmp_b
@@ -544,15 +346,23 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
         stream = rest_stream;
     }
     hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)l1, pyr + pd.offset[1],
-                       l1s, pyr_stride, w, h, pd.w[1], pd.h[1]);
+                       l1s, pyr_stride, w, h, pd.w[1], pd.h[1], pd.pitch[1]);
     // levels >= 2: binomial H at the resolution of level l-1, then V with 2x decimation; the small levels in one launch
     int l0 = pd.levels;
     while (l0 > 2 && pd.w[l0 - 2] * pd.h[l0 - 2] <= kTailPixels) --l0;
     for (int l = 2; l < l0; ++l)
         hipLaunchKernelGGL(pyr_down_fused, dim3((pd.w[l] + 255) / 256, (pd.h[l] + kDownRows - 1) / kDownRows, frames),
                            dim3(256), 0, stream, (const float *)(pyr + pd.offset[l - 1]), pyr + pd.offset[l], pyr_stride,
-                           pyr_stride, pd.w[l - 1], pd.h[l - 1], pd.w[l], pd.h[l]);
+                           pyr_stride, pd.w[l - 1], pd.h[l - 1], pd.pitch[l - 1], pd.w[l], pd.h[l], pd.pitch[l]);
     if (l0 < pd.levels) hipLaunchKernelGGL(pyr_tail, dim3(frames), dim3(1024), 0, stream, pyr, pyr_stride, pd, l0);
+    // the mirrored apron of levels >= 1: enough workgroups for the largest level's bands, the smaller levels loop less
+    {
+        const int a = pd.apron[1];
+        const long texels = 2L * a * pd.pitch[1] + 2L * a * pd.h[1];
+        const unsigned gx = (unsigned)std::min<long>((texels + 255) / 256, 1024);
+        hipLaunchKernelGGL(pyr_apron_fill, dim3(gx, (unsigned)(pd.levels - 1), (unsigned)frames), dim3(256), 0, stream, pyr,
+                           pyr_stride, pd);
+    }
     if (rest_stream) (void)hipEventRecord(join, rest_stream);
 }
 

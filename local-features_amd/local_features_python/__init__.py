@@ -13,11 +13,11 @@ import threading
 
 import numpy as np
 
-from ._lib import (ANGLE_EXACT, ANGLE_EXACT_ZERO, ANGLE_SHADER, FLAG_KERNEL_TIMING, FLAG_NO_OVERLAP, KEYPOINT_DTYPE, LIB_PATH, MODEL_DIR, PCA_NAMES,
+from ._lib import (ANGLE_EXACT, ANGLE_EXACT_ZERO, ANGLE_SHADER, FLAG_KERNEL_TIMING, FLAG_UNFUSED_KEYPOINTS, KEYPOINT_DTYPE, LIB_PATH, MODEL_DIR, PCA_NAMES,
                    POOL_DEFAULT, POOL_F16X3, POOL_F32, SYMBOLS, MkdHandle, load_library, model_path)
 
 __all__ = ["Keypoint", "LocalFeatures", "MkdHandle", "ANGLE_SHADER", "ANGLE_EXACT", "ANGLE_EXACT_ZERO", "POOL_DEFAULT", "POOL_F32",
-           "POOL_F16X3", "FLAG_KERNEL_TIMING", "FLAG_NO_OVERLAP", "KEYPOINT_DTYPE", "PCA_NAMES", "SYMBOLS", "LIB_PATH", "MODEL_DIR",
+           "POOL_F16X3", "FLAG_KERNEL_TIMING", "FLAG_UNFUSED_KEYPOINTS", "KEYPOINT_DTYPE", "PCA_NAMES", "SYMBOLS", "LIB_PATH", "MODEL_DIR",
            "load_library", "model_path"]
 
 

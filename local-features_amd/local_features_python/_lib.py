@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("LF_MKD_LIB", os.path.join(_ROOT, "liblf_mkd.so"))   #
 MODEL_DIR = os.path.join(_ROOT, "models", "mkd")
 
 FLAG_KERNEL_TIMING = 1
-FLAG_NO_OVERLAP = 2
+FLAG_UNFUSED_KEYPOINTS = 2
 ANGLE_SHADER, ANGLE_EXACT, ANGLE_EXACT_ZERO = 0, 1, 2
 POOL_DEFAULT, POOL_F16X3, POOL_F32 = 0, 1, 2   # lf_mkd_pool_mode; the default is the f16x3 split
 PCA_NAMES = ("liberty", "notredame", "yosemite")   # enum MKDPCA, lib.rs:26-32
@@ -23,6 +23,7 @@ SYMBOLS = (
     "lf_mkd_set_image", "lf_mkd_set_image_device", "lf_mkd_set_images_device", "lf_mkd_describe_keypoints",
     "lf_mkd_describe_keypoints_frames_device",
     "lf_mkd_describe_keypoints_device", "lf_mkd_sample_patches_device", "lf_mkd_get_pyramid_level",
+    "lf_mkd_get_pyramid_level_apron",
     "lf_mkd_build_constants", "lf_mkd_kernel_times", "lf_mkd_synchronize", "lf_mkd_version",
     "lf_mkd_orient_keypoints", "lf_mkd_orient_keypoints_device", "lf_mkd_get_coarse_layer",
     "lf_mkd_detect_extrema", "lf_mkd_detect_extrema_device", "lf_mkd_filter_extrema_device", "lf_mkd_detect",
@@ -88,6 +89,7 @@ def load_library():
     L.lf_mkd_describe_keypoints_device.argtypes = [vp, vp, u64, vp, vp]
     L.lf_mkd_sample_patches_device.argtypes = [vp, vp, u64, vp, vp]
     L.lf_mkd_get_pyramid_level.argtypes = [vp, u32, vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.lf_mkd_get_pyramid_level_apron.argtypes = [vp, u32, vp, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.lf_mkd_synchronize.argtypes = [vp]
     L.lf_mkd_orient_keypoints.argtypes = [vp, vp, u64, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     L.lf_mkd_orient_keypoints_device.argtypes = [vp, vp, vp, u64, vp, vp, u64, ctypes.POINTER(u64),
@@ -241,6 +243,16 @@ class MkdHandle:
         self._check(self.L.lf_mkd_get_pyramid_level(self._h, level, out.ctypes.data, None, None),
                     "lf_mkd_get_pyramid_level")
         return out
+
+    def pyramid_level_apron(self, level):
+        """(level with its mirrored apron [(h + 2a), (w + 2a)], a)."""
+        w, h, a = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self.L.lf_mkd_get_pyramid_level_apron(self._h, level, None, ctypes.byref(w), ctypes.byref(h),
+                                                          ctypes.byref(a)), "lf_mkd_get_pyramid_level_apron")
+        out = np.empty((h.value + 2 * a.value, w.value + 2 * a.value), np.float32)
+        self._check(self.L.lf_mkd_get_pyramid_level_apron(self._h, level, out.ctypes.data, None, None, None),
+                    "lf_mkd_get_pyramid_level_apron")
+        return out, a.value
 
     # --- device-pointer entry points ---------------------------------------------------------
     # `stream`: a HIP stream handle (e.g. torch.cuda.Stream().cuda_stream) on which the work is enqueued, in order with

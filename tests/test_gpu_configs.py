@@ -162,13 +162,14 @@ def test_configs2_256_frames_640x480_2000_keypoints_each(lfp, torch, oracle):
     for f in (0, 1, 17, 100, 129, 200, 254, 255):
         rows = f * nk + np.sort(rng.choice(nk, 64, replace=False))
         one.set_image(base[f % 16])
-        assert_keypoint_parity(oracle, one, base[f % 16], k5[rows], got[rows], what=f"configs[2] frame {f}")
+        # (64 rows: three patches on the atan2 discontinuity are already 5 %)
+        assert_keypoint_parity(oracle, one, base[f % 16], k5[rows], got[rows], what=f"configs[2] frame {f}", min_settled=0.9)
 
 
-def test_large_keypoint_batches_run_sampler_and_describe_side_by_side(lfp, torch, oracle):
-    """Batches of >= 65 536 keypoints are chunked: chunk i+1 is sampled on a second stream while chunk i is described
-    (lf_mkd.cpp).  The result must be what the single-stream order gives (LF_MKD_FLAG_NO_OVERLAP) up to the two samplers'
-    rounding, a sample of it what the oracle gives, and repeated calls must agree bit for bit (no race between the streams)."""
+def test_large_keypoint_batches_fused_and_two_launch_forms_agree(lfp, torch, oracle):
+    """80 000 keypoints on 4 frames: the one-launch form (patches sampled inside the describe kernel) and the two-launch form
+    through HBM (LF_MKD_FLAG_UNFUSED_KEYPOINTS) give the same bits, repeated calls agree bit for bit (no race between the
+    producer and the describe waves of a workgroup), and a sample of every frame is what the oracle gives."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from gen_golden import random_keypoints, smooth_image
     w, hgt, nf, nk = 320, 240, 4, 20000
@@ -180,7 +181,7 @@ def test_large_keypoint_batches_run_sampler_and_describe_side_by_side(lfp, torch
     d_img, d_k, d_f = torch.from_numpy(imgs).cuda(), torch.from_numpy(k5).cuda(), torch.from_numpy(fid).cuda()
     s = torch.cuda.current_stream().cuda_stream
     outs = []
-    for flags in (0, lfp.FLAG_NO_OVERLAP, 0):
+    for flags in (0, lfp.FLAG_UNFUSED_KEYPOINTS, 0):
         h = lfp.MkdHandle(max_features=n, max_image_width=w, max_image_height=hgt, max_frames=nf, flags=flags)
         out = torch.zeros((n, 128), device="cuda")
         h.set_images_device(d_img.data_ptr(), nf, w, hgt, s)
@@ -191,8 +192,7 @@ def test_large_keypoint_batches_run_sampler_and_describe_side_by_side(lfp, torch
     a, b, a2 = outs
     assert np.array_equal(a, a2)                                           # deterministic across handles and calls
     assert np.isfinite(a).all() and np.abs(np.linalg.norm(a, axis=1) - 1).max() < 1e-5
-    e = rel_l2(a, b)
-    assert np.quantile(e, 0.995) < 2e-5 and (e > GATE).mean() < 0.005, (np.quantile(e, 0.995), (e > GATE).mean())
+    assert np.array_equal(a, b)                                            # one sampling arithmetic: the same bits
     # a sample of every chunk against the oracle, end to end, through the helper: the GPU-sampled patches of the picked
     # rows must meet the gate on every settled row (no allowance)
     pick = np.arange(0, n, 160)

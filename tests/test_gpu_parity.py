@@ -360,25 +360,93 @@ def test_extreme_patch_values(lfp, oracle):
         assert rel_l2(d[:6], ref[:6]).max() < GATE, (pool, rel_l2(d, ref))
 
 
-def test_the_two_sampler_forms_agree(tmp_path):
-    """The sampler stages the texels of interior footprints through LDS (sample_patches_lds) and gathers the rest; the
-    all-gather form (sample_patches) runs beside the describe kernel in large batches and behind LF_MKD_SAMPLER=gather.
-    Same texels, same weights: they agree to the rounding of the sample coordinates (the two kernels contract the same
-    expressions into different fma's) -- on interior keypoints, footprints over the level's edge, sizes beyond both ends
-    of the pyramid, and non-finite keypoints (finite or not, the two agree and nothing faults)."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tool = os.path.join(root, "tools", "sample_dump.py")
-    for size, tol in (((333, 257), 5e-6), ((1920, 1080), 3e-5), ((40, 36), 5e-6)):
+def _adversarial_keypoints(w, h):
+    """Interior keypoints, keypoints on and next to the frame's borders, footprints larger than the frame's levels, sizes
+    below level 0, non-finite ones."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_golden import random_keypoints
+    g = np.random.default_rng(5)
+    k = [random_keypoints(3000, w, h, 1, margin=0.0)]                       # anywhere, border included
+    edge = random_keypoints(600, w, h, 2, margin=0.0)
+    edge[:, 0] = g.choice([0.0, 0.4, w - 1.0, w - 0.3, w / 2], 600)         # on and next to the vertical borders
+    edge[:300, 1] = g.choice([0.0, h - 1.0, h - 0.2], 300)
+    k.append(edge)
+    big = random_keypoints(200, w, h, 3, margin=0.0)
+    big[:, 2] = g.uniform(40.0, 400.0, 200)                                 # footprints larger than the frame's levels
+    k.append(big)
+    tiny = random_keypoints(200, w, h, 4, margin=0.0)
+    tiny[:, 2] = g.uniform(0.01, 1.4, 200)                                  # below level 0
+    k.append(tiny)
+    outside = random_keypoints(100, w, h, 7, margin=0.0)
+    outside[:, 0] += g.choice([-3.0 * w, -40.0, 55.0 + w, 2.5 * w], 100)    # centres outside the frame: no apron reaches
+    k.append(outside)
+    odd = random_keypoints(8, w, h, 6, margin=0.0)
+    odd[0, 2], odd[1, 2], odd[2, 0], odd[3, 3], odd[4, 2], odd[5, 1] = np.nan, np.inf, np.nan, np.inf, 0.0, -1e30
+    k.append(odd)
+    k = np.concatenate(k).astype(np.float32)
+    return np.ascontiguousarray(np.concatenate([k, np.zeros((len(k), 1), np.float32)], axis=1))
+
+
+def test_pyramid_apron_is_mirrored_repeat(lfp):
+    """Levels >= 1 of the patch pyramid carry an apron of 48 texels holding what MirroredRepeat addressing would fetch there
+    (several mirror periods on the small levels); level 0, which the detector shares, is dense."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_golden import smooth_image
+    for w, hgt in ((640, 480), (333, 257), (40, 36), (1920, 1080)):
+        img = np.ascontiguousarray(smooth_image(hgt, w, w + 1), np.float32)
+        h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt)
+        h.set_image(img)
+        l = 0
+        while True:
+            try:
+                lvl = h.pyramid_level(l)
+            except RuntimeError:
+                break
+            padded, a = h.pyramid_level_apron(l)
+            assert a == (0 if l == 0 else 48)
+            assert np.array_equal(padded, np.pad(lvl, a, mode="symmetric")), (w, hgt, l)
+            l += 1
+        assert l >= 5
+
+
+def test_the_fused_keypoint_kernel_describes_exactly_what_the_sampler_samples(lfp, torch, oracle):
+    """Keypoint mode is one launch: producer waves of the describe kernel sample the patches into its LDS ring.  The
+    two-launch form (LF_MKD_FLAG_UNFUSED_KEYPOINTS: sampler -> patches in HBM -> patch kernel) and the verification tap
+    lf_mkd_sample_patches_device use the same sampling arithmetic (csrc/mkd_sample.h), so all three agree BIT FOR BIT -- on
+    interior keypoints, footprints over the level's edge (apron), footprints the apron does not cover (MirroredRepeat per
+    tap), sizes beyond both ends of the pyramid, and non-finite keypoints (finite or not, they agree and nothing faults)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_golden import smooth_image
+    for (w, hgt) in ((333, 257), (1920, 1080), (40, 36)):
+        img = np.ascontiguousarray(smooth_image(hgt, w, 9), np.float32)
+        k5 = _adversarial_keypoints(w, hgt)
+        n = len(k5)
+        d_k = torch.from_numpy(k5).cuda()
         outs = []
-        for mode in ("lds", "gather"):
-            f = tmp_path / f"{mode}_{size[0]}.npy"
-            subprocess.check_call([sys.executable, tool, str(f), str(size[0]), str(size[1])],
-                                  env=dict(os.environ, LF_MKD_SAMPLER=mode), timeout=300)
-            outs.append(np.load(f))
-        a, b = outs
-        assert a.shape == b.shape and len(a) > 4000
-        assert (np.isfinite(a) == np.isfinite(b)).all(), size
-        fin = np.isfinite(a)
-        assert np.abs(a[fin] - b[fin]).max() < tol, (size, np.abs(a[fin] - b[fin]).max())
-        assert np.isfinite(a[:3000]).all() and (a[:3000] != -7.0).all()      # every pixel written
+        for flags in (0, lfp.FLAG_UNFUSED_KEYPOINTS):
+            h = lfp.MkdHandle(max_features=1024, max_image_width=w, max_image_height=hgt, flags=flags)   # several internal batches
+            h.set_image(img)
+            out = torch.full((n, 128), -7.0, device="cuda")
+            h.describe_keypoints_device(d_k.data_ptr(), n, out.data_ptr())
+            outs.append(out.cpu().numpy())
+        fused, unfused = outs
+        fin = np.isfinite(fused).all(axis=1)
+        assert np.array_equal(fin, np.isfinite(unfused).all(axis=1)), (w, hgt)
+        assert fin[:4100].all() and fin.sum() >= n - 8
+        assert np.array_equal(fused[fin], unfused[fin]), (w, hgt, np.abs(fused[fin] - unfused[fin]).max())
+        assert (fused[fin] != -7.0).any(axis=1).all()                      # every row written
+        # the tap, described by the patch kernel, is the fused kernel's answer too
+        d_p = torch.full((n, 32, 32), -7.0, device="cuda")
+        h.sample_patches_device(d_k.data_ptr(), n, d_p.data_ptr())
+        p = d_p.cpu().numpy()
+        assert (p[fin] != -7.0).all()                                       # every pixel written
+        hp = lfp.MkdHandle(max_features=n)
+        assert np.array_equal(hp.describe_patches(p[fin]), fused[fin])
+        # and the sampled values are the oracle's, to the rounding of the sample coordinates (different libm)
+        ok = np.where(fin)[0][::7]
+        ref_p = oracle.sample_patches(oracle.build_pyramid(img), w, hgt, k5[ok, :4])
+        tol = 6e-5 if w > 1000 else 1e-5    # (coordinates up to 1920: one ulp there is 1.2e-4 texel)
+        assert np.abs(p[ok] - ref_p).max() < tol, (w, hgt, np.abs(p[ok] - ref_p).max())
