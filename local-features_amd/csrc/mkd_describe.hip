@@ -451,13 +451,28 @@ __device__ __forceinline__ void pool_harmonics(const f32x2 (&m)[4], const f32x2 
         if (k < 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+#ifdef LF_SCALAR_RECURRENCE   // A/B build: the recurrence between the harmonics' MFMAs as scalar f32 instead of packed f32
+                const f32x2 pm = k == 0 ? m[e] : pp[e];
+                const f32x2 pn = {__builtin_fmaf(tc[e].x, pk[e].x, -pm.x), __builtin_fmaf(tc[e].y, pk[e].y, -pm.y)};
+                const f32x2 qn = k == 0 ? f32x2{tc[e].x * qk[e].x, tc[e].y * qk[e].y}
+                                        : f32x2{__builtin_fmaf(tc[e].x, qk[e].x, -qp[e].x), __builtin_fmaf(tc[e].y, qk[e].y, -qp[e].y)};
+#else
                 const f32x2 pn = pk_fma(tc[e], pk[e], k == 0 ? -m[e] : -pp[e]);
                 const f32x2 qn = k == 0 ? tc[e] * qk[e] : pk_fma(tc[e], qk[e], -qp[e]);
+#endif
                 pp[e] = pk[e]; qp[e] = qk[e];
                 pk[e] = pn; qk[e] = qn;
             }
         }
         const int a0 = 3 + 7 * k, u0 = 3 + 4 * k;
+#ifdef LF_ABLATE_HALF_MMA   // timing-only build: what a formulation with half the matrix work and half the fragment reads would cost
+        const BFrag p0 = g, q0 = load_b(brow, u0 + 1);
+        if (k < 2) g = load_b(brow, u0 + 4);
+        mma_part<POOL, 0>(ac, p0, acc[a0 + 0]); mma_part<POOL, 0>(as, p0, acc[a0 + 2]); mma_part<POOL, 0>(as, q0, acc[a0 + 1]);
+        mma_part<POOL, 1>(ac, p0, acc[a0 + 0]); mma_part<POOL, 1>(as, p0, acc[a0 + 2]); mma_part<POOL, 1>(as, q0, acc[a0 + 1]);
+        mma_part<POOL, 2>(ac, p0, acc[a0 + 0]); mma_part<POOL, 2>(as, p0, acc[a0 + 2]); mma_part<POOL, 2>(as, q0, acc[a0 + 1]);
+        mma_part<POOL, 0>(ac, q0, acc[a0 + 2]); mma_part<POOL, 1>(ac, q0, acc[a0 + 2]); mma_part<POOL, 2>(ac, q0, acc[a0 + 2]);
+#else
         const BFrag p0 = g, q0 = load_b(brow, u0 + 1), r = load_b(brow, u0 + 2), sf = load_b(brow, u0 + 3);
         if (k < 2) g = load_b(brow, u0 + 4);
         // cos x P0 -> a0 | sin x P0 -> a0+2 | sin x Q0 -> a0+1 | cos x R, sin x R -> a0+3, a0+4 | cos x S, sin x S -> a0+5, a0+6
@@ -472,6 +487,7 @@ __device__ __forceinline__ void pool_harmonics(const f32x2 (&m)[4], const f32x2 
         mma_part<POOL, 2>(ac, sf, acc[a0 + 5]); mma_part<POOL, 2>(as, sf, acc[a0 + 6]);
         // cos x Q0: the second product of relsin[0:16], into the accumulator of the first
         mma_part<POOL, 0>(ac, q0, acc[a0 + 2]); mma_part<POOL, 1>(ac, q0, acc[a0 + 2]); mma_part<POOL, 2>(ac, q0, acc[a0 + 2]);
+#endif
     }
 }
 
@@ -732,9 +748,12 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
                                            BatchWalk walk, unsigned char *s_mem, const unsigned char *__restrict__ lut_rows,
                                            int pw, int lane) {
     unsigned char *ring = s_mem + kRingOff + pw * (kRingSlotsKp * 2048);
-#ifdef LF_KP_PRODUCER_PRIO
-    __builtin_amdgcn_s_setprio(LF_KP_PRODUCER_PRIO);
+    // The producer is the shorter instruction stream of the two waves on its SIMD, but its step ends in the barrier the
+    // describe waves of all four SIMDs wait at: served first, it keeps out of their way (same-box A/B: +4 %)
+#ifndef LF_KP_PRODUCER_PRIO
+#define LF_KP_PRODUCER_PRIO 2
 #endif
+    __builtin_amdgcn_s_setprio(LF_KP_PRODUCER_PRIO);
     // geometry of a batch's 16 keypoints, one per lane: lanes 0-15 hold set 0, lanes 16-31 set 1 (this batch / the next).
     // g_xmax / g_ymax: largest first-tap index in the level's allocation (apron included), g_pitch4: row pitch in bytes.
     float g_ca = 0.f, g_sa = 0.f, g_rem = 0.f, g_cx = 0.f, g_cy = 0.f;

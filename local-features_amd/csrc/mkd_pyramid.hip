@@ -150,6 +150,56 @@ __global__ void pyr_decimate(const float *__restrict__ in, float *__restrict__ o
     out[(size_t)y * opitch + x] = in[(size_t)sy * w + sx];
 }
 
+// Level 1 in one launch when nobody else needs a-trous layer 1 (describe-only callers: the detector and the orientation
+// stage are what share it): the a-trous pass (swt.glsl:24-58, dilation 1) evaluated only at the texels the Nearest blit
+// (patch_pyramid.rs:251-285) picks -- the horizontal pass at the picked columns of the rows the picked rows reach, kept in
+// LDS, the vertical pass at the picked rows.  Same pixel arithmetic in the same order as pyr_swt_fused + pyr_decimate:
+// bit-identical, a quarter of the vertical work, and layer 1 (a full frame) is neither written nor read back.
+constexpr int kL1Rows = 8;                       // output rows per workgroup
+constexpr int kL1Slots = 2 * kL1Rows + 8;        // source rows they reach (odd heights step by 3 now and then)
+
+__device__ __forceinline__ int blit_src(int i, int n) {   // pyr_decimate's source index, clamped the same way
+    int s = (int)floorf(((float)i + 0.5f) * (float)n / (float)(n / 2));
+    return s > n - 1 ? n - 1 : s;
+}
+
+__global__ __launch_bounds__(256) void pyr_level1_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
+                                                        long out_stride, int w, int h, int ow, int oh, int opitch) {
+#pragma clang fp contract(off)
+    __shared__ float s_h[kL1Slots][256];
+    const float k0 = 6.f / 16.f, k1 = 4.f / 16.f, k2 = 1.f / 16.f;
+    in += blockIdx.z * in_stride;
+    out += blockIdx.z * out_stride;
+    const int y0 = (int)blockIdx.y * kL1Rows;
+    const int xr = (int)blockIdx.x * 256 + (int)threadIdx.x, x = xr < ow ? xr : ow - 1;
+    const int sx = blit_src(x, w);
+    int xi[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) xi[t] = mirror_idx(sx + t - 2, w);
+    const int y_last = min(y0 + kL1Rows, oh) - 1;
+    const int v0 = blit_src(y0, h) - 2;                       // virtual source row of slot 0
+    const int n_slots = min(blit_src(y_last, h) + 2 - v0 + 1, kL1Slots);
+    for (int m = 0; m < n_slots; ++m) {
+        const float *row = in + (size_t)mirror_idx(v0 + m, h) * w;
+        float sum = row[xi[2]] * k0;
+        sum += row[xi[0]] * k2;
+        sum += row[xi[1]] * k1;
+        sum += row[xi[3]] * k1;
+        sum += row[xi[4]] * k2;
+        s_h[m][threadIdx.x] = sum;
+    }
+    __syncthreads();
+    for (int y = y0; y <= y_last; ++y) {
+        const int k = blit_src(y, h) - 2 - v0;                  // slot of source row sy - 2
+        float sum = s_h[k + 2][threadIdx.x] * k0;
+        sum += s_h[k + 1][threadIdx.x] * k1;
+        sum += s_h[k][threadIdx.x] * k2;
+        sum += s_h[k + 4][threadIdx.x] * k2;
+        sum += s_h[k + 3][threadIdx.x] * k1;
+        if (xr < ow) out[(size_t)y * opitch + xr] = sum;
+    }
+}
+
 // blur_pyramid.glsl:36-49 vertical pass: binomial taps centred on texel (2x, 2y) of the H result.
 __device__ __forceinline__ float down_v_pixel(const float *__restrict__ in, int w, int h, int x, int y) {
 #pragma clang fp contract(off)
@@ -334,10 +384,12 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     hipLaunchKernelGGL(pyr_sep3_fused, dim3((w + 255) / 256, (h + 11) / 12, frames), dim3(256), 0, stream, image,
                        pyr + pd.offset[0], image_stride, pyr_stride, w, h, 0.66381836f, 0.16809084f, 1.015267163f);
     if (pd.levels < 2) return;
-    // level 1: one a-trous pass over level 0, nearest-decimated
+    // level 1: one a-trous pass over level 0, nearest-decimated.  Without a taker for the a-trous layer itself (layer1 ==
+    // nullptr: no detector / orientation stage has been used on this handle) only the texels the blit picks are computed.
+    const bool need_layer1 = layer1 != nullptr;
     float *l1 = layer1 ? layer1 : tmp_b;
     const long l1s = layer1 ? layer1_stride : ts;
-    launch_swt(pyr + pd.offset[0], pyr_stride, l1, l1s, w, h, 1, frames, stream);
+    if (need_layer1) launch_swt(pyr + pd.offset[0], pyr_stride, l1, l1s, w, h, 1, frames, stream);
     // Levels >= 1 are only read by the patch sampler: a caller whose next steps need level 0 and layer 1 alone (the
     // detector) can have them built on `rest_stream` beside those steps and wait for `join` before it samples.
     if (rest_stream) {
@@ -345,8 +397,13 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
         (void)hipStreamWaitEvent(rest_stream, fork, 0);
         stream = rest_stream;
     }
-    hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)l1, pyr + pd.offset[1],
-                       l1s, pyr_stride, w, h, pd.w[1], pd.h[1], pd.pitch[1]);
+    if (need_layer1)
+        hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)l1, pyr + pd.offset[1],
+                           l1s, pyr_stride, w, h, pd.w[1], pd.h[1], pd.pitch[1]);
+    else
+        hipLaunchKernelGGL(pyr_level1_fused, dim3((pd.w[1] + 255) / 256, (pd.h[1] + kL1Rows - 1) / kL1Rows, frames), dim3(256),
+                           0, stream, (const float *)(pyr + pd.offset[0]), pyr + pd.offset[1], pyr_stride, pyr_stride, w, h,
+                           pd.w[1], pd.h[1], pd.pitch[1]);
     // levels >= 2: binomial H at the resolution of level l-1, then V with 2x decimation; the small levels in one launch
     int l0 = pd.levels;
     while (l0 > 2 && pd.w[l0 - 2] * pd.h[l0 - 2] <= kTailPixels) --l0;
@@ -357,9 +414,11 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     if (l0 < pd.levels) hipLaunchKernelGGL(pyr_tail, dim3(frames), dim3(1024), 0, stream, pyr, pyr_stride, pd, l0);
     // the mirrored apron of levels >= 1: enough workgroups for the largest level's bands, the smaller levels loop less
     {
+        // (a few fat workgroups per level and frame: with hundreds of frames a thread-per-texel grid is half a million tiny
+        // workgroups, most of them on the small levels where they find nothing to do)
         const int a = pd.apron[1];
         const long texels = 2L * a * pd.pitch[1] + 2L * a * pd.h[1];
-        const unsigned gx = (unsigned)std::min<long>((texels + 255) / 256, 1024);
+        const unsigned gx = (unsigned)std::max<long>(1, std::min<long>((texels + 2047) / 2048, frames > 8 ? 8 : 64));
         hipLaunchKernelGGL(pyr_apron_fill, dim3(gx, (unsigned)(pd.levels - 1), (unsigned)frames), dim3(256), 0, stream, pyr,
                            pyr_stride, pd);
     }

@@ -128,6 +128,7 @@ def assert_keypoint_parity(oracle, handle, img, kps5, desc, gate=GATE, what="", 
     test frames that is 1e-6 in the sampled values, on a sharp photograph up to the local gradient times that."""
     import torch
     from oracle import ATAN_SHADER
+    what = str(what)
     img = np.ascontiguousarray(img, np.float32)
     kps5 = np.ascontiguousarray(kps5, np.float32)
     hgt, w = img.shape

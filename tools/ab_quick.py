@@ -13,7 +13,7 @@ p = torch.rand((n, 32, 32), device="cuda"); out = torch.empty((n, 128), device="
 res = []
 for angle in (0, 1):
     h = lfp.MkdHandle(max_features=n, angle_mode=angle)
-    s = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream(); torch.cuda.synchronize(); s = side.cuda_stream
     for _ in range(2): h.describe_patches_device(p.data_ptr(), n, out.data_ptr(), s)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(5): h.describe_patches_device(p.data_ptr(), n, out.data_ptr(), s)
