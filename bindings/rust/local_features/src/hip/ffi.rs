@@ -13,6 +13,7 @@ pub const LF_MKD_ERR_HIP: c_int = -2;
 pub const LF_MKD_ERR_IO: c_int = -3;
 pub const LF_MKD_ERR_NO_IMAGE: c_int = -4;
 pub const LF_MKD_ERR_NO_DEVICE: c_int = -5;
+pub const LF_MKD_ERR_COMM: c_int = -6;
 
 pub const LF_MKD_ANGLE_SHADER: i32 = 0;
 pub const LF_MKD_ANGLE_EXACT: i32 = 1;
@@ -23,6 +24,9 @@ pub const LF_MKD_POOL_F32: i32 = 2;
 pub const LF_MKD_FLAG_KERNEL_TIMING: u32 = 1;
 pub const LF_MKD_FLAG_UNFUSED_KEYPOINTS: u32 = 2;
 pub const LF_MKD_MAX_ANGLES_PER_EXTREMUM: usize = 18;
+pub const LF_MKD_COMM_ID_BYTES: usize = 128;
+pub const LF_MKD_GATHER_DIRECT: i32 = 0;
+pub const LF_MKD_GATHER_RING: i32 = 1;
 
 /// `lf_mkd_params`: BuildTimeParams (lib.rs:54-75) + FeatureDetectParams (lib.rs:34-52) for this path; 0 = default.
 #[repr(C)]
@@ -66,6 +70,12 @@ pub struct lf_mkd_extremum {
 /// Opaque handle; owns all device memory.
 #[repr(C)]
 pub struct lf_mkd {
+    _private: [u8; 0],
+}
+
+/// Opaque RCCL communicator of one rank (`lf_mkd_comm_create`).
+#[repr(C)]
+pub struct lf_mkd_comm {
     _private: [u8; 0],
 }
 
@@ -137,6 +147,14 @@ extern "C" {
     pub fn lf_mkd_match(h: *mut lf_mkd, a: *const f32, na: u64, b: *const f32, nb: u64, ratio: f32,
                         matches: *mut i32) -> c_int;
     pub fn lf_mkd_match_overflowed(h: *mut lf_mkd, stream: *mut c_void, n_rows: *mut u64) -> c_int;
+
+    // the path's one collective: the all-gather of descriptor shards over RCCL (configs[3])
+    pub fn lf_mkd_comm_unique_id(id: *mut u8) -> c_int;
+    pub fn lf_mkd_comm_create(h: *mut lf_mkd, id: *const u8, n_ranks: i32, rank: i32, out: *mut *mut lf_mkd_comm) -> c_int;
+    pub fn lf_mkd_comm_destroy(c: *mut lf_mkd_comm) -> c_int;
+    pub fn lf_mkd_comm_info(c: *const lf_mkd_comm, rccl_version: *mut i32, n_ranks: *mut i32, rank: *mut i32) -> c_int;
+    pub fn lf_mkd_allgather_descriptors(h: *mut lf_mkd, c: *mut lf_mkd_comm, counts: *const u64, d_buf: *mut f32,
+                                        mode: i32, stream: *mut c_void) -> c_int;
 
     pub fn lf_mkd_get_coarse_layer(h: *mut lf_mkd, layer: u32, out: *mut f32) -> c_int;
     pub fn lf_mkd_sample_patches_device(h: *mut lf_mkd, d_kps: *const lf_mkd_keypoint, n: u64, d_patches: *mut f32,

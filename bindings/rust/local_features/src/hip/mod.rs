@@ -13,11 +13,14 @@
 //!     pyramid mirrors at the content edge;
 //!   * the pooling contraction runs on the matrix cores from f16 hi+lo splits (descriptors within 1e-5 relative L2 of the
 //!     f32 formulation; `LF_MKD_POOL_F32` selects exact f32 arithmetic at half the speed).
+mod device;
 pub mod ffi;
 
 use std::ffi::{CStr, CString};
 
 use ndarray::{s, Array2, ArrayView2};
+
+use device::DeviceBuffer;
 
 use crate::vulkan::{BlobLocationsView, FilterBlobs, FilterBlobsOutput};
 use crate::{BuildTimeParams, FeatureDetectParams, FeaturesResult, Keypoint, DESCRIPTOR_LEN, MKDPCA};
@@ -36,6 +39,8 @@ pub enum Error {
     Io(String),
     #[error("no usable gfx950 device: {0}")]
     NoDevice(String),
+    #[error("RCCL: {0}")]
+    Comm(String),
     #[error("liblf_mkd: status {0}: {1}")]
     Other(i32, String),
 }
@@ -52,6 +57,7 @@ fn check(h: *const ffi::lf_mkd, rc: i32) -> Result<(), Error> {
         ffi::LF_MKD_ERR_HIP => Err(Error::Hip(last_error(h))),
         ffi::LF_MKD_ERR_IO => Err(Error::Io(last_error(h))),
         ffi::LF_MKD_ERR_NO_DEVICE => Err(Error::NoDevice(last_error(h))),
+        ffi::LF_MKD_ERR_COMM => Err(Error::Comm(last_error(h))),
         other => Err(Error::Other(other, last_error(h))),
     }
 }
@@ -231,6 +237,45 @@ impl LocalFeaturesHip {
         Ok(m.iter().enumerate().filter(|(_, j)| **j >= 0).map(|(i, j)| (i, *j as usize)).collect())
     }
 
+    /// The match stage of a job sharded by image over the GPUs of a node (one process and one `LocalFeaturesHip` per GPU;
+    /// BASELINE configs[3]): `desc_local` holds this rank's descriptors, image after image (`image_sizes` rows each);
+    /// the shards are all-gathered over RCCL -- the path's one collective -- and every local descriptor is matched against
+    /// the descriptors of all OTHER images (`match_features`' rule, ratio 0.8).  Returns (local row, global row) pairs;
+    /// global rows count through the ranks' shards in rank order.  `comm`: see `HipComm::new`.
+    pub fn cross_image_match(&mut self, comm: &HipComm, desc_local: &ArrayView2<f32>, image_sizes: &[usize])
+        -> Result<Vec<(usize, usize)>, Error>
+    {
+        assert_eq!(desc_local.ncols(), DESCRIPTOR_LEN);
+        assert_eq!(image_sizes.iter().sum::<usize>(), desc_local.nrows());
+        let local = desc_local.as_standard_layout();
+        let counts = comm.shard_counts(local.nrows() as u64)?;           // one u64 per rank, exchanged by the application
+        let base: u64 = counts[..comm.rank as usize].iter().sum();
+        let total: u64 = counts.iter().sum();
+        let (mut lo, mut hi) = (Vec::with_capacity(local.nrows()), Vec::with_capacity(local.nrows()));
+        let mut start = base as u32;
+        for &n in image_sizes {
+            for _ in 0..n { lo.push(start); hi.push(start + n as u32); }
+            start += n as u32;
+        }
+        let mut matches = vec![-1i32; local.nrows()];
+        // SAFETY: device buffers sized as declared; every rank makes the same collective call
+        unsafe {
+            let gathered = DeviceBuffer::<f32>::new(total as usize * DESCRIPTOR_LEN)?;
+            let own = gathered.as_mut_ptr().add(base as usize * DESCRIPTOR_LEN);
+            gathered.upload_at(own, local.as_slice().unwrap())?;
+            check(self.h, ffi::lf_mkd_allgather_descriptors(self.h, comm.c, counts.as_ptr(), gathered.as_mut_ptr(),
+                                                            ffi::LF_MKD_GATHER_DIRECT, std::ptr::null_mut()))?;
+            let (d_lo, d_hi) = (DeviceBuffer::from_slice(&lo)?, DeviceBuffer::from_slice(&hi)?);
+            let d_match = DeviceBuffer::<i32>::new(local.nrows())?;
+            check(self.h, ffi::lf_mkd_match_device(self.h, own, local.nrows() as u64, gathered.as_mut_ptr(), total,
+                                                   d_lo.as_ptr(), d_hi.as_ptr(), 0.8, d_match.as_mut_ptr(),
+                                                   std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut()))?;
+            check(self.h, ffi::lf_mkd_synchronize(self.h))?;
+            d_match.download(&mut matches)?;
+        }
+        Ok(matches.iter().enumerate().filter(|(_, j)| **j >= 0).map(|(i, j)| (i, *j as usize)).collect())
+    }
+
     fn image_dims(img: &ArrayView2<f32>) -> Result<(u32, u32), Error> {
         let width: u32 = img.ncols().try_into().map_err(|_| Error::BadArgument("image too wide".into()))?;
         let height: u32 = img.nrows().try_into().map_err(|_| Error::BadArgument("image too tall".into()))?;
@@ -259,6 +304,56 @@ impl LocalFeaturesHip {
             dropped_blobs: dropped_blobs as u32,
             dropped_features: dropped_features as u32,
         })
+    }
+}
+
+/// One rank's RCCL communicator for `cross_image_match`.  Rank 0 draws the identifier (`HipComm::unique_id`) and hands its
+/// 128 bytes to the other ranks by whatever channel the application has; every rank then calls `HipComm::new` with it.
+pub struct HipComm {
+    c: *mut ffi::lf_mkd_comm,
+    pub n_ranks: i32,
+    pub rank: i32,
+    /// how the application exchanges one u64 per rank (the shard sizes): e.g. over the channel that carried the identifier
+    exchange_counts: Box<dyn Fn(u64) -> Vec<u64>>,
+}
+
+impl HipComm {
+    pub fn unique_id() -> Result<[u8; ffi::LF_MKD_COMM_ID_BYTES], Error> {
+        let mut id = [0u8; ffi::LF_MKD_COMM_ID_BYTES];
+        // SAFETY: `id` has LF_MKD_COMM_ID_BYTES bytes
+        check(std::ptr::null(), unsafe { ffi::lf_mkd_comm_unique_id(id.as_mut_ptr()) })?;
+        Ok(id)
+    }
+
+    pub fn new(lf: &mut LocalFeaturesHip, id: &[u8; ffi::LF_MKD_COMM_ID_BYTES], n_ranks: i32, rank: i32,
+               exchange_counts: Box<dyn Fn(u64) -> Vec<u64>>) -> Result<Self, Error> {
+        let mut c = std::ptr::null_mut();
+        // SAFETY: collective over the ranks that share `id`
+        check(lf.h, unsafe { ffi::lf_mkd_comm_create(lf.h, id.as_ptr(), n_ranks, rank, &mut c) })?;
+        Ok(Self { c, n_ranks, rank, exchange_counts })
+    }
+
+    fn shard_counts(&self, mine: u64) -> Result<Vec<u64>, Error> {
+        let counts = (self.exchange_counts)(mine);
+        if counts.len() != self.n_ranks as usize || counts[self.rank as usize] != mine {
+            return Err(Error::BadArgument("exchange_counts must return one entry per rank, this rank's own included".into()));
+        }
+        Ok(counts)
+    }
+
+    /// (RCCL version code, ranks, this rank)
+    pub fn info(&self) -> Result<(i32, i32, i32), Error> {
+        let (mut v, mut n, mut r) = (0, 0, 0);
+        // SAFETY: plain out-pointers
+        check(std::ptr::null(), unsafe { ffi::lf_mkd_comm_info(self.c, &mut v, &mut n, &mut r) })?;
+        Ok((v, n, r))
+    }
+}
+
+impl Drop for HipComm {
+    fn drop(&mut self) {
+        // SAFETY: `c` came from lf_mkd_comm_create and is destroyed exactly once
+        unsafe { ffi::lf_mkd_comm_destroy(self.c); }
     }
 }
 

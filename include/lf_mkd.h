@@ -34,7 +34,8 @@ typedef enum {
     LF_MKD_ERR_HIP = -2,       /* a HIP runtime call failed; see lf_mkd_last_error         */
     LF_MKD_ERR_IO = -3,        /* cannot read / parse the PCA model file                   */
     LF_MKD_ERR_NO_IMAGE = -4,  /* describe_keypoints before set_image                      */
-    LF_MKD_ERR_NO_DEVICE = -5  /* no usable gfx950 device                                  */
+    LF_MKD_ERR_NO_DEVICE = -5, /* no usable gfx950 device                                  */
+    LF_MKD_ERR_COMM = -6       /* RCCL is not loadable, or one of its calls failed         */
 } lf_mkd_status;
 
 /* Which PCA model to load from a model directory: enum MKDPCA, lib.rs:26-32. */
@@ -276,6 +277,37 @@ int lf_mkd_match(lf_mkd *h, const float *a, uint64_t na, const float *b, uint64_
 /* Diagnostic: *n_rows = rows of a that the handle's latest match call had to redo by the full scan (0 in the ordinary
  * case).  Waits for that call to finish (synchronises `stream`, NULL = the handle's own). */
 int lf_mkd_match_overflowed(lf_mkd *h, void *stream, uint64_t *n_rows);
+
+/* ---- multi-GPU: the path's ONE collective (BASELINE configs[3]) -------------------------------------------------
+ * Keypoint batches shard by image, one process and one handle per GPU, and nothing is exchanged while describing.  The
+ * cross-image match stage needs every rank's descriptors on every rank: an all-gather of the descriptor shards over RCCL
+ * (xGMI).  The reference has no counterpart (one device, one queue: vulkan/make_a_vulkan.rs:80-115); the Rust crate calls
+ * these from LocalFeaturesHip::cross_image_match (bindings/rust/).  librccl is loaded when the first of these functions
+ * is called (dlopen: a process that has torch's copy loaded gets that one), so the library itself does not depend on it.
+ *
+ * lf_mkd_comm_unique_id   rank 0 draws the identifier (ncclGetUniqueId) and ships its LF_MKD_COMM_ID_BYTES to the other
+ *                         ranks by whatever channel the application has (a file, a socket, MPI, torch.distributed).
+ * lf_mkd_comm_create      every rank, with the same identifier: ncclCommInitRank on the handle's device.  Collective.
+ * lf_mkd_allgather_descriptors
+ *     d_buf   [sum(counts)][128] f32 on the handle's device: the gathered set, rank r's rows at offset sum(counts[0..r));
+ *             this rank's own rows are already in place (a producer that writes its descriptors straight there makes
+ *             the gather copy-free on the sending side too).
+ *     counts  [n_ranks] descriptors held by every rank (host array; shards may differ in size).
+ *     mode    LF_MKD_GATHER_DIRECT: one group of point-to-point transfers (ncclGroupStart .. ncclSend / ncclRecv to and from
+ *             every peer .. ncclGroupEnd): xGMI is a full point-to-point mesh, so a rank's n-1 sends leave on n-1 links at
+ *             once.  LF_MKD_GATHER_RING: one ncclAllGather (in place; needs equal shards, else DIRECT is used).
+ *     Asynchronous on `stream` (NULL: the handle's own).  Collective: every rank calls it with the same counts and mode.
+ * lf_mkd_comm_info        RCCL's version code, this communicator's size and rank (any pointer may be NULL). */
+#define LF_MKD_COMM_ID_BYTES 128
+#define LF_MKD_GATHER_DIRECT 0
+#define LF_MKD_GATHER_RING 1
+typedef struct lf_mkd_comm lf_mkd_comm;
+int lf_mkd_comm_unique_id(uint8_t *id);
+int lf_mkd_comm_create(lf_mkd *h, const uint8_t *id, int32_t n_ranks, int32_t rank, lf_mkd_comm **out);
+int lf_mkd_comm_destroy(lf_mkd_comm *c);
+int lf_mkd_comm_info(const lf_mkd_comm *c, int32_t *rccl_version, int32_t *n_ranks, int32_t *rank);
+int lf_mkd_allgather_descriptors(lf_mkd *h, lf_mkd_comm *c, const uint64_t *counts, float *d_buf, int32_t mode,
+                                 void *stream);
 
 /* The same stage on the reference's own buffer formats, for a caller that keeps the reference's detect graph and host
  * filter and swaps only the extract graph.  Host pointers; synchronous.

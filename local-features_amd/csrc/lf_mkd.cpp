@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "lf_mkd_internal.h"
 #include "mkd_consts.hpp"
 #include "mkd_device.h"
 
@@ -421,6 +422,10 @@ int orient_device(lf_mkd *h, const float *d_extrema, const uint32_t *d_frame_of,
 }
 
 }  // namespace
+
+int lf_mkd_internal_device(const lf_mkd *h) { return h->params.device; }
+hipStream_t lf_mkd_internal_stream(lf_mkd *h) { return h->stream; }
+int lf_mkd_internal_fail(lf_mkd *h, int code, const std::string &msg) { return fail(h, code, msg); }
 
 extern "C" {
 

@@ -57,7 +57,7 @@ constexpr int kRingSlots = 6;
 // patch rows at a time (a group), so it holds 12 rows: the 8 a describe wave reads while a group is being written + that
 // group.  Raw row r of the workgroup's it-th batch lives in slot (8 it + r) mod 12 (32 mod 12 = 8: the numbering simply
 // runs on across batches).  4 describe waves: kRingOff + 4 * 12 * 2048 = 159744 B, plus the level table.
-constexpr int kSrcPatches = 0, kSrcKeypoints = 1;
+[[maybe_unused]] constexpr int kSrcPatches = 0, kSrcKeypoints = 1;
 constexpr int kRingSlotsKp = 12;
 constexpr int kLevelTableBytes = 5 * kMaxPyrLevels * 4;
 

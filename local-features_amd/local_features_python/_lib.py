@@ -29,7 +29,10 @@ SYMBOLS = (
     "lf_mkd_detect_extrema", "lf_mkd_detect_extrema_device", "lf_mkd_filter_extrema_device", "lf_mkd_detect",
     "lf_mkd_match", "lf_mkd_match_device", "lf_mkd_match_overflowed", "lf_mkd_stream_create", "lf_mkd_stream_frame",
     "lf_mkd_detect_frames_device", "lf_mkd_orient_keypoints_blocked",
+    "lf_mkd_comm_unique_id", "lf_mkd_comm_create", "lf_mkd_comm_destroy", "lf_mkd_comm_info", "lf_mkd_allgather_descriptors",
 )
+COMM_ID_BYTES = 128
+GATHER_DIRECT, GATHER_RING = 0, 1
 
 
 class Params(ctypes.Structure):
@@ -109,10 +112,59 @@ def load_library():
     L.lf_mkd_detect_frames_device.argtypes = [vp, vp, u32, u32, u32, u32, ctypes.c_float, vp, vp, vp, u64, pu64, pu64,
                                               pu64, vp]
     L.lf_mkd_build_constants.argtypes = [vp] * 7
+    i32 = ctypes.c_int32
+    L.lf_mkd_comm_unique_id.argtypes = [vp]
+    L.lf_mkd_comm_create.argtypes = [vp, vp, i32, i32, ctypes.POINTER(vp)]
+    L.lf_mkd_comm_destroy.argtypes = [vp]
+    L.lf_mkd_comm_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.lf_mkd_allgather_descriptors.argtypes = [vp, vp, vp, vp, i32, vp]
     L.lf_mkd_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(u64)]
     _lib = L
     return L
+
+
+def comm_unique_id():
+    """Rank 0: the 128-byte RCCL identifier the other ranks need for Comm(...)."""
+    buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
+    rc = load_library().lf_mkd_comm_unique_id(buf)
+    if rc != 0:
+        raise RuntimeError(f"lf_mkd_comm_unique_id failed ({rc}): RCCL is not loadable")
+    return bytes(buf)
+
+
+class Comm:
+    """One rank's RCCL communicator on a handle's device (lf_mkd_comm_create): the all-gather of descriptor shards, the
+    path's one collective, through the C boundary."""
+
+    def __init__(self, handle, unique_id, n_ranks, rank):
+        self._c = None
+        self.handle, self.n_ranks, self.rank = handle, n_ranks, rank
+        c = ctypes.c_void_p()
+        ident = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        handle._check(handle.L.lf_mkd_comm_create(handle._h, ident, n_ranks, rank, ctypes.byref(c)), "lf_mkd_comm_create")
+        self._c = c
+
+    def info(self):
+        """(RCCL version code, ranks, this rank)"""
+        v, n, r = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        self.handle._check(self.handle.L.lf_mkd_comm_info(self._c, ctypes.byref(v), ctypes.byref(n), ctypes.byref(r)),
+                           "lf_mkd_comm_info")
+        return v.value, n.value, r.value
+
+    def allgather_descriptors(self, d_buf, counts, mode=GATHER_DIRECT, stream=None):
+        """d_buf: device pointer of the [sum(counts)][128] f32 gathered set, this rank's rows already at their offset."""
+        arr = (ctypes.c_uint64 * len(counts))(*[int(c) for c in counts])
+        self.handle._device_call(stream, lambda s: self.handle.L.lf_mkd_allgather_descriptors(
+            self.handle._h, self._c, arr, d_buf, mode, s), "lf_mkd_allgather_descriptors")
+
+    def close(self):
+        if self._c is not None:
+            self.handle.L.lf_mkd_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        self.close()
 
 
 class MkdHandle:

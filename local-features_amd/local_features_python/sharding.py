@@ -35,7 +35,17 @@ def gathered_buffer(counts, rank, width=128, device="cuda", dtype=torch.float32)
     return buf, buf[lo:lo + counts[rank]]
 
 
-def all_gather_descriptors(desc_local, group=None, mode="direct", out=None, counts=None):
+def make_comm(handle, group=None):
+    """An RCCL communicator of the C boundary (lf_mkd_comm_create) over the ranks of `group`: rank 0 draws the identifier,
+    torch.distributed -- whatever its backend -- only carries its 128 bytes to the others.  Collective."""
+    from ._lib import Comm, comm_unique_id
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return Comm(handle, box[0], world, rank)
+
+
+def all_gather_descriptors(desc_local, group=None, mode="direct", out=None, counts=None, comm=None):
     """[n_i,128] per rank -> ([sum n_i,128] on every rank, counts).  Every shard lands at its final place (rank order)
     in ONE buffer: no padding to the largest shard, no second copy.
 
@@ -45,7 +55,10 @@ def all_gather_descriptors(desc_local, group=None, mode="direct", out=None, coun
     mode "ring":   one all_gather_into_tensor (RCCL's ring: every byte crosses world-1 links in turn); needs equal
                    shards, falls back to "direct" otherwise.
     out / counts:  a buffer from gathered_buffer() whose own-rank view already holds desc_local (then nothing is copied
-                   locally); counts may be passed when the caller already knows them."""
+                   locally); counts may be passed when the caller already knows them.
+    comm:          a communicator from make_comm(): the gather then goes through the C boundary
+                   (lf_mkd_allgather_descriptors: grouped ncclSend / ncclRecv, or ncclAllGather) on torch's current stream --
+                   the same call the Rust crate makes; torch.distributed moves no descriptor."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if counts is None:
@@ -60,6 +73,18 @@ def all_gather_descriptors(desc_local, group=None, mode="direct", out=None, coun
     mine = out[offs[rank]:offs[rank + 1]]
     if mine.data_ptr() != desc_local.data_ptr() and counts[rank]:
         mine.copy_(desc_local)
+    if comm is not None:
+        if not out.is_cuda:
+            raise ValueError("the C-boundary gather moves device memory")
+        from ._lib import GATHER_DIRECT, GATHER_RING
+        if mode not in ("direct", "ring"):
+            raise ValueError(f"unknown all-gather mode {mode!r}")
+        s = torch.cuda.current_stream(out.device)
+        if s.cuda_stream == 0:          # the ABI reads handle 0 as the library's own stream: order the two by hand
+            s.synchronize()
+        comm.allgather_descriptors(out.data_ptr(), counts, GATHER_RING if mode == "ring" else GATHER_DIRECT,
+                                   s.cuda_stream or None)
+        return out, counts
     # gloo moves host memory only: a CUDA shard on a gloo group (the one-GPU rehearsal of bench.py) goes through the host
     via_host = out.is_cuda and dist.get_backend(group) == "gloo"
     buf = out.cpu() if via_host else out
@@ -99,7 +124,7 @@ def exclusion_ranges(image_sizes_local, base, device):
     return lo.to(device), hi.to(device)
 
 
-def cross_image_match(desc_local, image_sizes_local, match_fn, ratio=0.8, group=None, mode="direct", out=None):
+def cross_image_match(desc_local, image_sizes_local, match_fn, ratio=0.8, group=None, mode="direct", out=None, comm=None):
     """The match stage of BASELINE configs[3]: every rank holds the descriptors of its own images
     (desc_local [n_i,128], image_sizes_local = descriptors per image, in storage order); descriptor shards are
     all-gathered (the path's one collective), and each rank matches ITS descriptors against ALL descriptors
@@ -114,7 +139,7 @@ def cross_image_match(desc_local, image_sizes_local, match_fn, ratio=0.8, group=
     if sum(int(s) for s in image_sizes_local) != desc_local.shape[0]:
         raise ValueError("image_sizes_local must add up to the number of local descriptors")
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        gathered, counts = all_gather_descriptors(desc_local, group, mode=mode, out=out)
+        gathered, counts = all_gather_descriptors(desc_local, group, mode=mode, out=out, comm=comm)
     else:
         gathered, counts = desc_local, [desc_local.shape[0]]
     base = sum(counts[:rank])

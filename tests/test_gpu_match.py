@@ -291,3 +291,4 @@ def test_full_size_properties(lfp, torch, form):
     same = perm[m1] == m0
     # exact ties between two different candidates may resolve differently under another order; none are expected here
     assert int((~same).sum()) <= 2 and bool(torch.equal(s0, s1)) and bool(torch.equal(t0, t1))
+

@@ -18,7 +18,7 @@ HDR = os.path.join(ROOT, "include", "lf_mkd.h")
 FFI = os.path.join(ROOT, "bindings", "rust", "local_features", "src", "hip", "ffi.rs")
 MOD = os.path.join(ROOT, "bindings", "rust", "local_features", "src", "hip", "mod.rs")
 
-C_SCALARS = {"uint64_t": "u64", "uint32_t": "u32", "int32_t": "i32", "float": "f32", "double": "f64", "int": "c_int",
+C_SCALARS = {"uint64_t": "u64", "uint32_t": "u32", "int32_t": "i32", "uint8_t": "u8", "float": "f32", "double": "f64", "int": "c_int",
              "char": "c_char", "void": "c_void"}
 
 
@@ -149,7 +149,8 @@ STRUCTS = {
     "lf_mkd_extremum": ["x", "y", "size", "response"],
 }
 CONSTANTS = ["LF_MKD_OK", "LF_MKD_ERR_BAD_ARG", "LF_MKD_ERR_HIP", "LF_MKD_ERR_IO", "LF_MKD_ERR_NO_IMAGE",
-             "LF_MKD_ERR_NO_DEVICE", "LF_MKD_ANGLE_SHADER", "LF_MKD_ANGLE_EXACT", "LF_MKD_ANGLE_EXACT_ZERO",
+             "LF_MKD_ERR_NO_DEVICE", "LF_MKD_ERR_COMM", "LF_MKD_COMM_ID_BYTES", "LF_MKD_GATHER_DIRECT", "LF_MKD_GATHER_RING",
+             "LF_MKD_ANGLE_SHADER", "LF_MKD_ANGLE_EXACT", "LF_MKD_ANGLE_EXACT_ZERO",
              "LF_MKD_POOL_DEFAULT", "LF_MKD_POOL_F16X3", "LF_MKD_POOL_F32", "LF_MKD_FLAG_KERNEL_TIMING", "LF_MKD_FLAG_UNFUSED_KEYPOINTS",
              "LF_MKD_MAX_ANGLES_PER_EXTREMUM", "LF_MKD_PCA_LIBERTY", "LF_MKD_PCA_NOTREDAME", "LF_MKD_PCA_YOSEMITE",
              "LF_MKD_PATCH_SIZE", "LF_MKD_RAW_LEN", "LF_MKD_DESC_LEN"]
