@@ -195,22 +195,29 @@ def pipeline_extras(lfp, torch, device):
             for _ in range(2):
                 one()
             side.synchronize()
-            torch.cuda.synchronize()       # the library's second stream too
             e0.record(side)
             for _ in range(iters):
                 one()
             e1.record(side)
             side.synchronize()
             ms = e0.elapsed_time(e1) / iters
+            e0.record(side)                     # the describe launch alone (pyramid already built)
+            for _ in range(iters):
+                hnd.describe_keypoints_frames_device(kps.data_ptr(), fid.data_ptr(), n, o.data_ptr(), s)
+            e1.record(side)
+            side.synchronize()
+            ms_d = e0.elapsed_time(e1) / iters
             alg = n * (16 + 512) + nf * w * h * 4
             ach = alg / (ms * 1e-3) / 1e9
             out[f"keypoint_mode_{tag}"] = {
                 "ms_per_call": ms, "descriptors_per_s": n / (ms * 1e-3),
-                "what": "set_images (pyramid) + sample + describe of given keypoints, one call per batch",
+                "describe_only_ms": ms_d, "describe_only_descriptors_per_s": n / (ms_d * 1e-3),
+                "what": "set_images (pyramid) + describe of given keypoints (one launch: patches are sampled by producer waves "
+                        "of the describe kernel into its LDS ring), one call per batch; describe_only = that launch alone",
                 "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                              "traffic": kp_traffic.get(tag), "algorithmic_bytes_per_call": alg,
                              "algorithmic_bytes_per_descriptor": alg / n,
-                             "kernels": "pyr_* + sample_patches + mkd_pool (the patches cross HBM between the last two)"}}
+                             "kernels": "pyr_* + mkd_pool<.., keypoints> (no patch crosses HBM)"}}
             del hnd, imgs, kps, fid, o
         # patch mode at the keypoint counts of configs[1] and configs[2]: the same describe call, smaller n
         for n in (10000, 512000):
@@ -267,15 +274,68 @@ def launch_ranks(n, limit_s=None):
         return 124
 
 
+def planted_descriptors(torch, n, per_img, rank, world):
+    """Descriptors with cross-image correspondences for the match stage's second leg: image g (global index, per_img rows)
+    is random unit vectors, except that its first quarter is the second quarter of image g-1 perturbed at 1e-2 -- so every
+    such row has exactly one partner, in a neighbouring image, in either direction (half of all rows) -- and, on rank 0, a
+    block of near-duplicates of one vector that crowds the candidate rings of 3 x per_img / 2 query rows (they are redone
+    by the full-precision scan; all of it in rows that carry no planted correspondence).  Returns (descriptors [n,128], expected global match or -1 per row, crowded-row mask)."""
+    n_img = n // per_img
+    g_total = n_img * world
+    q = per_img // 4
+
+    def base(g):
+        gen = torch.Generator(device="cuda").manual_seed(1000 + g)
+        return torch.nn.functional.normalize(torch.randn((per_img, 128), device="cuda", generator=gen), dim=1)
+
+    out = torch.empty((n, 128), device="cuda")
+    want = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+    ar = torch.arange(q, device="cuda")
+    for j in range(n_img):
+        g = rank * n_img + j
+        d = base(g)
+        gen = torch.Generator(device="cuda").manual_seed(5000 + g)
+        d[:q] = torch.nn.functional.normalize(base((g - 1) % g_total)[q:2 * q]
+                                              + 1e-2 * torch.randn((q, 128), device="cuda", generator=gen) / 128 ** 0.5, dim=1)
+        out[j * per_img:(j + 1) * per_img] = d
+        want[j * per_img:j * per_img + q] = ((g - 1) % g_total) * per_img + q + ar           # partner in image g-1
+        want[j * per_img + q:j * per_img + 2 * q] = ((g + 1) % g_total) * per_img + ar         # partner in image g+1
+    crowded = torch.zeros((n,), dtype=torch.bool, device="cuda")
+    if rank == 0 and n_img >= 6:
+        gen = torch.Generator(device="cuda").manual_seed(77)
+        hub = torch.nn.functional.normalize(torch.randn((1, 128), device="cuda", generator=gen), dim=1)
+        cl = slice(per_img + 2 * q, per_img + 2 * q + 1024)                      # image 1: 1024 near-duplicates, contiguous
+        out[cl] = torch.nn.functional.normalize(hub + 2e-4 * torch.randn((1024, 128), device="cuda", generator=gen), dim=1)
+        crowded[cl] = True
+        for j in (3, 4, 5):         # 3 x 4096 = 12 288 queries next to the hub: the second halves (no planted rows) of three images
+            qs = slice(j * per_img + 2 * q, (j + 1) * per_img)
+            out[qs] = torch.nn.functional.normalize(hub + 1e-4 * torch.randn((2 * q, 128), device="cuda", generator=gen), dim=1)
+            crowded[qs] = True
+    return out, want, crowded
+
+
 def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehearsal, gathered, out, n):
     """configs[3] after the describe: descriptor shards -> all-gather -> cross-image brute-force match, once, timed.
     Every rank's `out` is already its own view of `gathered` (the describe wrote there), so the gather copies nothing
-    locally.  Images: --kpts-per-image descriptors each, in storage order; a query never matches its own image."""
+    locally.  Images: --kpts-per-image descriptors each, in storage order; a query never matches its own image.
+    Two legs: the descriptors the describe step just produced (uniform-random patches: nothing passes the ratio test --
+    the screening pass's best case) and descriptors with planted cross-image correspondences plus a crowded block."""
     per_img = max(2, min(args.kpts_per_image, n))
     sizes = [per_img] * (n // per_img) + ([n % per_img] if n % per_img else [])
     counts = [n] * world
-    res = {"ranks_seen": world, "descriptors_per_rank": n, "keypoints_per_image": per_img,
+    res = {"ranks_seen": world, "world_size": dist.get_world_size() if dist is not None else 1,
+           "descriptors_per_rank": n, "keypoints_per_image": per_img,
            "gathered_bytes": world * n * 512, "received_bytes_per_rank": (world - 1) * n * 512}
+    hm = lfp.MkdHandle(max_features=64, device=local_rank)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def per_rank(value):
+        """every rank's value, in rank order (a tiny object gather)"""
+        if dist is None:
+            return [value]
+        box = [None] * world
+        dist.all_gather_object(box, value)
+        return box
 
     def timed(fn):
         if dist is not None:
@@ -284,14 +344,28 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
         t0 = time.perf_counter()
         fn()
         torch.cuda.synchronize()
-        return sharding.max_over_ranks(time.perf_counter() - t0, "cpu" if rehearsal else "cuda") * 1e3
+        mine = (time.perf_counter() - t0) * 1e3
+        return sharding.max_over_ranks(mine / 1e3, "cpu" if rehearsal else "cuda") * 1e3, mine
 
+    comm = None
     if world > 1:
+        # the gather goes through the C boundary (lf_mkd_allgather_descriptors over RCCL: what the Rust crate calls);
+        # torch.distributed carries the 128-byte identifier only.  (Rehearsal on one GPU: gloo through the host.)
+        if not rehearsal:
+            try:
+                comm = sharding.make_comm(hm)
+                res["rccl_version"] = comm.info()[0]
+            except Exception as e:
+                res["comm_error"] = f"{type(e).__name__}: {e}"
+                comm = None
+        res["allgather_transport"] = "lf_mkd_allgather_descriptors (RCCL, C boundary)" if comm else "torch.distributed"
         for mode in ("direct", "ring"):
-            run = lambda: sharding.all_gather_descriptors(out, mode=mode, out=gathered, counts=counts)
+            run = lambda: sharding.all_gather_descriptors(out, mode=mode, out=gathered, counts=counts, comm=comm)
             run()                                                       # first call sets up the communicator's channels
-            res[f"allgather_{mode}_ms"] = min(timed(run) for _ in range(3))
-            res[f"allgather_{mode}_gbs_per_rank"] = res["received_bytes_per_rank"] / res[f"allgather_{mode}_ms"] / 1e6
+            best, mine = min(timed(run) for _ in range(3))
+            res[f"allgather_{mode}_ms"] = best
+            res[f"allgather_{mode}_ms_per_rank"] = per_rank(round(mine, 3))
+            res[f"allgather_{mode}_gbs_per_rank"] = res["received_bytes_per_rank"] / best / 1e6
         res["allgather_ms"] = min(res["allgather_direct_ms"], res["allgather_ring_ms"])
         # every shard must have arrived: row norms of the whole gathered set are 1
         nrm = gathered.norm(dim=1)
@@ -299,30 +373,74 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
             raise SystemExit("bench.py: gathered descriptors are not all unit norm (a shard did not arrive)")
     else:
         res["allgather_ms"] = 0.0
-    hm = lfp.MkdHandle(max_features=64, device=local_rank)
     lo, hi = sharding.exclusion_ranges(sizes, rank * n, "cuda")
     m = torch.empty((n,), dtype=torch.int32, device="cuda")
     best = torch.empty((n,), device="cuda")
-    s = torch.cuda.current_stream().cuda_stream
-    run = lambda: hm.match_device(out.data_ptr(), n, gathered.data_ptr(), world * n, m.data_ptr(), 0.8, lo.data_ptr(),
-                                  hi.data_ptr(), best.data_ptr(), None, s)
-    run()                                                               # warm: the first call allocates the scratch
-    res["match_ms"] = timed(run)
-    res["rows_redone_by_full_scan"] = int(hm.match_overflowed(s))
-    # the match stage is matrix-core work: one 128-long f16 dot product per pair in the screening pass
-    tf = 2.0 * 128 * float(n) * n * world / (res["match_ms"] * 1e-3) / 1e12          # per GPU
-    res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": tf / MFMA_F16_PEAK_TFLOPS, "flop_per_pair": 256, "traffic": None,
-                       "what": "per GPU, whole match call (split + screen + verify) on its clock"}
-    res["similarities_per_s"] = float(n) * n * world * world / (res["match_ms"] * 1e-3)
-    # accepted matches point outside the query's own image, and every best similarity is a valid cosine
-    acc = m >= 0
-    bad = acc & (m >= lo) & (m < hi)
-    if bool(bad.any().item()) or not bool((best.abs() <= 1.0 + 1e-4).all().item()):
-        raise SystemExit("bench.py: cross-image match returned a candidate inside the query's own image")
-    res["accepted_fraction"] = float(acc.float().mean().item())
+
+    def leg(tag, a, b_all):
+        run = lambda: hm.match_device(a.data_ptr(), n, b_all.data_ptr(), world * n, m.data_ptr(), 0.8, lo.data_ptr(),
+                                      hi.data_ptr(), best.data_ptr(), None, s)
+        run()                                                           # warm: the first call allocates the scratch
+        ms, mine = timed(run)
+        r = {"match_ms": ms, "match_ms_per_rank": per_rank(round(mine, 3)),
+             "rows_redone_by_full_scan": int(hm.match_overflowed(s))}
+        # the match stage is matrix-core work: one 128-long f16 dot product per pair in the screening pass
+        tf = 2.0 * 128 * float(n) * n * world / (ms * 1e-3) / 1e12          # per GPU
+        r["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / MFMA_F16_PEAK_TFLOPS, "flop_per_pair": 256, "traffic": None,
+                         "what": "per GPU, whole match call (split + screen + verify + redone rows) on its clock"}
+        r["similarities_per_s"] = float(n) * n * world * world / (ms * 1e-3)
+        # accepted matches point outside the query's own image, and every best similarity is a valid cosine
+        acc = m >= 0
+        bad = acc & (m >= lo) & (m < hi)
+        if bool(bad.any().item()) or not bool((best.abs() <= 1.0 + 1e-4).all().item()):
+            raise SystemExit(f"bench.py: cross-image match ({tag}) returned a candidate inside the query's own image")
+        r["accepted_fraction"] = float(acc.float().mean().item())
+        return r, acc
+
+    # leg 1: the descriptors of the timed describe steps.  Nothing passes ratio 0.8 there (accepted_fraction 0), so the
+    # exclusion rule is checked on a second call with ratio 0 -- every row then returns its best candidate -- and a few
+    # hundred rows of that call against a plain matrix product over the gathered set
+    r1, _ = leg("random", out, gathered)
+    hm.match_device(out.data_ptr(), n, gathered.data_ptr(), world * n, m.data_ptr(), 0.0, lo.data_ptr(), hi.data_ptr(),
+                    best.data_ptr(), None, s)
+    torch.cuda.synchronize()
+    if not bool((m >= 0).all().item()) or bool(((m >= lo) & (m < hi)).any().item()):
+        raise SystemExit("bench.py: with ratio 0 every row must return a candidate outside its own image")
+    pick = torch.arange(0, n, max(1, n // 64), device="cuda")[:64]
+    sim = out[pick] @ gathered.T
+    for i, row in enumerate(pick.tolist()):
+        sim[i, int(lo[row]):int(hi[row])] = -2.0
+    ref = sim.argmax(dim=1)
+    same = (ref == m[pick].long()) | ((sim.gather(1, m[pick].long()[:, None])[:, 0] - sim.max(dim=1).values).abs() < 2e-6)
+    if not bool(same.all().item()):
+        raise SystemExit("bench.py: the matcher's best candidate differs from a plain matrix product")
+    res.update(r1)
     res["what"] = ("each rank: its descriptors x the gathered set, own image excluded, ratio 0.8 "
-                   "(examples/match_images/src/main.rs:8-27); ms = slowest rank")
+                   "(examples/match_images/src/main.rs:8-27); ms = slowest rank; best candidates checked at ratio 0")
+    # leg 2: planted correspondences and a crowded block (gathered the same way)
+    if n % per_img == 0 and n // per_img >= 6:
+        mine_p, want, crowded = planted_descriptors(torch, n, per_img, rank, world)
+        gathered_p, view = sharding.gathered_buffer([n] * world, rank)
+        view.copy_(mine_p)
+        del mine_p
+        if world > 1:
+            sharding.all_gather_descriptors(view, mode="direct", out=gathered_p, counts=counts, comm=comm)
+        r2, acc = leg("planted", view, gathered_p)
+        planted = want >= 0
+        hit = (m.long() == want) & planted
+        r2["planted_rows_fraction"] = float(planted.float().mean().item())
+        r2["planted_rows_recovered"] = float(hit.sum().item()) / max(1.0, float(planted.sum().item()))
+        r2["crowded_query_rows"] = int(crowded.sum().item())
+        r2["what"] = ("image g's first quarter = image g-1's second quarter perturbed at 1e-2 (one partner per planted row, "
+                      "either direction); rank 0 also holds 1024 near-duplicates of one vector and 12 288 queries next to it, "
+                      "whose candidate rings overflow: those rows are redone by the full-precision scan")
+        if r2["planted_rows_recovered"] < 0.999:
+            raise SystemExit(f"bench.py: only {r2['planted_rows_recovered']:.4f} of the planted correspondences were matched")
+        res["planted"] = r2
+        del gathered_p, view
+    if comm is not None:
+        comm.close()
     return res
 
 
@@ -421,6 +539,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     pool_ms, whiten_ms, launches = h.kernel_times()
+    clock_mhz, wg0_ms = h.kernel_clock(stream)     # stamps of the last timed launch's workgroup 0
     dt = sharding.max_over_ranks(dt, "cpu" if rehearsal else "cuda")
 
     # secondary figure: the same workload with the exact gradient direction (plus the shader's angle 0 at gx == 0)
@@ -466,7 +585,7 @@ def main():
         achieved = BYTES_PER_DESC * n / kern_s / 1e9 if kern_s > 0 else 0.0
         # HBM traffic of the kernel comes from rocprofv3 PMC passes (tools/profile_round.sh), which cannot run inside
         # this process: the committed figure is quoted only if it was measured on this very kernel source and workload
-        traffic = None
+        traffic = mfma_busy = projection = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
@@ -474,6 +593,8 @@ def main():
                 if (tj.get("patches") == n and tj.get("pool") == args.pool and tj.get("angle") == args.angle
                         and tj.get("source_sha256") == source_stamp()):
                     traffic = tj.get("hbm_bytes_per_launch")
+                    mfma_busy = tj.get("mfma_busy_frac")          # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles)
+                    projection = tj.get("projection")             # the whitening stage on its own (phase clocks)
             except Exception:
                 traffic = None
         line = {
@@ -492,6 +613,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mkd_pool", "kernel_ms": kern_s * 1e3,
                          "algorithmic_bytes_per_launch": BYTES_PER_DESC * n,
+                         # the clock the chip held under this very kernel (in-kernel stamps: shader-clock counter over the
+                         # constant 100 MHz counter; MI355X_MICROARCH.md DVFS give-back) -- boxes differ by several per cent
+                         "shader_clock_mhz": clock_mhz, "workgroup0_ms": wg0_ms,
+                         "mfma_busy_frac": mfma_busy, "projection": projection,
                          # beside it, the arithmetic view (informative): the path's f32 arithmetic is a
                          # [n x 1024] x [1024 x 238] pooling product + the 238 x 128 whitening; the matrix cores have no
                          # f32-input rate above 157.3 TFLOP/s (MI355X_MICROARCH.md), the kernel buys its rate with f16 splits

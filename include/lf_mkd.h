@@ -352,6 +352,12 @@ int lf_mkd_build_constants(const float *mean, const float *eigvals, const float 
  * be NULL. */
 int lf_mkd_kernel_times(lf_mkd *h, double *pool_ms, double *whiten_ms, uint64_t *launches);
 
+/* With LF_MKD_FLAG_KERNEL_TIMING: the shader clock the chip sustained during the handle's latest describe launch, from
+ * stamps workgroup 0 of the kernel leaves on entry and exit (shader-clock counter / constant 100 MHz counter), and that
+ * workgroup's lifetime in ms.  The chip lowers its clock under load, box by box: this is what makes two boxes' figures
+ * comparable.  Waits for `stream` (NULL: the handle's own).  Either output pointer may be NULL. */
+int lf_mkd_kernel_clock(lf_mkd *h, void *stream, double *shader_mhz, double *kernel_ms);
+
 /* Blocks until everything enqueued on the handle's own stream has finished. */
 int lf_mkd_synchronize(lf_mkd *h);
 

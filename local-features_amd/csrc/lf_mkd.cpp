@@ -44,6 +44,7 @@ struct lf_mkd {
     unsigned *d_counts = nullptr, *d_orient_sums = nullptr;
     uint64_t kps_out_cap = 0;
     unsigned long long *d_totals = nullptr;
+    unsigned long long *d_clk = nullptr;       // LF_MKD_FLAG_KERNEL_TIMING: clock stamps of the latest describe launch
     // detector scratch (allocated on first use): per-cube slots and counts for max_frames frames of the maximum size
     uint64_t max_extrema = 8192;
     float *d_slots = nullptr, *d_det_extrema = nullptr, *d_det_selected = nullptr, *d_det_desc = nullptr;
@@ -192,6 +193,10 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     // (the staging buffers of the host-pointer and keypoint entry points -- 4.6 KiB per descriptor of the internal batch --
     // are allocated on first use: a caller of the device-pointer patch API never needs them)
     LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_totals), 8 * sizeof(unsigned long long)));
+    if (h->params.flags & LF_MKD_FLAG_KERNEL_TIMING) {
+        LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_clk), 4 * sizeof(unsigned long long)));
+        LF_CREATE_HIP(hipMemset(h->d_clk, 0, 4 * sizeof(unsigned long long)));
+    }
     if (params->max_image_width && params->max_image_height) {
         // the sampler addresses a pyramid level with 32-bit byte offsets from its first texel
         if (uint64_t(params->max_image_width) * params->max_image_height >= (1ull << 30) ||
@@ -260,7 +265,7 @@ int ensure_side_stream(lf_mkd *h, size_t events) {
 int run_batch(lf_mkd *h, const float *d_patches, uint64_t n, float *d_out, float *d_raw, hipStream_t s, int waves = 0) {
     if (int rc = mark(h, s)) return rc;
     launch_describe(d_patches, long(n), nullptr, h->dc, h->params.angle_mode, h->params.pool_mode, d_out ? d_out : h->d_out,
-                    d_raw, h->num_cus, s, waves);
+                    d_raw, h->num_cus, s, waves, h->d_clk);
     LF_HIP(h, hipGetLastError());
     if (int rc = mark(h, s)) return rc;
     return LF_MKD_OK;
@@ -277,7 +282,7 @@ int describe_keypoints_on_device(lf_mkd *h, const float *d_kps, const uint32_t *
     if (fused_keypoints(h)) {
         if (int rc = mark(h, s)) return rc;
         launch_describe_keypoints(h->d_pyr, h->pyr_stride, h->pd, d_kps, d_frame_of, long(n), nullptr,
-                                  h->params.patch_scale_factor, h->dc, h->params.angle_mode, d_out, h->num_cus, s);
+                                  h->params.patch_scale_factor, h->dc, h->params.angle_mode, d_out, h->num_cus, s, h->d_clk);
         LF_HIP(h, hipGetLastError());
         return mark(h, s);
     }
@@ -476,7 +481,7 @@ void lf_mkd_destroy(lf_mkd *h) {
     void *ptrs[] = {h->dc.colmap,     h->dc.pool_b_f32, h->dc.pool_b_f16, h->dc.white_a_f16,
                     h->dc.white_a_f32, h->dc.white_bias, h->d_patches,     h->d_out,         h->d_kps,
                     h->d_image,        h->d_pyr,         h->d_tmp_a,       h->d_tmp_b,       h->d_coarse,
-                    h->d_extrema,      h->d_angles,      h->d_counts,      h->d_kps_out,     h->d_totals,
+                    h->d_extrema,      h->d_angles,      h->d_counts,      h->d_kps_out,     h->d_totals,      h->d_clk,
                     h->d_slots,        h->d_det_extrema, h->d_det_selected, h->d_det_desc,
                     h->d_cube_counts,  h->d_cube_sums,   h->d_sel_count,   h->d_match_a,     h->d_match_b,
                     h->d_orient_sums,  h->d_topk_work,
@@ -515,6 +520,24 @@ int lf_mkd_kernel_times(lf_mkd *h, double *pool_ms, double *whiten_ms, uint64_t 
     if (pool_ms) *pool_ms = tp;
     if (whiten_ms) *whiten_ms = tw;
     if (launches) *launches = nb;
+    return LF_MKD_OK;
+}
+
+int lf_mkd_kernel_clock(lf_mkd *h, void *stream, double *shader_mhz, double *kernel_ms) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (shader_mhz) *shader_mhz = 0;
+    if (kernel_ms) *kernel_ms = 0;
+    if (!h->d_clk) return fail(h, LF_MKD_ERR_BAD_ARG, "kernel_clock: the handle was not created with LF_MKD_FLAG_KERNEL_TIMING");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    unsigned long long c[4] = {0, 0, 0, 0};
+    LF_HIP(h, hipMemcpyAsync(c, h->d_clk, sizeof(c), hipMemcpyDeviceToHost, s));
+    LF_HIP(h, hipStreamSynchronize(s));
+    if (c[3] > c[1] && c[2] > c[0]) {
+        const double ticks = double(c[3] - c[1]);            // s_memrealtime: 100 MHz
+        if (shader_mhz) *shader_mhz = double(c[2] - c[0]) / ticks * 100.0;
+        if (kernel_ms) *kernel_ms = ticks / 1e5;
+    }
     return LF_MKD_OK;
 }
 

@@ -924,8 +924,15 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
     const float *__restrict__ patches, long n_host, const unsigned long long *__restrict__ n_dev,
     const unsigned char *__restrict__ lut_rows, const short *__restrict__ colmap, const unsigned char *__restrict__ wfrag,
     const float *__restrict__ bias, float *__restrict__ out, float *__restrict__ raw_out,
-    std::conditional_t<SRC == kSrcKeypoints, KpSource, int> ks) {
+    std::conditional_t<SRC == kSrcKeypoints, KpSource, int> ks, unsigned long long *__restrict__ clk) {
     constexpr bool kKp = SRC == kSrcKeypoints;
+    // clk (LF_MKD_FLAG_KERNEL_TIMING, else null): workgroup 0 stamps the shader clock (s_memtime) and the constant 100 MHz
+    // clock (s_memrealtime) on entry and on exit -- the clock the chip sustained under THIS launch is their quotient
+    // (MI355X_MICROARCH.md, DVFS give-back); the values go to a buffer nothing else reads
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = __builtin_readcyclecounter();
+        clk[1] = __builtin_amdgcn_s_memrealtime();
+    }
     constexpr int kSlots = kKp ? kRingSlotsKp : kRingSlots;
     static_assert(!kKp || POOL == LF_POOL_F16X3, "keypoint mode pools in f16x3");
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kRingOff + W * kSlots * 2048 +
@@ -1159,6 +1166,10 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
     if (blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < 8; ++i) out[wave * 128 + i] = (float)phase_clk[i];
 #endif
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[2] = __builtin_readcyclecounter();
+        clk[3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1171,7 +1182,8 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
 #ifndef LF_DESCRIBE_KP
 // n_dev != nullptr: the patch count is read on the device (<= n, which then only sizes the grid)
 void launch_describe(const float *patches, long n, const unsigned long long *n_dev, const DeviceConsts &dc,
-                     int angle_mode, int pool_mode, float *out, float *raw_out, int num_cus, hipStream_t stream, int waves) {
+                     int angle_mode, int pool_mode, float *out, float *raw_out, int num_cus, hipStream_t stream, int waves,
+                     unsigned long long *clk) {
     if (n <= 0) return;
     // one 100-152 KiB-LDS workgroup per CU; requests of at most one round of 64-patch workgroups take the 4-wave form
 #ifdef LF_ABLATE_FORCE_W4   // timing-only build: the 4-wave form at every size
@@ -1188,7 +1200,7 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
                                   : reinterpret_cast<const unsigned char *>(dc.white_a_f32);
 #define LF_LAUNCH_W(A, P, WV)                                                                                          \
     hipLaunchKernelGGL((mkd_pool<A, P, WV, kSrcPatches>), dim3(grid), dim3(64 * WV), 0, stream, patches, n, n_dev, lut, \
-                       dc.colmap, wf, dc.white_bias, out, raw_out, 0)
+                       dc.colmap, wf, dc.white_bias, out, raw_out, 0, clk)
 #define LF_LAUNCH(A, P)            \
     do {                           \
         if (small) LF_LAUNCH_W(A, P, 4); \
@@ -1212,7 +1224,8 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
 // per CU (160 KB of LDS), persistent.
 void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                                const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
-                               const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream) {
+                               const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream,
+                               unsigned long long *clk) {
     if (n <= 0) return;
     const long nbatch = (n + 63) / 64;
     const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);
@@ -1222,7 +1235,7 @@ void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidD
     ks.pyr = pyr; ks.pyr_stride = pyr_stride; ks.kps = kps; ks.frame_of = frame_of_kp; ks.psf = psf; ks.pd = pd;
 #define LF_LAUNCH_KP(A)                                                                                                \
     hipLaunchKernelGGL((mkd_pool<A, LF_POOL_F16X3, 4, kSrcKeypoints>), dim3(grid), dim3(512), 0, stream,                \
-                       (const float *)nullptr, n, n_dev, lut, dc.colmap, wf, dc.white_bias, out, (float *)nullptr, ks)
+                       (const float *)nullptr, n, n_dev, lut, dc.colmap, wf, dc.white_bias, out, (float *)nullptr, ks, clk)
     if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH_KP(LF_ANGLE_EXACT);
     else if (angle_mode == LF_ANGLE_EXACT_ZERO) LF_LAUNCH_KP(LF_ANGLE_EXACT_ZERO);
     else LF_LAUNCH_KP(LF_ANGLE_SHADER);

@@ -45,7 +45,8 @@ struct DeviceConsts {
 // waves: 0 = choose by size (4-wave workgroups when the request fits one round of them, else 8-wave), 4 / 8 = that form
 void launch_describe(const float *patches, long n, const unsigned long long *n_dev, const DeviceConsts &dc,
                      int angle_mode, int pool_mode, float *out, float *raw_out, int num_cus, hipStream_t stream,
-                     int waves = 0);
+                     int waves = 0, unsigned long long *clk = nullptr);
+// clk (nullable, device, 4 words): workgroup 0 leaves (shader clock, 100 MHz clock) on entry and on exit
 // frame_of_kp == nullptr: every keypoint belongs to frame 0
 void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                            const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
@@ -54,7 +55,8 @@ void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc 
 // straight into its LDS row ring and never touch HBM.  f16x3 pooling only.
 void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                                const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
-                               const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream);
+                               const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream,
+                               unsigned long long *clk = nullptr);
 // rest_stream (nullable): levels >= 1 are built there -- after `fork`, recorded on `stream` once level 0 and a-trous layer 1
 // exist -- and `join` is recorded behind them; the caller waits for `join` before it samples patches
 void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,

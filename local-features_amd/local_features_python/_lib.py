@@ -24,7 +24,7 @@ SYMBOLS = (
     "lf_mkd_describe_keypoints_frames_device",
     "lf_mkd_describe_keypoints_device", "lf_mkd_sample_patches_device", "lf_mkd_get_pyramid_level",
     "lf_mkd_get_pyramid_level_apron",
-    "lf_mkd_build_constants", "lf_mkd_kernel_times", "lf_mkd_synchronize", "lf_mkd_version",
+    "lf_mkd_build_constants", "lf_mkd_kernel_times", "lf_mkd_kernel_clock", "lf_mkd_synchronize", "lf_mkd_version",
     "lf_mkd_orient_keypoints", "lf_mkd_orient_keypoints_device", "lf_mkd_get_coarse_layer",
     "lf_mkd_detect_extrema", "lf_mkd_detect_extrema_device", "lf_mkd_filter_extrema_device", "lf_mkd_detect",
     "lf_mkd_match", "lf_mkd_match_device", "lf_mkd_match_overflowed", "lf_mkd_stream_create", "lf_mkd_stream_frame",
@@ -93,6 +93,7 @@ def load_library():
     L.lf_mkd_sample_patches_device.argtypes = [vp, vp, u64, vp, vp]
     L.lf_mkd_get_pyramid_level.argtypes = [vp, u32, vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.lf_mkd_get_pyramid_level_apron.argtypes = [vp, u32, vp, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.lf_mkd_kernel_clock.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.lf_mkd_synchronize.argtypes = [vp]
     L.lf_mkd_orient_keypoints.argtypes = [vp, vp, u64, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     L.lf_mkd_orient_keypoints_device.argtypes = [vp, vp, vp, u64, vp, vp, u64, ctypes.POINTER(u64),
@@ -408,6 +409,12 @@ class MkdHandle:
         self._check(self.L.lf_mkd_kernel_times(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)),
                     "lf_mkd_kernel_times")
         return a.value, b.value, n.value
+
+    def kernel_clock(self, stream=None):
+        """(shader MHz sustained during the latest describe launch, lifetime of its workgroup 0 in ms); FLAG_KERNEL_TIMING."""
+        mhz, ms = ctypes.c_double(), ctypes.c_double()
+        self._check(self.L.lf_mkd_kernel_clock(self._h, stream, ctypes.byref(mhz), ctypes.byref(ms)), "lf_mkd_kernel_clock")
+        return mhz.value, ms.value
 
     def synchronize(self):
         self._check(self.L.lf_mkd_synchronize(self._h), "lf_mkd_synchronize")

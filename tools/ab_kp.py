@@ -29,7 +29,7 @@ for tag, w, h, nk, nf, iters in (("configs2", 640, 480, 2000, 256, 10), ("config
     hnd = lfp.MkdHandle(max_features=n, max_image_width=w, max_image_height=h, max_frames=nf,
                         flags=int(os.environ.get("LF_KP_FLAGS", "0")))
     imgs = frames(nf, h, w, 11)
-    base = [np.concatenate([random_keypoints(nk, w, h, 200 + f, margin=64.0 if nf == 1 else 8.0), np.zeros((nk, 1), np.float32)],
+    base = [np.concatenate([random_keypoints(nk, w, h, 200 + f, margin=float(os.environ.get("LF_KP_MARGIN", "64" if nf == 1 else "8"))), np.zeros((nk, 1), np.float32)],
                            axis=1) for f in range(min(nf, 8))]
     kps = torch.from_numpy(np.concatenate([base[f % len(base)] for f in range(nf)]).astype(np.float32)).cuda()
     fid = torch.arange(nf, device="cuda", dtype=torch.int32).repeat_interleave(nk).contiguous()
