@@ -109,14 +109,14 @@ long pyramid_levels(uint32_t w, uint32_t h) {  // mod.rs:271-277,372-373
     return std::lround(std::ceil(std::log2(float(std::min(w, h)))));
 }
 
-// returns the floats one frame's pyramid occupies (level 0 dense, levels >= 1 with their mirrored apron: mkd_device.h)
+// returns the floats one frame's pyramid occupies (every level with its mirrored apron: mkd_device.h)
 long describe_pyramid(uint32_t w, uint32_t h, PyramidDesc &pd) {
     pd.levels = int(std::min<long>(std::max<long>(pyramid_levels(w, h), 1), kMaxPyrLevels));
     long off = 0;
     for (int l = 0; l < pd.levels; ++l) {
         pd.w[l] = std::max<int>(int(w >> l), 1);
         pd.h[l] = std::max<int>(int(h >> l), 1);
-        pd.apron[l] = l == 0 ? 0 : kPyrApron;
+        pd.apron[l] = kPyrApron;
         pd.pitch[l] = pd.w[l] + 2 * pd.apron[l];
         pd.offset[l] = off + long(pd.apron[l]) * pd.pitch[l] + pd.apron[l];
         off += long(pd.pitch[l]) * (pd.h[l] + 2 * pd.apron[l]);
@@ -315,7 +315,7 @@ int ensure_coarse_stack(lf_mkd *h, hipStream_t s) {
         h->coarse_stride = h->layer_stride * (h->n_layers - 1);
         LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_coarse), size_t(h->coarse_stride) * h->max_frames * 4));
     }
-    launch_build_coarse_stack(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride,
+    launch_build_coarse_stack(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride,
                               h->d_tmp_a, h->n_layers, h->coarse_l1_valid ? 1 : 0, h->pd.w[0], h->pd.h[0],
                               int(h->n_frames), s);
     LF_HIP(h, hipGetLastError());
@@ -375,7 +375,7 @@ int detect_extrema_device(lf_mkd *h, float *d_out, uint32_t *d_frame_of, uint64_
                           uint64_t *n_dropped, hipStream_t s) {
     if (int rc = ensure_coarse_stack(h, s)) return rc;
     if (int rc = ensure_detect_scratch(h)) return rc;
-    launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride,
+    launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride,
                           h->n_layers, h->pd.w[0], h->pd.h[0], int(h->n_frames), kBorder, kSkipLayers, kContrastThreshold,
                           h->d_slots, h->d_cube_counts, h->d_cube_sums, d_out, d_frame_of, nullptr, max_out, h->d_totals,
                           s);
@@ -414,7 +414,7 @@ int grow_topk_work(lf_mkd *h, uint64_t n_cap, hipStream_t s) {
 int orient_device(lf_mkd *h, const float *d_extrema, const uint32_t *d_frame_of, uint64_t n, float *d_out,
                   uint32_t *d_frame_of_kp, uint64_t max_out, uint64_t *n_out, uint64_t *n_dropped, hipStream_t s) {
     if (int rc = ensure_coarse_stack(h, s)) return rc;
-    launch_orient(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride, h->n_layers,
+    launch_orient(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride, h->n_layers,
                   h->pd.w[0], h->pd.h[0], d_extrema, d_frame_of, long(n), nullptr, h->d_angles, h->d_counts,
                   h->d_orient_sums, d_out, d_frame_of_kp, max_out, h->d_totals, s);
     LF_HIP(h, hipGetLastError());
@@ -860,7 +860,7 @@ int lf_mkd_detect_frames_device(lf_mkd *h, const float *d_images, uint32_t n_fra
     if (int rc = grow(h, &h->d_mf_list, &h->mf_list_cap, keep * n_frames, sizeof(lf_mkd_extremum))) return rc;
     if (int rc = grow(h, &h->d_mf_frame_of, &h->mf_fo_cap, keep * n_frames, 4)) return rc;
     // 1. every frame's extrema, ordered by frame; 2. per-frame selection; 3. one contiguous list + frame ids
-    launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride,
+    launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride,
                           h->n_layers, int(width), int(height), int(n_frames), kBorder, kSkipLayers, kContrastThreshold,
                           h->d_slots, h->d_cube_counts, h->d_cube_sums, h->d_det_extrema, nullptr, h->d_mf_frame_start,
                           all_cap, h->d_totals + 0, s);
@@ -934,9 +934,9 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
     launch_build_pyramid(d_image, long(width) * height, h->d_pyr, h->pyr_stride, h->d_tmp_a, h->d_tmp_b, h->pd, 1,
                          h->pd.levels >= 2 ? h->d_coarse : nullptr, h->coarse_stride, s, fork ? h->side_stream : nullptr,
                          fork ? h->side_events[0] : nullptr, fork ? h->side_events[1] : nullptr);
-    launch_build_coarse_stack(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride,
+    launch_build_coarse_stack(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride,
                               h->d_tmp_a, h->n_layers, h->pd.levels >= 2 ? 1 : 0, int(width), int(height), 1, s);
-    launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride,
+    launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride,
                           h->n_layers, int(width), int(height), 1, kBorder, kSkipLayers, kContrastThreshold, h->d_slots,
                           h->d_cube_counts, h->d_cube_sums, h->d_det_extrema, nullptr, nullptr, h->max_extrema, cnt + 0, s);
     const float *d_sel = h->d_det_extrema;
@@ -947,7 +947,7 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
         d_sel = h->d_det_selected;
         n_sel = cnt + 2;
     }
-    launch_orient(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->d_coarse, h->coarse_stride, h->layer_stride, h->n_layers,
+    launch_orient(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride, h->n_layers,
                   int(width), int(height), d_sel, nullptr, long(cap), n_sel, h->d_angles, h->d_counts, h->d_orient_sums,
                   reinterpret_cast<float *>(d_keypoints), nullptr, max_out, cnt + 3, s);
     // (the join costs ~12 us of queue latency wherever it stands, measured; the branch saves ~40)
@@ -1135,7 +1135,9 @@ int lf_mkd_get_coarse_layer(lf_mkd *h, uint32_t layer, float *out) {
     if (int rc = ensure_coarse_stack(h, h->stream)) return rc;
     LF_HIP(h, hipStreamSynchronize(h->stream));
     const float *src = layer == 0 ? h->d_pyr + h->pd.offset[0] : h->d_coarse + long(layer - 1) * h->layer_stride;
-    LF_HIP(h, hipMemcpy(out, src, size_t(h->pd.w[0]) * h->pd.h[0] * 4, hipMemcpyDeviceToHost));
+    const size_t spitch = size_t(layer == 0 ? h->pd.pitch[0] : h->pd.w[0]) * 4;
+    LF_HIP(h, hipMemcpy2D(out, size_t(h->pd.w[0]) * 4, src, spitch, size_t(h->pd.w[0]) * 4, size_t(h->pd.h[0]),
+                          hipMemcpyDeviceToHost));
     return LF_MKD_OK;
 }
 

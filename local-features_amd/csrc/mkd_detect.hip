@@ -22,7 +22,7 @@ namespace lfmkd {
 constexpr int kScanTX = 32, kScanTY = 8, kScanMaxFine = 8;
 constexpr int kScanRowLen = kScanTX + 2, kScanPlane = (kScanTY + 2) * kScanRowLen;
 
-__global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ layer0, long layer0_stride,
+__global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ layer0, long layer0_stride, int layer0_pitch,
                                                     const float *__restrict__ coarse, long coarse_stride,
                                                     long layer_stride, int n_fine, int w, int h, int border,
                                                     int skip_layers, float contrast_threshold, int gx, int gy, int gz,
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
         const bool in = x >= 0 && x < w && y >= 0 && y < h;
         const size_t o = in ? (size_t)y * w + x : 0;
         float c[kScanMaxFine + 1];   // all layers of this texel requested at once
-        c[0] = in ? l0[o] : 0.f;
+        c[0] = in ? l0[(size_t)y * layer0_pitch + x] : 0.f;   // layer 0 = pyramid level 0, stored with its apron
 #pragma unroll
         for (int z = 0; z < kScanMaxFine; ++z) c[z + 1] = (in && z < n_fine) ? cs[(size_t)z * layer_stride + o] : 0.f;
 #pragma unroll
@@ -546,7 +546,7 @@ void scan_grid(int w, int h, int n_fine, int border, int skip_layers, int &gx, i
 }
 
 // a-trous stack -> ordered extrema of `frames` frames.  slots/counts/sums are scratch sized for frames x cubes.
-void launch_detect_extrema(const float *layer0, long layer0_stride, const float *coarse, long coarse_stride,
+void launch_detect_extrema(const float *layer0, long layer0_stride, int layer0_pitch, const float *coarse, long coarse_stride,
                            long layer_stride, int n_layers, int w, int h, int frames, int border, int skip_layers,
                            float contrast_threshold, float *slots, unsigned *counts, unsigned *sums, float *extrema,
                            unsigned *frame_of, unsigned *frame_start, unsigned long long max_out,
@@ -558,7 +558,7 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, const float 
     if (ncubes > 0) {
         hipLaunchKernelGGL(scan_extrema, dim3((gx + kScanTX / 4 - 1) / (kScanTX / 4), (gy + kScanTY / 4 - 1) / (kScanTY / 4), frames),
                            dim3(256), 0, stream, layer0,
-                           layer0_stride, coarse, coarse_stride, layer_stride, n_layers - 1, w, h, border, skip_layers,
+                           layer0_stride, layer0_pitch, coarse, coarse_stride, layer_stride, n_layers - 1, w, h, border, skip_layers,
                            contrast_threshold, gx, gy, gz, slots, counts);
         hipLaunchKernelGGL(cubes_block_sums, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts, n, sums);
     }

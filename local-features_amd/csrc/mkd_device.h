@@ -17,16 +17,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxPyrLevels = 16;
 
 // Patch pyramid: levels packed back to back in one allocation; level l is w[l] x h[l] f32, rows pitch[l] floats apart.
-// Level 0 is dense (pitch = w: the detector and the orientation stage read it as a-trous layer 0).  Levels >= 1, which
-// only the patch sampler reads, carry an APRON of kPyrApron texels on every side, filled with the level's own texels under
-// MirroredRepeat (mod.rs:940-943): a keypoint whose centre lies inside its level reaches at most 22.7 rem + 2 < 48 texels
-// from it (rem < 2), so its whole footprint is addressed without any mirror arithmetic.  offset[l] is texel (0, 0).
+// Every level carries an APRON of kPyrApron texels on every side, filled with the level's own texels under MirroredRepeat
+// (mod.rs:940-943): a keypoint whose centre lies inside its level reaches at most 22.7 rem + 2 < 48 texels from it
+// (rem < 2), so its whole footprint is addressed without any mirror arithmetic.  offset[l] is texel (0, 0).  (Level 0 is also
+// a-trous layer 0 of the detector and the orientation stage: they read it with its pitch.)
 constexpr int kPyrApron = 48;
 struct PyramidDesc {
     int levels;
     int w[kMaxPyrLevels], h[kMaxPyrLevels];
     int pitch[kMaxPyrLevels];    // floats between rows
-    int apron[kMaxPyrLevels];    // mirrored texels around the level (0 for level 0)
+    int apron[kMaxPyrLevels];    // mirrored texels around the level
     long offset[kMaxPyrLevels];  // in floats, of texel (0, 0)
 };
 
@@ -65,13 +65,13 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
                           hipEvent_t join = nullptr);
 
 // a-trous layers 1 .. n_layers-1 over layer0 (= pyramid level 0); tmp holds frames x w x h floats
-void launch_build_coarse_stack(const float *layer0, long layer0_stride, float *coarse, long coarse_stride,
+void launch_build_coarse_stack(const float *layer0, long layer0_stride, int layer0_pitch, float *coarse, long coarse_stride,
                                long layer_stride, float *tmp, int n_layers, int first_layer, int w, int h, int frames,
                                hipStream_t stream);
 // extrema [n][4] -> kps [<= max_out][5] ordered by extremum then bin; angles [n][18], counts [n], sums [n/1024+1]
 // are scratch (sums may be null for n <= 8192);
 // totals[0] = written, totals[1] = dropped
-void launch_orient(const float *layer0, long layer0_stride, const float *coarse, long coarse_stride, long layer_stride,
+void launch_orient(const float *layer0, long layer0_stride, int layer0_pitch, const float *coarse, long coarse_stride, long layer_stride,
                    int n_layers, int w, int h, const float *extrema, const unsigned *frame_of, long n,
                    const unsigned long long *n_dev, float *angles, unsigned *counts, unsigned *sums, float *kps,
                    unsigned *frame_of_kp, unsigned long long max_out, unsigned long long *totals, hipStream_t stream);
@@ -80,7 +80,7 @@ void launch_orient(const float *layer0, long layer0_stride, const float *coarse,
 void scan_grid(int w, int h, int n_fine, int border, int skip_layers, int &gx, int &gy, int &gz);
 // a-trous stack -> extrema [<= max_out][4] of all frames, ordered by frame, cube (raster), lane; scratch: slots
 // [frames*cubes][8][4], counts [frames*cubes], sums [ceil(frames*cubes/1024)]; totals[0] = written, [1] = dropped
-void launch_detect_extrema(const float *layer0, long layer0_stride, const float *coarse, long coarse_stride,
+void launch_detect_extrema(const float *layer0, long layer0_stride, int layer0_pitch, const float *coarse, long coarse_stride,
                            long layer_stride, int n_layers, int w, int h, int frames, int border, int skip_layers,
                            float contrast_threshold, float *slots, unsigned *counts, unsigned *sums, float *extrema,
                            unsigned *frame_of, unsigned *frame_start, unsigned long long max_out,

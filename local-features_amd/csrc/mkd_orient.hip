@@ -42,7 +42,7 @@ constexpr int kOriWin = 15, kOriPx = kOriWin * kOriWin, kOriBins = 36, kOriMaxPe
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void orient_peaks(const float *__restrict__ layer0, long layer0_stride,
+__global__ __launch_bounds__(256) void orient_peaks(const float *__restrict__ layer0, long layer0_stride, int layer0_pitch,
                                                     const float *__restrict__ coarse, long coarse_stride,
                                                     long layer_stride, int n_layers, int w, int h,
                                                     const float *__restrict__ extrema /*[n][4]*/,
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void orient_peaks(const float *__restrict__ la
     const float sigma = 1.5f * size / kSigmaRadius;
     const unsigned f = frame_of ? frame_of[k] : 0u;
     const float *img = level == 0 ? layer0 + f * layer0_stride : coarse + f * coarse_stride + (level - 1) * layer_stride;
+    const int ipitch = level == 0 ? layer0_pitch : w;   // layer 0 is pyramid level 0, stored with its apron
 
     float *patch = s_patch[wave], *weight = s_weight[wave];
     int *bin = s_bin[wave];
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void orient_peaks(const float *__restrict__ la
             const int xi = kx + xd, yi = ky + yd;
             // valid_px admits y == height (line 73); that row reads as 0 like every out-of-image load
             const bool valid = 0 <= xi && xi < w && 0 <= yi && yi <= h;
-            patch[i] = (valid && yi < h) ? img[(size_t)yi * w + xi] : 0.f;
+            patch[i] = (valid && yi < h) ? img[(size_t)yi * ipitch + xi] : 0.f;
             const bool inner = lx > 0 && lx < kOriWin - 1 && ly > 0 && ly < kOriWin - 1;
             if (valid && inner && abs(xd) <= radius && abs(yd) <= radius) ingrad |= 1u << j;
         }
@@ -277,12 +278,12 @@ __global__ __launch_bounds__(1024) void orient_scatter(const float *__restrict__
     }
 }
 
-void launch_orient(const float *layer0, long layer0_stride, const float *coarse, long coarse_stride, long layer_stride,
+void launch_orient(const float *layer0, long layer0_stride, int layer0_pitch, const float *coarse, long coarse_stride, long layer_stride,
                    int n_layers, int w, int h, const float *extrema, const unsigned *frame_of, long n,
                    const unsigned long long *n_dev, float *angles, unsigned *counts, unsigned *sums, float *kps,
                    unsigned *frame_of_kp, unsigned long long max_out, unsigned long long *totals, hipStream_t stream) {
     if (n > 0)
-        hipLaunchKernelGGL(orient_peaks, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, layer0, layer0_stride,
+        hipLaunchKernelGGL(orient_peaks, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, layer0, layer0_stride, layer0_pitch,
                            coarse, coarse_stride, layer_stride, n_layers, w, h, extrema, frame_of, n, n_dev, angles,
                            counts);
     if (n <= 8192 || !sums) {   // a few thousand extrema (one frame): every workgroup adds up the counts before its own

@@ -52,7 +52,7 @@ __device__ __forceinline__ float sep3_pixel(const float *__restrict__ in, int w,
 // in the middle from them.  The vertical taps of row y blend rows floor(y - off) .. +1 and floor(y + off) .. +1, i.e.
 // rows y-2 .. y+2.  Same arithmetic as the two pyr_sep3 dispatches: bit-identical.
 __global__ __launch_bounds__(256) void pyr_sep3_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
-                                                      long out_stride, int w, int h, float w0, float w1, float off) {
+                                                      long out_stride, int w, int h, int opitch, float w0, float w1, float off) {
 #pragma clang fp contract(off)
     __shared__ float s_h[16][256];   // kSwtRows + 4 rows
     in += blockIdx.z * in_stride;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void pyr_sep3_fused(const float *__restrict__ 
         }
         float sum = s_h[k + 2][threadIdx.x] * w0;
         sum += (side[0] + side[1]) * w1;
-        if (xr < w) out[(size_t)y * w + xr] = sum;
+        if (xr < w) out[(size_t)y * opitch + xr] = sum;
     }
 }
 
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void pyr_sep3_fused(const float *__restrict__ 
 constexpr int kSwtRows = 12, kSwtCols = 256;
 
 __global__ __launch_bounds__(256) void pyr_swt_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
-                                                     long out_stride, int w, int h, int d, int blocks_per_class) {
+                                                     long out_stride, int w, int h, int ipitch, int d, int blocks_per_class) {
 #pragma clang fp contract(off)
     __shared__ float s_h[kSwtRows + 4][kSwtCols];
     const float k0 = 6.f / 16.f, k1 = 4.f / 16.f, k2 = 1.f / 16.f;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void pyr_swt_fused(const float *__restrict__ i
 #pragma unroll 4
     for (int m = 0; m < kSwtRows + 4; ++m) {
         const int v = r + (kb + m - 2) * d;                // virtual row of slot m
-        const float *row = in + (size_t)mirror_idx(v, h) * w;
+        const float *row = in + (size_t)mirror_idx(v, h) * ipitch;
         float sum = row[xi[2]] * k0;
         sum += row[xi[0]] * k2;
         sum += row[xi[1]] * k1;
@@ -164,7 +164,8 @@ __device__ __forceinline__ int blit_src(int i, int n) {   // pyr_decimate's sour
 }
 
 __global__ __launch_bounds__(256) void pyr_level1_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
-                                                        long out_stride, int w, int h, int ow, int oh, int opitch) {
+                                                        long out_stride, int w, int h, int ipitch, int ow, int oh,
+                                                        int opitch) {
 #pragma clang fp contract(off)
     __shared__ float s_h[kL1Slots][256];
     const float k0 = 6.f / 16.f, k1 = 4.f / 16.f, k2 = 1.f / 16.f;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void pyr_level1_fused(const float *__restrict_
     const int v0 = blit_src(y0, h) - 2;                       // virtual source row of slot 0
     const int n_slots = min(blit_src(y_last, h) + 2 - v0 + 1, kL1Slots);
     for (int m = 0; m < n_slots; ++m) {
-        const float *row = in + (size_t)mirror_idx(v0 + m, h) * w;
+        const float *row = in + (size_t)mirror_idx(v0 + m, h) * ipitch;
         float sum = row[xi[2]] * k0;
         sum += row[xi[0]] * k2;
         sum += row[xi[1]] * k1;
@@ -289,27 +290,30 @@ __global__ __launch_bounds__(1024) void pyr_tail(float *__restrict__ pyr, long p
     }
 }
 
-// The apron of levels >= 1 (mkd_device.h): every texel outside the level, up to kPyrApron away, takes the value
+// The apron of the pyramid's levels (mkd_device.h): every texel outside the level, up to kPyrApron away, takes the value
 // MirroredRepeat addressing would have fetched for it.  One launch for all levels and frames, after the last level is
-// written: blockIdx.y = level - 1, blockIdx.z = frame; a thread handles one apron texel -- first the bands above and
-// below the level (full padded width), then the bands left and right of its rows.
+// written: blockIdx.y = level, blockIdx.z = frame.
 __global__ __launch_bounds__(256) void pyr_apron_fill(float *__restrict__ pyr, long pyr_stride, PyramidDesc pd) {
-    const int l = (int)blockIdx.y + 1;
+    const int l = (int)blockIdx.y;
     const int w = pd.w[l], h = pd.h[l], a = pd.apron[l], pitch = pd.pitch[l];
     float *lvl0 = pyr + blockIdx.z * pyr_stride + pd.offset[l];
-    const int n_band = 2 * a * pitch, n_side = 2 * a * h;
-    for (int t = (int)(blockIdx.x * 256 + threadIdx.x); t < n_band + n_side; t += (int)gridDim.x * 256) {
-        int x, y;
-        if (t < n_band) {
-            const int r = t / pitch;
-            x = t - r * pitch - a;
-            y = r < a ? r - a : h + (r - a);
-        } else {
-            const int u = t - n_band, r = u / (2 * a), c = u - r * (2 * a);
-            y = r;
-            x = c < a ? c - a : w + (c - a);
+    const int task = (int)blockIdx.x;
+    if (task < 2 * a) {
+        // a row of the band above or below the level, over the whole padded width: the mirrored source row is uniform
+        const int y = task < a ? task - a : h + (task - a);
+        const float *src = lvl0 + (long)mirror_idx(y, h) * pitch;
+        float *dst = lvl0 + (long)y * pitch;
+        for (int t = (int)threadIdx.x; t < pitch; t += 256) dst[t - a] = src[mirror_idx(t - a, w)];
+    } else {
+        // the bands left and right of eight of the level's own rows
+        const int y0 = 8 * (task - 2 * a);
+        if (y0 >= h) return;
+        for (int i = (int)threadIdx.x; i < 8 * 2 * a; i += 256) {
+            const int rr = i / (2 * a), c = i - rr * (2 * a), y = y0 + rr;
+            if (y >= h) break;
+            const int x = c < a ? c - a : w + (c - a);
+            lvl0[(long)y * pitch + x] = lvl0[(long)y * pitch + mirror_idx(x, w)];
         }
-        lvl0[(long)y * pitch + x] = lvl0[(long)mirror_idx(y, h) * pitch + mirror_idx(x, w)];
     }
 }
 
@@ -362,13 +366,21 @@ void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc 
 // Builds the pyramids of `frames` frames (image_stride floats apart) into pyr (pyr_stride apart); tmp_a and tmp_b
 // hold frames x w x h floats each.
 // one a-trous layer (both passes) for `frames` frames
-static void launch_swt(const float *in, long in_stride, float *out, long out_stride, int w, int h, int d, int frames,
-                       hipStream_t stream) {
+static void launch_swt(const float *in, long in_stride, int in_pitch, float *out, long out_stride, int w, int h, int d,
+                       int frames, hipStream_t stream) {
     const int classes = d < h ? d : h;                                   // residue classes that hold rows
     const int lattice = (h + d - 1) / d;                                 // rows of the longest class
     const int per_class = (lattice + kSwtRows - 1) / kSwtRows;
     hipLaunchKernelGGL(pyr_swt_fused, dim3((w + kSwtCols - 1) / kSwtCols, classes * per_class, frames), dim3(256), 0, stream,
-                       in, out, in_stride, out_stride, w, h, d, per_class);
+                       in, out, in_stride, out_stride, w, h, in_pitch, d, per_class);
+}
+
+// (blockIdx.x = a row of the upper / lower band or a group of eight rows of the side bands; sized for level 0, the smaller
+// levels' surplus workgroups leave at once)
+static void launch_apron_fill(float *pyr, long pyr_stride, const PyramidDesc &pd, int frames, hipStream_t stream) {
+    const unsigned gx = (unsigned)(2 * pd.apron[0] + (pd.h[0] + 7) / 8);
+    hipLaunchKernelGGL(pyr_apron_fill, dim3(gx, (unsigned)pd.levels, (unsigned)frames), dim3(256), 0, stream, pyr, pyr_stride,
+                       pd);
 }
 
 // With layer1 != nullptr the a-trous layer 1 the pyramid needs anyway is written there (frames layer1_stride apart) instead
@@ -382,14 +394,17 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     auto grid = [&](int gw, int gh) { return dim3((gw + 31) / 32, (gh + 7) / 8, frames); };
     // level 0: sigma-0.6 blur, H then V (tasks_detect.rs:150-161, mod.rs:1043-1067)
     hipLaunchKernelGGL(pyr_sep3_fused, dim3((w + 255) / 256, (h + 11) / 12, frames), dim3(256), 0, stream, image,
-                       pyr + pd.offset[0], image_stride, pyr_stride, w, h, 0.66381836f, 0.16809084f, 1.015267163f);
-    if (pd.levels < 2) return;
+                       pyr + pd.offset[0], image_stride, pyr_stride, w, h, pd.pitch[0], 0.66381836f, 0.16809084f, 1.015267163f);
+    if (pd.levels < 2) {
+        launch_apron_fill(pyr, pyr_stride, pd, frames, stream);
+        return;
+    }
     // level 1: one a-trous pass over level 0, nearest-decimated.  Without a taker for the a-trous layer itself (layer1 ==
     // nullptr: no detector / orientation stage has been used on this handle) only the texels the blit picks are computed.
     const bool need_layer1 = layer1 != nullptr;
     float *l1 = layer1 ? layer1 : tmp_b;
     const long l1s = layer1 ? layer1_stride : ts;
-    if (need_layer1) launch_swt(pyr + pd.offset[0], pyr_stride, l1, l1s, w, h, 1, frames, stream);
+    if (need_layer1) launch_swt(pyr + pd.offset[0], pyr_stride, pd.pitch[0], l1, l1s, w, h, 1, frames, stream);
     // Levels >= 1 are only read by the patch sampler: a caller whose next steps need level 0 and layer 1 alone (the
     // detector) can have them built on `rest_stream` beside those steps and wait for `join` before it samples.
     if (rest_stream) {
@@ -403,7 +418,7 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     else
         hipLaunchKernelGGL(pyr_level1_fused, dim3((pd.w[1] + 255) / 256, (pd.h[1] + kL1Rows - 1) / kL1Rows, frames), dim3(256),
                            0, stream, (const float *)(pyr + pd.offset[0]), pyr + pd.offset[1], pyr_stride, pyr_stride, w, h,
-                           pd.w[1], pd.h[1], pd.pitch[1]);
+                           pd.pitch[0], pd.w[1], pd.h[1], pd.pitch[1]);
     // levels >= 2: binomial H at the resolution of level l-1, then V with 2x decimation; the small levels in one launch
     int l0 = pd.levels;
     while (l0 > 2 && pd.w[l0 - 2] * pd.h[l0 - 2] <= kTailPixels) --l0;
@@ -412,29 +427,22 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
                            dim3(256), 0, stream, (const float *)(pyr + pd.offset[l - 1]), pyr + pd.offset[l], pyr_stride,
                            pyr_stride, pd.w[l - 1], pd.h[l - 1], pd.pitch[l - 1], pd.w[l], pd.h[l], pd.pitch[l]);
     if (l0 < pd.levels) hipLaunchKernelGGL(pyr_tail, dim3(frames), dim3(1024), 0, stream, pyr, pyr_stride, pd, l0);
-    // the mirrored apron of levels >= 1: enough workgroups for the largest level's bands, the smaller levels loop less
-    {
-        // (a few fat workgroups per level and frame: with hundreds of frames a thread-per-texel grid is half a million tiny
-        // workgroups, most of them on the small levels where they find nothing to do)
-        const int a = pd.apron[1];
-        const long texels = 2L * a * pd.pitch[1] + 2L * a * pd.h[1];
-        const unsigned gx = (unsigned)std::max<long>(1, std::min<long>((texels + 2047) / 2048, frames > 8 ? 8 : 64));
-        hipLaunchKernelGGL(pyr_apron_fill, dim3(gx, (unsigned)(pd.levels - 1), (unsigned)frames), dim3(256), 0, stream, pyr,
-                           pyr_stride, pd);
-    }
+    // the mirrored apron of every level, once the last one is written
+    launch_apron_fill(pyr, pyr_stride, pd, frames, stream);
     if (rest_stream) (void)hipEventRecord(join, rest_stream);
 }
 
 // Layers 1 .. n_layers-1 of the a-trous stack (mod.rs:1093-1130): layer l+1 = [1 4 6 4 1]/16 H then V over layer l
 // with taps 2^l apart.  Layer 0 is pyramid level 0 (the sigma-0.6 blur), so it is read in place.
-void launch_build_coarse_stack(const float *layer0, long layer0_stride, float *coarse, long coarse_stride,
+void launch_build_coarse_stack(const float *layer0, long layer0_stride, int layer0_pitch, float *coarse, long coarse_stride,
                                long layer_stride, float *tmp, int n_layers, int first_layer, int w, int h, int frames,
                                hipStream_t stream) {
     (void)tmp;
     for (int l = first_layer; l + 1 < n_layers; ++l) {   // first_layer = 1: layer 1 came with the pyramid
         const float *in = l == 0 ? layer0 : coarse + (long)(l - 1) * layer_stride;
         const long in_stride = l == 0 ? layer0_stride : coarse_stride;
-        launch_swt(in, in_stride, coarse + (long)l * layer_stride, coarse_stride, w, h, 1 << l, frames, stream);
+        launch_swt(in, in_stride, l == 0 ? layer0_pitch : w, coarse + (long)l * layer_stride, coarse_stride, w, h, 1 << l, frames,
+                   stream);
     }
 }
 

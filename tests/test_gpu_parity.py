@@ -389,8 +389,8 @@ def _adversarial_keypoints(w, h):
 
 
 def test_pyramid_apron_is_mirrored_repeat(lfp):
-    """Levels >= 1 of the patch pyramid carry an apron of 48 texels holding what MirroredRepeat addressing would fetch there
-    (several mirror periods on the small levels); level 0, which the detector shares, is dense."""
+    """Every level of the patch pyramid carries an apron of 48 texels holding what MirroredRepeat addressing would fetch there
+    (several mirror periods on the small levels)."""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     from gen_golden import smooth_image
@@ -405,7 +405,7 @@ def test_pyramid_apron_is_mirrored_repeat(lfp):
             except RuntimeError:
                 break
             padded, a = h.pyramid_level_apron(l)
-            assert a == (0 if l == 0 else 48)
+            assert a == 48
             assert np.array_equal(padded, np.pad(lvl, a, mode="symmetric")), (w, hgt, l)
             l += 1
         assert l >= 5

@@ -9,7 +9,9 @@ from gen_golden import random_keypoints
 w, h, nk, frames = 640, 480, 2000, 256
 n = nk * frames
 hnd = lfp.MkdHandle(max_features=n, max_image_width=w, max_image_height=h, max_frames=frames)
-s = torch.cuda.current_stream().cuda_stream
+side = torch.cuda.Stream()
+torch.cuda.set_stream(side)
+s = side.cuda_stream
 imgs = torch.rand((frames, h, w), device="cuda")
 base = [np.concatenate([random_keypoints(nk, w, h, 200 + f, margin=8.0), np.zeros((nk, 1), np.float32)], axis=1) for f in range(8)]
 kps = torch.from_numpy(np.concatenate([base[f % 8] for f in range(frames)]).astype(np.float32)).cuda()

@@ -30,8 +30,8 @@ stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), 
 kern_ms = None
 # the timed kernel variant: mkd_pool<ANGLE, POOL>; bench.py also runs the exact-angle variant once as a
 # secondary figure, which must not be mixed into the headline kernel's numbers
-variant = "mkd_pool<%d, %d, 8>" % (0 if (not bench or bench["config"]["angle_mode"] == "shader") else 1,
-                                   1 if (not bench or bench["config"]["pool_mode"] == "f16x3") else 2)
+variant = "mkd_pool<%d, %d, 8, 0>" % (0 if (not bench or bench["config"]["angle_mode"] == "shader") else 1,
+                                      1 if (not bench or bench["config"]["pool_mode"] == "f16x3") else 2)
 if stats:
     lines += ["## `--kernel-trace --stats` (kernel_stats.csv)", "", "| kernel | calls | avg ms | min ms | max ms | % |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(stats[0])):
@@ -69,6 +69,23 @@ if fetch and write:
                "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 wide streaming reads count half)"},
               open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
 sq = {**pmc("sq"), **pmc("sq2")}
+# the clock the chip held during the profiled launches (GRBM_GUI_ACTIVE sums the 8 XCDs: MI355X_MICROARCH.md, DVFS give-back)
+# and the share of SIMD-cycles in which the matrix pipe was busy (SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMDs x kernel cycles)
+clock_mhz = mfma_busy = None
+if sq.get("GRBM_GUI_ACTIVE") and kern_ms:
+    cycles = sq["GRBM_GUI_ACTIVE"] / 8.0
+    clock_mhz = cycles / (kern_ms * 1e3)
+    if sq.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        mfma_busy = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cycles)
+projection = None
+pj = os.path.join(ROOT, "gpurun_out", f"{tag}_projection.json")
+if os.path.exists(pj):
+    projection = json.load(open(pj))
+tl = os.path.join(ROOT, "profiles", "traffic_latest.json")
+if traffic is not None and os.path.exists(tl):
+    tj = json.load(open(tl))
+    tj.update({"shader_clock_mhz_profiled": clock_mhz, "mfma_busy_frac": mfma_busy, "projection": projection})
+    json.dump(tj, open(tl, "w"), indent=1)
 if sq:
     lines += [f"## SQ counters of `{variant}` per launch", "", "| counter | value |", "|---|---|"]
     lines += [f"| {k} | {v:.4g} |" for k, v in sorted(sq.items())]
@@ -77,6 +94,17 @@ if sq:
         lines += ["", f"Shares of wave time: active {sq.get('SQ_ACTIVE_INST_ANY',0)/w:.0%}, waiting (s_waitcnt/barrier) {sq.get('SQ_WAIT_ANY',0)/w:.0%}, "
                   f"issue stalls {sq.get('SQ_WAIT_INST_ANY',0)/w:.0%}; VALU instructions per descriptor {sq.get('SQ_INSTS_VALU',0)/n:.0f}, "
                   f"MFMA per descriptor {sq.get('SQ_INSTS_MFMA',0)/n:.1f}."]
+    if clock_mhz:
+        lines += ["", f"Shader clock during the profiled launches: GRBM_GUI_ACTIVE / 8 / kernel time = {clock_mhz:.0f} MHz"
+                  + (f"; matrix pipe busy {mfma_busy:.1%} of all SIMD-cycles (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles))."
+                     if mfma_busy else ".")]
+    if projection:
+        lines += ["", "### The whitening projection on its own (`tools/phase_timing.py`, a `-DLF_PHASE_TIMING` build)", "",
+                  f"- {projection['epilogue_cycles_per_wave_batch']:.0f} shader cycles per wave and batch of 16 descriptors "
+                  f"({projection['stage_share_of_kernel']:.1%} of the kernel), 264 `v_mfma_f32_16x16x32_f16` in it",
+                  f"- matrix pipe busy {projection['matrix_pipe_busy_frac_in_stage']:.1%} of the stage (two waves per SIMD x 264 x 16 cycles), "
+                  f"{projection['f16_pflops_in_stage']:.3f} PFLOP/s of f16 MFMA chip-wide while in it = "
+                  f"{projection['f16_pflops_in_stage'] / 2.5:.1%} of the 2.5 PFLOP/s peak"]
     lines.append("")
 if bench:
     lines += ["## bench.py line of the `--stats` run", "", "```json", json.dumps(bench), "```", ""]
