@@ -444,6 +444,53 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
     return res
 
 
+def headline_line(args, world, n, total, dt, kern_s, achieved, alt, alt_f32, clock_mhz, wg0_ms):
+    """The bench line without its match_stage / pipelines / cpu_baseline objects."""
+    # HBM traffic of the kernel comes from rocprofv3 PMC passes (tools/profile_round.sh), which cannot run inside
+    # this process: the committed figure is quoted only if it was measured on this very kernel source and workload
+    traffic = mfma_busy = projection = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if (tj.get("patches") == n and tj.get("pool") == args.pool and tj.get("angle") == args.angle
+                    and tj.get("source_sha256") == source_stamp()):
+                traffic = tj.get("hbm_bytes_per_launch")
+                mfma_busy = tj.get("mfma_busy_frac")          # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles)
+                projection = tj.get("projection")             # the whitening stage on its own (phase clocks)
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "MKD descriptors/sec (32x32 patch, 128-D)", "value": total / dt, "unit": "descriptors/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32" if args.pool == "f32" else "f32 (f16x3 split MFMA pooling)",
+        "data": "synthetic",
+        "config": {"workload": f"patch mode: {n} uniform-random 32x32 f32 patches per GPU resident in HBM "
+                               "(per-GPU share of BASELINE configs[3]; SURVEY 8(d) headline), PCA=liberty",
+                   "patches_per_gpu": n, "angle_mode": args.angle, "pool_mode": args.pool,
+                   "parallelism": f"shard-by-rank x{world}, no collective in the describe path"},
+        "exact_zero_angle_mode_value": alt,
+        "f32_pool_mode_value": alt_f32,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "mkd_pool", "kernel_ms": kern_s * 1e3,
+                     "algorithmic_bytes_per_launch": BYTES_PER_DESC * n,
+                     # the clock the chip held under this very kernel (in-kernel stamps: shader-clock counter over the
+                     # constant 100 MHz counter; MI355X_MICROARCH.md DVFS give-back) -- boxes differ by several per cent
+                     "shader_clock_mhz": clock_mhz, "workgroup0_ms": wg0_ms,
+                     "mfma_busy_frac": mfma_busy, "projection": projection,
+                     # beside it, the arithmetic view (informative; DESIGN.md 4): the path's f32 arithmetic is a
+                     # [n x 1024] x [1024 x 238] pooling product + the 238 x 128 whitening; the matrix cores have no
+                     # f32-input rate above 157.3 TFLOP/s (MI355X_MICROARCH.md), the kernel buys its rate with f16 splits
+                     "f32_matrix_view": {"flop_per_descriptor": FLOP_PER_DESC,
+                                         "achieved": FLOP_PER_DESC * n / kern_s / 1e12, "peak": 157.3,
+                                         "unit": "TFLOP/s", "frac": FLOP_PER_DESC * n / kern_s / 1e12 / 157.3}},
+        "match_stage": None,
+    }
+    return line
+
+
 def source_stamp():
     """What the traffic counters in profiles/traffic_latest.json were measured on: sha256 of the describe kernel's source."""
     import hashlib
@@ -569,62 +616,43 @@ def main():
     if not ok:
         raise SystemExit("bench.py: descriptors are not finite / unit norm")
 
-    # configs[3]'s second half on the descriptors just produced: every rank takes part (the all-gather is collective)
+    # The headline is complete at this point; what follows (the collective and the match stage, then the secondary pipelines)
+    # must never cost it.  An exception is reported in place of the stage; a HANG -- a rank stuck in a collective its peers
+    # never entered: no N > 1 run of this code has ever met real RCCL before the driver's -- is cut by a watchdog: rank 0
+    # prints the line with the stage marked as timed out, and every rank leaves without waiting for the others.
+    total = n * world * args.steps
+    kern_s = pool_ms / 1e3 / max(launches, 1)
+    achieved = BYTES_PER_DESC * n / kern_s / 1e9 if kern_s > 0 else 0.0
+    line = {}
+
+    def emit_and_leave(reason):
+        if rank == 0:
+            line["match_stage"] = {"error": reason}
+            print(json.dumps(line), flush=True)
+        os._exit(0)      # (no destroy_process_group: it would wait for the stuck collective)
+
+    import threading
+    # the other ranks leave a little later than rank 0, so that the launcher does not tear rank 0 down before it has printed
+    limit = float(os.environ.get("LF_BENCH_STAGE_LIMIT_S", "300")) + (0.0 if rank == 0 else 20.0)
     stage = None
+    if rank == 0:
+        line.update(headline_line(args, world, n, total, dt, kern_s, achieved, alt, alt_f32, clock_mhz, wg0_ms))
     if not args.no_match:
+        dog = threading.Timer(limit, emit_and_leave, args=(f"match stage did not finish within {limit:.0f} s",))
+        dog.daemon = True
+        dog.start()
         try:
             stage = match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehearsal, gathered, out, n)
-        except SystemExit:
-            raise
+        except SystemExit as e:          # a failed self-check of the stage: reported in its place, loudly
+            stage = {"error": f"FAILED CHECK: {e}"}
+            sys.stderr.write(f"bench.py rank {rank}: match stage failed a self-check: {e}\n")
         except Exception as e:           # reported, not fatal: the headline is the describe figure
             stage = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            dog.cancel()
 
     if rank == 0:
-        total = n * world * args.steps
-        kern_s = pool_ms / 1e3 / max(launches, 1)
-        achieved = BYTES_PER_DESC * n / kern_s / 1e9 if kern_s > 0 else 0.0
-        # HBM traffic of the kernel comes from rocprofv3 PMC passes (tools/profile_round.sh), which cannot run inside
-        # this process: the committed figure is quoted only if it was measured on this very kernel source and workload
-        traffic = mfma_busy = projection = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if (tj.get("patches") == n and tj.get("pool") == args.pool and tj.get("angle") == args.angle
-                        and tj.get("source_sha256") == source_stamp()):
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    mfma_busy = tj.get("mfma_busy_frac")          # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles)
-                    projection = tj.get("projection")             # the whitening stage on its own (phase clocks)
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "MKD descriptors/sec (32x32 patch, 128-D)", "value": total / dt, "unit": "descriptors/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.pool == "f32" else "f32 (f16x3 split MFMA pooling)",
-            "data": "synthetic",
-            "config": {"workload": f"patch mode: {n} uniform-random 32x32 f32 patches per GPU resident in HBM "
-                                   "(per-GPU share of BASELINE configs[3]; SURVEY 8(d) headline), PCA=liberty",
-                       "patches_per_gpu": n, "angle_mode": args.angle, "pool_mode": args.pool,
-                       "parallelism": f"shard-by-rank x{world}, no collective in the describe path"},
-            "exact_zero_angle_mode_value": alt,
-            "f32_pool_mode_value": alt_f32,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mkd_pool", "kernel_ms": kern_s * 1e3,
-                         "algorithmic_bytes_per_launch": BYTES_PER_DESC * n,
-                         # the clock the chip held under this very kernel (in-kernel stamps: shader-clock counter over the
-                         # constant 100 MHz counter; MI355X_MICROARCH.md DVFS give-back) -- boxes differ by several per cent
-                         "shader_clock_mhz": clock_mhz, "workgroup0_ms": wg0_ms,
-                         "mfma_busy_frac": mfma_busy, "projection": projection,
-                         # beside it, the arithmetic view (informative): the path's f32 arithmetic is a
-                         # [n x 1024] x [1024 x 238] pooling product + the 238 x 128 whitening; the matrix cores have no
-                         # f32-input rate above 157.3 TFLOP/s (MI355X_MICROARCH.md), the kernel buys its rate with f16 splits
-                         "f32_matrix_view": {"flop_per_descriptor": FLOP_PER_DESC,
-                                             "achieved": FLOP_PER_DESC * n / kern_s / 1e12, "peak": 157.3,
-                                             "unit": "TFLOP/s", "frac": FLOP_PER_DESC * n / kern_s / 1e12 / 157.3}},
-            "match_stage": stage,
-        }
+        line["match_stage"] = stage
         if world == 1 and not args.no_extras:
             del patches, out, gathered
             torch.cuda.empty_cache()
