@@ -755,9 +755,10 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
 #endif
     __builtin_amdgcn_s_setprio(LF_KP_PRODUCER_PRIO);
     // geometry of a batch's 16 keypoints, one per lane: lanes 0-15 hold set 0, lanes 16-31 set 1 (this batch / the next).
-    // g_xmax / g_ymax: largest first-tap index in the level's allocation (apron included), g_pitch4: row pitch in bytes.
+    // g_xmax / g_ymax: largest first-tap index in the level's allocation (apron included); the row pitch is g_xmax + 2
+    // texels and the apron kPyrApron on every level, so neither needs a register of its own.
     float g_ca = 0.f, g_sa = 0.f, g_rem = 0.f, g_cx = 0.f, g_cy = 0.f;
-    int g_xmax = 0, g_ymax = 0, g_pitch4 = 8, g_apron = 0, g_cov = 0;
+    int g_xmax = 0, g_ymax = 0, g_cov = 0;
     unsigned g_lo = 0, g_hi = 0;
     auto load_geometry = [&](long batch, int set) {
         long k = batch * (16 * W) + pw * 16 + (lane & 15);
@@ -770,7 +771,7 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
                           (long)a * pitch - a;
         if ((lane >> 4) == set) {
             g_ca = g.ca; g_sa = g.sa; g_rem = g.rem; g_cx = g.cx; g_cy = g.cy;
-            g_xmax = lt.w[g.level] + 2 * a - 2; g_ymax = lt.h[g.level] + 2 * a - 2; g_pitch4 = 4 * pitch; g_apron = a;
+            g_xmax = lt.w[g.level] + 2 * a - 2; g_ymax = lt.h[g.level] + 2 * a - 2;   // (pitch = w + 2a, a = kPyrApron)
             g_cov = g.covered ? 1 : 0;
             g_lo = (unsigned)(uintptr_t)a0; g_hi = (unsigned)((uintptr_t)a0 >> 32);
         }
@@ -791,8 +792,8 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
             const int src = 16 * set + 4 * q + i;   // uniform
             const float ca = readlane_f(g_ca, src), sa = readlane_f(g_sa, src), rem = readlane_f(g_rem, src);
             const float cx = readlane_f(g_cx, src), cy = readlane_f(g_cy, src);
-            const int xmax = readlane_i(g_xmax, src), ymax = readlane_i(g_ymax, src), pitch4 = readlane_i(g_pitch4, src);
-            const int apron = readlane_i(g_apron, src);
+            const int xmax = readlane_i(g_xmax, src), ymax = readlane_i(g_ymax, src), pitch4 = 4 * (xmax + 2);
+            constexpr int apron = kPyrApron;
             const unsigned char *a0 = base_of(src);
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -839,7 +840,8 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
             for (int i = 0; i < 4; ++i) {
                 const int src = 16 * set + 4 * q + i;
                 if (readlane_i(g_cov, src)) continue;
-                const int apron = readlane_i(g_apron, src), pitch = readlane_i(g_pitch4, src) >> 2;
+                constexpr int apron = kPyrApron;
+                const int pitch = readlane_i(g_xmax, src) + 2;
                 const int w = readlane_i(g_xmax, src) + 2 - 2 * apron, h = readlane_i(g_ymax, src) + 2 - 2 * apron;
                 const float *lvl0 = reinterpret_cast<const float *>(base_of(src)) + (long)apron * pitch + apron;
 #pragma unroll 1
