@@ -743,24 +743,28 @@ __device__ __forceinline__ f32x2 load2_sv(const unsigned char *uniform_base, uns
         (const __attribute__((address_space(1))) unsigned char *)uniform_base + lane_off);
 }
 
+// The sampling machinery of one row ring: the geometry of the ring's keypoints and the two halves of a quarter's work.
 template <int W>
-__device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable &lt, const long *lvl_offset, long n,
-                                           BatchWalk walk, unsigned char *s_mem, const unsigned char *__restrict__ lut_rows,
-                                           int pw, int lane) {
-    unsigned char *ring = s_mem + kRingOff + pw * (kRingSlotsKp * 2048);
-    // The producer is the shorter instruction stream of the two waves on its SIMD, but its step ends in the barrier the
-    // describe waves of all four SIMDs wait at: served first, it keeps out of their way (same-box A/B: +4 %)
-#ifndef LF_KP_PRODUCER_PRIO
-#define LF_KP_PRODUCER_PRIO 2
-#endif
-    __builtin_amdgcn_s_setprio(LF_KP_PRODUCER_PRIO);
+struct KpSampler {
+    const KpSource &ks;
+    const LevelTable &lt;
+    const long *lvl_offset;
+    long n;
+    unsigned char *ring;
+    int pw, lane, r, c;
     // geometry of a batch's 16 keypoints, one per lane: lanes 0-15 hold set 0, lanes 16-31 set 1 (this batch / the next).
     // g_xmax / g_ymax: largest first-tap index in the level's allocation (apron included); the row pitch is g_xmax + 2
     // texels and the apron kPyrApron on every level, so neither needs a register of its own.
     float g_ca = 0.f, g_sa = 0.f, g_rem = 0.f, g_cx = 0.f, g_cy = 0.f;
     int g_xmax = 0, g_ymax = 0, g_cov = 0;
     unsigned g_lo = 0, g_hi = 0;
-    auto load_geometry = [&](long batch, int set) {
+
+    __device__ __forceinline__ KpSampler(const KpSource &ks_, const LevelTable &lt_, const long *lvl_offset_, long n_,
+                                         unsigned char *s_mem, int pw_, int lane_)
+        : ks(ks_), lt(lt_), lvl_offset(lvl_offset_), n(n_), ring(s_mem + kRingOff + pw_ * (kRingSlotsKp * 2048)), pw(pw_),
+          lane(lane_), r(lane_ >> 4), c(lane_ & 15) {}
+
+    __device__ __forceinline__ void load_geometry(long batch, int set) {
         long k = batch * (16 * W) + pw * 16 + (lane & 15);
         k = k < n ? k : n - 1;
         const float *kp = ks.kps + k * 5;
@@ -775,14 +779,13 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
             g_cov = g.covered ? 1 : 0;
             g_lo = (unsigned)(uintptr_t)a0; g_hi = (unsigned)((uintptr_t)a0 >> 32);
         }
-    };
-    const int r = lane >> 4, c = lane & 15;
-    auto base_of = [&](int src) {
+    }
+    __device__ __forceinline__ const unsigned char *base_of(int src) const {
         return reinterpret_cast<const unsigned char *>((uintptr_t)(unsigned)readlane_i((int)g_lo, src) |
                                                        ((uintptr_t)(unsigned)readlane_i((int)g_hi, src) << 32));
-    };
+    }
     // requests the taps of a quarter (fetch_covered of mkd_sample.h: indices clamped into the level's allocation)
-    auto request = [&](int quarter, int set, KpTaps &t) {
+    __device__ __forceinline__ void request(int quarter, int set, KpTaps &t) const {
 #ifdef LF_KP_ABLATE_PRODUCER   // timing-only build: the describe waves alone (their rings hold whatever was there)
         return;
 #endif
@@ -811,9 +814,9 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
                 t.bot[2 * i + hh] = load2_sv(a0, off + (unsigned)pitch4);
             }
         }
-    };
+    }
     // blends them and writes the quarter's rows into the ring
-    auto finish = [&](int quarter, int set, int slot0, const KpTaps &t) {
+    __device__ __forceinline__ void finish(int quarter, int set, int slot0, const KpTaps &t) const {
 #ifdef LF_KP_ABLATE_PRODUCER
         return;
 #endif
@@ -832,8 +835,8 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
                     bilinear_blend(t.top[k].x, t.top[k].y, t.bot[k].x, t.bot[k].y, t.ax[k], t.ay[k]);
             }
         }
-        // keypoints whose footprint leaves the apron (centre outside the frame, sizes beyond the pyramid, level 0's border,
-        // non-finite data): rare -- their samples are redone with MirroredRepeat evaluated per tap
+        // keypoints whose footprint leaves the apron (centre outside the frame, sizes beyond the pyramid, non-finite data):
+        // rare -- their samples are redone with MirroredRepeat evaluated per tap
         if (any_uncovered) {
             const int ly = 4 * G + r;
 #pragma unroll 1
@@ -854,21 +857,36 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
                 }
             }
         }
-    };
+    }
+};
 
+template <int W>
+__device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable &lt, const long *lvl_offset, long n,
+                                           BatchWalk walk, unsigned char *s_mem, const unsigned char *__restrict__ lut_rows,
+                                           int pw, int lane) {
+    // The producer is the shorter instruction stream of the two waves on its SIMD, but its step ends in the barrier the
+    // describe waves of all four SIMDs wait at: served first, it keeps out of their way (same-box A/B: +4 %)
+#ifndef LF_KP_PRODUCER_PRIO
+#define LF_KP_PRODUCER_PRIO 2
+#endif
+    __builtin_amdgcn_s_setprio(LF_KP_PRODUCER_PRIO);
+    KpSampler<W> sm(ks, lt, lvl_offset, n, s_mem, pw, lane);
     KpTaps ta, tb;
     int set = 0, slot0 = 0;
-    load_geometry(walk.cur, 0);
+    // the first seven quarters of the first batch, before the describe waves' first row barrier.  (Letting the describe
+    // waves, idle until then, sample every other one of them was tried: nothing to gain -- same-box, a one-round launch of
+    // 10 000 keypoints took 96 us either way.)
+    sm.load_geometry(walk.cur, 0);
 #pragma unroll 1
     for (int quarter = 0; quarter < 7; ++quarter) {
-        request(quarter, 0, ta);
-        finish(quarter, 0, 0, ta);
+        sm.request(quarter, 0, ta);
+        sm.finish(quarter, 0, 0, ta);
     }
-    request(7, 0, ta);
+    sm.request(7, 0, ta);
 #pragma unroll 1
     for (long batch = walk.cur; batch < walk.end; batch += walk.step) {
         const bool more = batch + walk.step < walk.end;
-        if (more) load_geometry(batch + walk.step, set ^ 1);
+        if (more) sm.load_geometry(batch + walk.step, set ^ 1);
         const int slot1 = (slot0 + 8) % kRingSlotsKp;
         // step g: LUT row g + 1 is requested into the row buffer the describe waves have just left (row g uses buffer g & 1),
         // then the taps of the quarter step g + 1 will write (vector-memory results return in issue order: the taps, which
@@ -879,12 +897,12 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
             __syncthreads();
             if (g < 31) issue_lut_row<W>(lut_rows, g + 1, s_mem + ((g + 1) & 1) * kRowBytes, pw, lane);
             const int qn = g + 8;    // the quarter of step g + 1
-            if (qn < 32) request(qn, set, nxt);
-            else if (more) request(qn - 32, set ^ 1, nxt);   // (g = 31: quarter 7 of the next batch)
+            if (qn < 32) sm.request(qn, set, nxt);
+            else if (more) sm.request(qn - 32, set ^ 1, nxt);   // (g = 31: quarter 7 of the next batch)
             __builtin_amdgcn_sched_barrier(0);
             const int qc = g + 7;
-            if (qc < 32) finish(qc, set, slot0, cur);
-            else if (more) finish(qc - 32, set ^ 1, slot1, cur);
+            if (qc < 32) sm.finish(qc, set, slot0, cur);
+            else if (more) sm.finish(qc - 32, set ^ 1, slot1, cur);
         };
 #pragma unroll 1
         for (int g = 0; g < 32; g += 2) {
@@ -966,11 +984,12 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
             lv_off[l] = of_;
         }
         __syncthreads();
+        const LevelTable lt{ks.pd.levels, lv, lv + kMaxPyrLevels, lv + 2 * kMaxPyrLevels, lv + 3 * kMaxPyrLevels};
         if (wave >= W) {
-            const LevelTable lt{ks.pd.levels, lv, lv + kMaxPyrLevels, lv + 2 * kMaxPyrLevels, lv + 3 * kMaxPyrLevels};
             kp_produce<W>(ks, lt, lv_off, n, walk, s_mem, lut_rows, wave - W, lane);
             return;
         }
+
 #ifdef LF_KP_CONSUMER_PRIO
         __builtin_amdgcn_s_setprio(LF_KP_CONSUMER_PRIO);
 #endif
