@@ -495,7 +495,7 @@ def source_stamp():
     """What the traffic counters in profiles/traffic_latest.json were measured on: sha256 of the describe kernel's source."""
     import hashlib
     hsh = hashlib.sha256()
-    for f in ("mkd_describe.hip", "mkd_device.h"):
+    for f in ("mkd_describe.hip", "mkd_sample.h", "mkd_device.h"):
         hsh.update(open(os.path.join(ROOT, "local-features_amd", "csrc", f), "rb").read())
     return hsh.hexdigest()[:16]
 
@@ -503,7 +503,7 @@ def source_stamp():
 def keypoint_source_stamp():
     import hashlib
     hsh = hashlib.sha256()
-    for f in ("mkd_describe.hip", "mkd_pyramid.hip", "mkd_device.h", "lf_mkd.cpp"):
+    for f in ("mkd_describe.hip", "mkd_pyramid.hip", "mkd_sample.h", "mkd_device.h", "lf_mkd.cpp"):
         hsh.update(open(os.path.join(ROOT, "local-features_amd", "csrc", f), "rb").read())
     return hsh.hexdigest()[:16]
 

@@ -20,4 +20,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kp_stats -- python3
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/kp_fetch -- python3 $R/tools/prof_keypoints.py > $OUT/kp_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/kp_write -- python3 $R/tools/prof_keypoints.py > $OUT/kp_write.log 2>&1
 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ --output-format csv -d $OUT/kp_tcp -- python3 $R/tools/prof_keypoints.py > $OUT/kp_tcp.log 2>&1
+# configs[1] (one 1080p frame, 10 000 keypoints): HBM traffic of the same call
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/kp1_fetch -- python3 $R/tools/prof_keypoints.py configs1 > $OUT/kp1_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/kp1_write -- python3 $R/tools/prof_keypoints.py configs1 > $OUT/kp1_write.log 2>&1
 tail -1 $OUT/stats.log | cut -c1-400
