@@ -199,9 +199,9 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     }
     if (params->max_image_width && params->max_image_height) {
         // the sampler addresses a pyramid level with 32-bit byte offsets from its first texel
-        if (uint64_t(params->max_image_width) * params->max_image_height >= (1ull << 30) ||
+        if ((uint64_t(params->max_image_width) + 2 * kPyrApron) * (uint64_t(params->max_image_height) + 2 * kPyrApron) >= (1ull << 30) ||
             params->max_image_width >= (1u << 20) || params->max_image_height >= (1u << 20)) {
-            h->err = "max_image_width x max_image_height must stay below 2^30 pixels";
+            h->err = "max_image_width x max_image_height (with the pyramid's apron of 48 texels a side) must stay below 2^30 pixels";
             return bail(LF_MKD_ERR_BAD_ARG);
         }
         h->max_frames = params->max_frames ? params->max_frames : 1;
@@ -281,7 +281,7 @@ int describe_keypoints_on_device(lf_mkd *h, const float *d_kps, const uint32_t *
                                  hipStream_t s) {
     if (fused_keypoints(h)) {
         if (int rc = mark(h, s)) return rc;
-        launch_describe_keypoints(h->d_pyr, h->pyr_stride, h->pd, d_kps, d_frame_of, long(n), nullptr,
+        launch_describe_keypoints(h->d_pyr, h->pyr_stride, h->pd, d_kps, d_frame_of, h->n_frames, long(n), nullptr,
                                   h->params.patch_scale_factor, h->dc, h->params.angle_mode, d_out, h->num_cus, s, h->d_clk);
         LF_HIP(h, hipGetLastError());
         return mark(h, s);
@@ -289,8 +289,8 @@ int describe_keypoints_on_device(lf_mkd *h, const float *d_kps, const uint32_t *
     if (int rc = ensure_patch_staging(h)) return rc;
     for (uint64_t off = 0; off < n; off += h->batch) {
         const uint64_t m = std::min<uint64_t>(h->batch, n - off);
-        launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, d_kps + off * 5, d_frame_of ? d_frame_of + off : nullptr, long(m),
-                              nullptr, h->params.patch_scale_factor, h->d_patches, s);
+        launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, d_kps + off * 5, d_frame_of ? d_frame_of + off : nullptr,
+                              h->n_frames, long(m), nullptr, h->params.patch_scale_factor, h->d_patches, s);
         LF_HIP(h, hipGetLastError());
         if (int rc = run_batch(h, h->d_patches, m, d_out + off * kOut, nullptr, s)) return rc;
     }
@@ -646,7 +646,7 @@ int lf_mkd_sample_patches_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64
     if (!d_kps || !d_patches) return fail(h, LF_MKD_ERR_BAD_ARG, "sample_patches: null pointer");
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
-    launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_kps), nullptr, long(n),
+    launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_kps), nullptr, 1, long(n),
                           nullptr, h->params.patch_scale_factor, d_patches, s);
     LF_HIP(h, hipGetLastError());
     return LF_MKD_OK;
@@ -953,11 +953,11 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
     // (the join costs ~12 us of queue latency wherever it stands, measured; the branch saves ~40)
     if (fork) (void)hipStreamWaitEvent(s, h->side_events[1], 0);
     if (fused_keypoints(h)) {
-        launch_describe_keypoints(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr,
+        launch_describe_keypoints(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr, 1,
                                   long(max_out), cnt + 3, h->params.patch_scale_factor, h->dc, h->params.angle_mode,
                                   d_descriptors, h->num_cus, s);
     } else {
-        launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr,
+        launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr, 1,
                               long(max_out), cnt + 3, h->params.patch_scale_factor, h->d_stream_patches, s);
         launch_describe(h->d_stream_patches, long(max_out), cnt + 3, h->dc, h->params.angle_mode, h->params.pool_mode,
                         d_descriptors, nullptr, h->num_cus, s);

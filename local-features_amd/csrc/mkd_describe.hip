@@ -697,6 +697,7 @@ struct KpSource {
     long pyr_stride;
     const float *kps;            // [n][5] x, y, size, angle (degrees), response
     const unsigned *frame_of;    // [n] frame of each keypoint, or null: all on frame 0
+    unsigned n_frames;           // frames in the store: larger indices (caller's data) are clamped
     float psf;                   // patch_scale_factor
     PyramidDesc pd;
 };
@@ -771,7 +772,8 @@ struct KpSampler {
         const KpGeom g = keypoint_geometry(kp[0], kp[1], kp[2], kp[3], ks.psf, lt);
         // first texel of the level's allocation (apron included): offsets from it are never negative
         const int a = lt.apron[g.level], pitch = lt.pitch[g.level];
-        const float *a0 = ks.pyr + (ks.frame_of ? (long)ks.frame_of[k] * ks.pyr_stride : 0L) + lvl_offset[g.level] -
+        const float *a0 = ks.pyr + (ks.frame_of ? (long)min(ks.frame_of[k], ks.n_frames - 1u) * ks.pyr_stride : 0L) +
+                          lvl_offset[g.level] -
                           (long)a * pitch - a;
         if ((lane >> 4) == set) {
             g_ca = g.ca; g_sa = g.sa; g_rem = g.rem; g_cx = g.cx; g_cy = g.cy;
@@ -1244,8 +1246,8 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
 // Keypoint mode in one launch: 4 describe waves + 4 producer waves per workgroup, 64 keypoints per batch, one workgroup
 // per CU (160 KB of LDS), persistent.
 void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
-                               const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
-                               const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream,
+                               const unsigned *frame_of_kp, unsigned n_frames, long n, const unsigned long long *n_dev,
+                               float psf, const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream,
                                unsigned long long *clk) {
     if (n <= 0) return;
     const long nbatch = (n + 63) / 64;
@@ -1253,7 +1255,8 @@ void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidD
     const unsigned char *lut = reinterpret_cast<const unsigned char *>(dc.pool_b_f16);
     const unsigned char *wf = reinterpret_cast<const unsigned char *>(dc.white_a_f16);
     KpSource ks;
-    ks.pyr = pyr; ks.pyr_stride = pyr_stride; ks.kps = kps; ks.frame_of = frame_of_kp; ks.psf = psf; ks.pd = pd;
+    ks.pyr = pyr; ks.pyr_stride = pyr_stride; ks.kps = kps; ks.frame_of = frame_of_kp; ks.n_frames = n_frames ? n_frames : 1u;
+    ks.psf = psf; ks.pd = pd;
 #define LF_LAUNCH_KP(A)                                                                                                \
     hipLaunchKernelGGL((mkd_pool<A, LF_POOL_F16X3, 4, kSrcKeypoints>), dim3(grid), dim3(512), 0, stream,                \
                        (const float *)nullptr, n, n_dev, lut, dc.colmap, wf, dc.white_bias, out, (float *)nullptr, ks, clk)

@@ -48,14 +48,15 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
                      int waves = 0, unsigned long long *clk = nullptr);
 // clk (nullable, device, 4 words): workgroup 0 leaves (shader clock, 100 MHz clock) on entry and on exit
 // frame_of_kp == nullptr: every keypoint belongs to frame 0
+// (frame indices beyond n_frames - 1 -- caller's data -- are clamped to it: never a read outside the pyramid store)
 void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
-                           const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
+                           const unsigned *frame_of_kp, unsigned n_frames, long n, const unsigned long long *n_dev, float psf,
                            float *patches, hipStream_t stream);
 // keypoint mode in ONE launch (csrc/mkd_describe.hip): patches are sampled by producer waves of the describe workgroup
 // straight into its LDS row ring and never touch HBM.  f16x3 pooling only.
 void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
-                               const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
-                               const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream,
+                               const unsigned *frame_of_kp, unsigned n_frames, long n, const unsigned long long *n_dev,
+                               float psf, const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream,
                                unsigned long long *clk = nullptr);
 // rest_stream (nullable): levels >= 1 are built there -- after `fork`, recorded on `stream` once level 0 and a-trous layer 1
 // exist -- and `join` is recorded behind them; the caller waits for `join` before it samples patches

@@ -327,15 +327,15 @@ __global__ __launch_bounds__(256) void pyr_apron_fill(float *__restrict__ pyr, l
 // frame_of_kp (optional) selects the keypoint's pyramid among the frames of the batch (pyr_stride floats apart).
 __global__ __launch_bounds__(256) void sample_patches(const float *__restrict__ pyr, long pyr_stride, PyramidDesc pd,
                                                       const float *__restrict__ kps /*[n][5]*/,
-                                                      const unsigned *__restrict__ frame_of_kp, long n_host,
-                                                      const unsigned long long *__restrict__ n_dev, float psf,
+                                                      const unsigned *__restrict__ frame_of_kp, unsigned n_frames,
+                                                      long n_host, const unsigned long long *__restrict__ n_dev, float psf,
                                                       float *__restrict__ patches) {
     __shared__ float s_patch[4][1024];
     const long n = n_dev ? (long)*n_dev : n_host;
     const long k = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= n) return;
     const int lane = threadIdx.x & 63;
-    if (frame_of_kp) pyr += (long)frame_of_kp[k] * pyr_stride;
+    if (frame_of_kp) pyr += (long)min(frame_of_kp[k], n_frames - 1u) * pyr_stride;
     const float *kp = kps + k * 5;
     const KpGeom g = keypoint_geometry(kp[0], kp[1], kp[2], kp[3], psf, level_table(pd));
     const float *lvl0 = pyr + pd.offset[g.level];
@@ -356,11 +356,11 @@ __global__ __launch_bounds__(256) void sample_patches(const float *__restrict__ 
 }
 
 void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
-                           const unsigned *frame_of_kp, long n, const unsigned long long *n_dev, float psf,
+                           const unsigned *frame_of_kp, unsigned n_frames, long n, const unsigned long long *n_dev, float psf,
                            float *patches, hipStream_t stream) {
     if (n <= 0) return;
     hipLaunchKernelGGL(sample_patches, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, pyr, pyr_stride, pd, kps,
-                       frame_of_kp, n, n_dev, psf, patches);
+                       frame_of_kp, n_frames ? n_frames : 1u, n, n_dev, psf, patches);
 }
 
 // Builds the pyramids of `frames` frames (image_stride floats apart) into pyr (pyr_stride apart); tmp_a and tmp_b

@@ -269,6 +269,29 @@ def test_multi_frame_entry_points_match_single_frame_and_oracle(lfp, torch, orac
         single.set_images_device(d_frames.data_ptr(), nf, w, hgt)
 
 
+def test_frame_indices_beyond_the_store_are_clamped(lfp, torch):
+    """frame_of_kp is caller's data: an index past the loaded frames reads the last frame's pyramid, never outside the store
+    (both forms of keypoint mode)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_golden import random_keypoints, smooth_image
+    w, hgt, nf = 160, 120, 2
+    frames = np.ascontiguousarray(np.stack([smooth_image(hgt, w, 60 + f) for f in range(nf)]))
+    k5 = np.concatenate([random_keypoints(100, w, hgt, 61), np.zeros((100, 1), np.float32)], axis=1).astype(np.float32)
+    d_frames, d_k = torch.from_numpy(frames).cuda(), torch.from_numpy(k5).cuda()
+    last = torch.full((100,), nf - 1, dtype=torch.int32, device="cuda")
+    wild = last.clone()
+    wild[::3] = 99
+    wild[1::3] = 0x7FFFFFFF
+    for flags in (0, lfp.FLAG_UNFUSED_KEYPOINTS):
+        h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt, max_frames=nf, flags=flags)
+        h.set_images_device(d_frames.data_ptr(), nf, w, hgt)
+        a, b = torch.empty((100, 128), device="cuda"), torch.empty((100, 128), device="cuda")
+        h.describe_keypoints_frames_device(d_k.data_ptr(), last.data_ptr(), 100, a.data_ptr())
+        h.describe_keypoints_frames_device(d_k.data_ptr(), wild.data_ptr(), 100, b.data_ptr())
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+
+
 def test_keypoint_edge_cases_vs_oracle(lfp, oracle):
     """Keypoints whose sampling window leaves the image (MirroredRepeat), the smallest and largest sizes
     the detector emits, sizes below and above the pyramid range (level clamp), angles 0 / 360 / negative."""
