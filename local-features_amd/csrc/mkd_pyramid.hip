@@ -155,24 +155,27 @@ __global__ void pyr_decimate(const float *__restrict__ in, float *__restrict__ o
 // (patch_pyramid.rs:251-285) picks -- the horizontal pass at the picked columns of the rows the picked rows reach, kept in
 // LDS, the vertical pass at the picked rows.  Same pixel arithmetic in the same order as pyr_swt_fused + pyr_decimate:
 // bit-identical, a quarter of the vertical work, and layer 1 (a full frame) is neither written nor read back.
-constexpr int kL1Rows = 8;                       // output rows per workgroup
-constexpr int kL1Slots = 2 * kL1Rows + 8;        // source rows they reach (odd heights step by 3 now and then)
+constexpr int kL1Cols = 128;                     // output columns per workgroup (level 1 of a 640-wide frame: 320 = 2.5 x 128)
 
 __device__ __forceinline__ int blit_src(int i, int n) {   // pyr_decimate's source index, clamped the same way
     int s = (int)floorf(((float)i + 0.5f) * (float)n / (float)(n / 2));
     return s > n - 1 ? n - 1 : s;
 }
 
-__global__ __launch_bounds__(256) void pyr_level1_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
+// ROWS = output rows per workgroup: 16 for batches of frames (less halo per output row), 8 for a single frame (more
+// workgroups); they reach 2 ROWS + 8 source rows (odd heights step by 3 now and then)
+template <int ROWS>
+__global__ __launch_bounds__(kL1Cols) void pyr_level1_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
                                                         long out_stride, int w, int h, int ipitch, int ow, int oh,
                                                         int opitch) {
 #pragma clang fp contract(off)
-    __shared__ float s_h[kL1Slots][256];
+    constexpr int kL1Rows = ROWS, kL1Slots = 2 * ROWS + 8;
+    __shared__ float s_h[kL1Slots][kL1Cols];
     const float k0 = 6.f / 16.f, k1 = 4.f / 16.f, k2 = 1.f / 16.f;
     in += blockIdx.z * in_stride;
     out += blockIdx.z * out_stride;
     const int y0 = (int)blockIdx.y * kL1Rows;
-    const int xr = (int)blockIdx.x * 256 + (int)threadIdx.x, x = xr < ow ? xr : ow - 1;
+    const int xr = (int)blockIdx.x * kL1Cols + (int)threadIdx.x, x = xr < ow ? xr : ow - 1;
     const int sx = blit_src(x, w);
     int xi[5];
 #pragma unroll
@@ -416,9 +419,14 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
         hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)l1, pyr + pd.offset[1],
                            l1s, pyr_stride, w, h, pd.w[1], pd.h[1], pd.pitch[1]);
     else
-        hipLaunchKernelGGL(pyr_level1_fused, dim3((pd.w[1] + 255) / 256, (pd.h[1] + kL1Rows - 1) / kL1Rows, frames), dim3(256),
-                           0, stream, (const float *)(pyr + pd.offset[0]), pyr + pd.offset[1], pyr_stride, pyr_stride, w, h,
-                           pd.pitch[0], pd.w[1], pd.h[1], pd.pitch[1]);
+        if (frames >= 8)
+            hipLaunchKernelGGL(pyr_level1_fused<16>, dim3((pd.w[1] + kL1Cols - 1) / kL1Cols, (pd.h[1] + 15) / 16, frames),
+                               dim3(kL1Cols), 0, stream, (const float *)(pyr + pd.offset[0]), pyr + pd.offset[1], pyr_stride,
+                               pyr_stride, w, h, pd.pitch[0], pd.w[1], pd.h[1], pd.pitch[1]);
+        else
+            hipLaunchKernelGGL(pyr_level1_fused<8>, dim3((pd.w[1] + kL1Cols - 1) / kL1Cols, (pd.h[1] + 7) / 8, frames),
+                               dim3(kL1Cols), 0, stream, (const float *)(pyr + pd.offset[0]), pyr + pd.offset[1], pyr_stride,
+                               pyr_stride, w, h, pd.pitch[0], pd.w[1], pd.h[1], pd.pitch[1]);
     // levels >= 2: binomial H at the resolution of level l-1, then V with 2x decimation; the small levels in one launch
     int l0 = pd.levels;
     while (l0 > 2 && pd.w[l0 - 2] * pd.h[l0 - 2] <= kTailPixels) --l0;
