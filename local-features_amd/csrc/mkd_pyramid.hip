@@ -46,13 +46,42 @@ __device__ __forceinline__ float sep3_pixel(const float *__restrict__ in, int w,
     return s;
 }
 
+// A level's texel together with the texels of the mirrored apron (mkd_device.h) that take its value: the kernels that
+// produce a level write its apron themselves where one reflection reaches every apron texel (w >= a and h >= a; the
+// smaller levels are left to pyr_apron_fill).  (x, y) inside the level, `lvl0` at its texel (0, 0); a = 0: no apron written.
+// x' in [-a, 0) mirrors to -1 - x', x' in [w, w + a) to 2 w - 1 - x'; a texel of a level narrower than 2 a can own both.
+__device__ __forceinline__ void store_with_apron(float *__restrict__ lvl0, int pitch, int w, int h, int a, int x, int y,
+                                                 float v) {
+    float *row = lvl0 + (long)y * pitch;
+    row[x] = v;
+    if (a == 0) return;
+    const bool xl = x < a, xh = x >= w - a;
+    if (xl) row[-1 - x] = v;
+    if (xh) row[2 * w - 1 - x] = v;
+    if (y < a) {
+        float *up = lvl0 + (long)(-1 - y) * pitch;
+        up[x] = v;
+        if (xl) up[-1 - x] = v;
+        if (xh) up[2 * w - 1 - x] = v;
+    }
+    if (y >= h - a) {
+        float *dn = lvl0 + (long)(2 * h - 1 - y) * pitch;
+        dn[x] = v;
+        if (xl) dn[-1 - x] = v;
+        if (xh) dn[2 * w - 1 - x] = v;
+    }
+}
+
 // blur.glsl's two passes (horizontal, then vertical) in one launch, for tap offsets in (1, 2): the same LDS tiling as
 // pyr_swt_fused with dilation 1 -- a workgroup computes the horizontal pass of kSwtRows + 4 rows of a 256-column strip
 // (slot m = virtual row y0 - 2 + m, holding the row that index mirrors to) and the vertical pass of the kSwtRows rows
 // in the middle from them.  The vertical taps of row y blend rows floor(y - off) .. +1 and floor(y + off) .. +1, i.e.
 // rows y-2 .. y+2.  Same arithmetic as the two pyr_sep3 dispatches: bit-identical.
-__global__ __launch_bounds__(256) void pyr_sep3_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
-                                                      long out_stride, int w, int h, int opitch, float w0, float w1, float off) {
+// (waves_per_eu: left alone the scheduler aims at 8 waves per SIMD, 36 registers, and waits for every pair of loads of the
+// horizontal pass; with ten in flight the kernel is 40 % faster)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 6))) void pyr_sep3_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
+                                                      long out_stride, int w, int h, int opitch, int oapron, float w0, float w1,
+                                                      float off) {
 #pragma clang fp contract(off)
     __shared__ float s_h[16][256];   // kSwtRows + 4 rows
     in += blockIdx.z * in_stride;
@@ -80,7 +109,7 @@ __global__ __launch_bounds__(256) void pyr_sep3_fused(const float *__restrict__ 
         }
         float sum = s_h[k + 2][threadIdx.x] * w0;
         sum += (side[0] + side[1]) * w1;
-        if (xr < w) out[(size_t)y * opitch + xr] = sum;
+        if (xr < w) store_with_apron(out, opitch, w, h, oapron, xr, y, sum);
     }
 }
 
@@ -138,7 +167,7 @@ __global__ __launch_bounds__(256) void pyr_swt_fused(const float *__restrict__ i
 
 // Nearest blit [0,w)x[0,h) -> [0,w/2)x[0,h/2): patch_pyramid.rs:251-285.
 __global__ void pyr_decimate(const float *__restrict__ in, float *__restrict__ out, long in_stride, long out_stride,
-                             int w, int h, int ow, int oh, int opitch) {
+                             int w, int h, int ow, int oh, int opitch, int oapron) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= ow || y >= oh) return;
     in += blockIdx.z * in_stride;
@@ -147,7 +176,7 @@ __global__ void pyr_decimate(const float *__restrict__ in, float *__restrict__ o
     int sy = (int)floorf(((float)y + 0.5f) * (float)h / (float)(h / 2));
     sx = sx > w - 1 ? w - 1 : sx;
     sy = sy > h - 1 ? h - 1 : sy;
-    out[(size_t)y * opitch + x] = in[(size_t)sy * w + sx];
+    store_with_apron(out, opitch, ow, oh, oapron, x, y, in[(size_t)sy * w + sx]);
 }
 
 // Level 1 in one launch when nobody else needs a-trous layer 1 (describe-only callers: the detector and the orientation
@@ -167,7 +196,7 @@ __device__ __forceinline__ int blit_src(int i, int n) {   // pyr_decimate's sour
 template <int ROWS>
 __global__ __launch_bounds__(kL1Cols) void pyr_level1_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
                                                         long out_stride, int w, int h, int ipitch, int ow, int oh,
-                                                        int opitch) {
+                                                        int opitch, int oapron) {
 #pragma clang fp contract(off)
     constexpr int kL1Rows = ROWS, kL1Slots = 2 * ROWS + 8;
     __shared__ float s_h[kL1Slots][kL1Cols];
@@ -200,7 +229,7 @@ __global__ __launch_bounds__(kL1Cols) void pyr_level1_fused(const float *__restr
         sum += s_h[k][threadIdx.x] * k2;
         sum += s_h[k + 4][threadIdx.x] * k2;
         sum += s_h[k + 3][threadIdx.x] * k1;
-        if (xr < ow) out[(size_t)y * opitch + xr] = sum;
+        if (xr < ow) store_with_apron(out, opitch, ow, oh, oapron, xr, y, sum);
     }
 }
 
@@ -232,7 +261,7 @@ constexpr int kDownRows = 6;
 
 __global__ __launch_bounds__(256) void pyr_down_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
                                                       long out_stride, int pw, int ph, int ppitch, int ow, int oh,
-                                                      int opitch) {
+                                                      int opitch, int oapron) {
 #pragma clang fp contract(off)
     __shared__ float s_h[2 * kDownRows + 3][256];
     in += blockIdx.z * in_stride;
@@ -263,16 +292,19 @@ __global__ __launch_bounds__(256) void pyr_down_fused(const float *__restrict__ 
         }
         float sum = s_h[2 * k + 2][threadIdx.x] * 0.375f;
         sum += (side[0] + side[1]) * 0.3125f;
-        if (xr < ow) out[(size_t)y * opitch + xr] = sum;
+        if (xr < ow) store_with_apron(out, opitch, ow, oh, oapron, xr, y, sum);
     }
 }
 
 // The small end of the pyramid in one launch: from level l0 on (where the horizontal result of level l-1 fits the
 // 64 KiB LDS tile) one workgroup per frame walks the remaining levels, the horizontal pass into LDS, the decimating
-// vertical pass from it.  Same pixel functions as the per-level kernels; it only replaces a dozen tiny launches.
+// vertical pass from it, then the level's apron.  Same pixel functions as the per-level kernels; it only replaces a dozen tiny launches.
 constexpr int kTailPixels = 16384;
+constexpr int kTailAprChunks = 4;   // 64-texel pieces of a padded row of a tail level: 256 texels hold the levels of ordinary shapes
+// (slimmer, wider tail levels: the launcher leaves their aprons to pyr_apron_fill)
 
-__global__ __launch_bounds__(1024) void pyr_tail(float *__restrict__ pyr, long pyr_stride, PyramidDesc pd, int l0) {
+__global__ __launch_bounds__(1024) void pyr_tail(float *__restrict__ pyr, long pyr_stride, PyramidDesc pd, int l0,
+                                                 int with_apron) {
     __shared__ float s_tmp[kTailPixels];
     float *base = pyr + blockIdx.x * pyr_stride;
     for (int l = l0; l < pd.levels; ++l) {
@@ -290,14 +322,42 @@ __global__ __launch_bounds__(1024) void pyr_tail(float *__restrict__ pyr, long p
         }
         __threadfence_block();   // level l is the input of level l + 1, read by other threads of this workgroup
         __syncthreads();
+        // its mirrored apron (any number of reflections: these levels are smaller than the apron is wide); the next level's
+        // horizontal pass reads the interior only, so no barrier is needed behind this.  A wave takes four rows of the padded
+        // level at a time, all their loads before the first store (one round trip per four rows, not per texel).
+        if (!with_apron) continue;
+        const int a = pd.apron[l], pitch = pd.pitch[l];
+        const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+        for (int r0 = 4 * wave - a; r0 < oh + a; r0 += 64) {
+            float v[4][kTailAprChunks];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float *src = out + (long)mirror_idx(min(r0 + j, oh + a - 1), oh) * pitch;
+#pragma unroll
+                for (int m = 0; m < kTailAprChunks; ++m) v[j][m] = src[mirror_idx(min(lane + 64 * m - a, ow + a - 1), ow)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int py = r0 + j;
+                if (py >= oh + a) break;
+                float *dst = out + (long)py * pitch;
+                const bool inside = py >= 0 && py < oh;
+#pragma unroll
+                for (int m = 0; m < kTailAprChunks; ++m) {
+                    const int px = lane + 64 * m - a;
+                    if (px < ow + a && (!inside || px < 0 || px >= ow)) dst[px] = v[j][m];
+                }
+            }
+        }
     }
 }
 
 // The apron of the pyramid's levels (mkd_device.h): every texel outside the level, up to kPyrApron away, takes the value
-// MirroredRepeat addressing would have fetched for it.  One launch for all levels and frames, after the last level is
-// written: blockIdx.y = level, blockIdx.z = frame.
-__global__ __launch_bounds__(256) void pyr_apron_fill(float *__restrict__ pyr, long pyr_stride, PyramidDesc pd) {
-    const int l = (int)blockIdx.y;
+// MirroredRepeat addressing would have fetched for it.  The kernels that produce a level write its apron with it
+// (store_with_apron, pyr_tail); this one is for what they leave: levels narrower than the apron that are too large for
+// pyr_tail (frames of extreme aspect ratio).  blockIdx.y = level - first, blockIdx.z = frame.
+__global__ __launch_bounds__(256) void pyr_apron_fill(float *__restrict__ pyr, long pyr_stride, PyramidDesc pd, int first) {
+    const int l = first + (int)blockIdx.y;
     const int w = pd.w[l], h = pd.h[l], a = pd.apron[l], pitch = pd.pitch[l];
     float *lvl0 = pyr + blockIdx.z * pyr_stride + pd.offset[l];
     const int task = (int)blockIdx.x;
@@ -378,12 +438,14 @@ static void launch_swt(const float *in, long in_stride, int in_pitch, float *out
                        in, out, in_stride, out_stride, w, h, in_pitch, d, per_class);
 }
 
-// (blockIdx.x = a row of the upper / lower band or a group of eight rows of the side bands; sized for level 0, the smaller
-// levels' surplus workgroups leave at once)
-static void launch_apron_fill(float *pyr, long pyr_stride, const PyramidDesc &pd, int frames, hipStream_t stream) {
-    const unsigned gx = (unsigned)(2 * pd.apron[0] + (pd.h[0] + 7) / 8);
-    hipLaunchKernelGGL(pyr_apron_fill, dim3(gx, (unsigned)pd.levels, (unsigned)frames), dim3(256), 0, stream, pyr, pyr_stride,
-                       pd);
+// (blockIdx.x = a row of the upper / lower band or a group of eight rows of the side bands; sized for level `first`, the
+// smaller levels' surplus workgroups leave at once)
+static void launch_apron_fill(float *pyr, long pyr_stride, const PyramidDesc &pd, int first, int end, int frames,
+                              hipStream_t stream) {
+    if (first >= end) return;
+    const unsigned gx = (unsigned)(2 * pd.apron[first] + (pd.h[first] + 7) / 8);
+    hipLaunchKernelGGL(pyr_apron_fill, dim3(gx, (unsigned)(end - first), (unsigned)frames), dim3(256), 0, stream, pyr,
+                       pyr_stride, pd, first);
 }
 
 // With layer1 != nullptr the a-trous layer 1 the pyramid needs anyway is written there (frames layer1_stride apart) instead
@@ -395,11 +457,24 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     const long ts = (long)w * h;
     const dim3 blk(32, 8);
     auto grid = [&](int gw, int gh) { return dim3((gw + 31) / 32, (gh + 7) / 8, frames); };
+    // levels >= 2: binomial H at the resolution of level l-1, then V with 2x decimation; the small levels in one launch
+    int l0 = pd.levels;
+    while (l0 > 2 && pd.w[l0 - 2] * pd.h[l0 - 2] <= kTailPixels) --l0;
+    // the kernels of levels 0 .. l0-1 write the level's apron with it where one reflection covers it; for a batch of frames
+    // pyr_tail writes the aprons of its levels (one workgroup per frame: for a single frame the many workgroups of
+    // pyr_apron_fill are quicker); pyr_apron_fill does what is left, levels fill_from .. fill_end-1
+    const int n_direct = std::min(l0, pd.levels);
+    const bool tail_aprons = frames >= 8 && l0 < pd.levels && pd.w[l0] + 2 * pd.apron[l0] <= 64 * kTailAprChunks;
+    const int fill_end = tail_aprons ? n_direct : pd.levels;
+    int fill_from = 0;
+    while (fill_from < n_direct && std::min(pd.w[fill_from], pd.h[fill_from]) >= pd.apron[fill_from]) ++fill_from;
+    auto apron_of = [&](int l) { return l < fill_from ? pd.apron[l] : 0; };
     // level 0: sigma-0.6 blur, H then V (tasks_detect.rs:150-161, mod.rs:1043-1067)
     hipLaunchKernelGGL(pyr_sep3_fused, dim3((w + 255) / 256, (h + 11) / 12, frames), dim3(256), 0, stream, image,
-                       pyr + pd.offset[0], image_stride, pyr_stride, w, h, pd.pitch[0], 0.66381836f, 0.16809084f, 1.015267163f);
+                       pyr + pd.offset[0], image_stride, pyr_stride, w, h, pd.pitch[0], apron_of(0), 0.66381836f, 0.16809084f,
+                       1.015267163f);
     if (pd.levels < 2) {
-        launch_apron_fill(pyr, pyr_stride, pd, frames, stream);
+        launch_apron_fill(pyr, pyr_stride, pd, fill_from, fill_end, frames, stream);
         return;
     }
     // level 1: one a-trous pass over level 0, nearest-decimated.  Without a taker for the a-trous layer itself (layer1 ==
@@ -417,26 +492,23 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     }
     if (need_layer1)
         hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)l1, pyr + pd.offset[1],
-                           l1s, pyr_stride, w, h, pd.w[1], pd.h[1], pd.pitch[1]);
+                           l1s, pyr_stride, w, h, pd.w[1], pd.h[1], pd.pitch[1], apron_of(1));
     else
         if (frames >= 8)
             hipLaunchKernelGGL(pyr_level1_fused<16>, dim3((pd.w[1] + kL1Cols - 1) / kL1Cols, (pd.h[1] + 15) / 16, frames),
                                dim3(kL1Cols), 0, stream, (const float *)(pyr + pd.offset[0]), pyr + pd.offset[1], pyr_stride,
-                               pyr_stride, w, h, pd.pitch[0], pd.w[1], pd.h[1], pd.pitch[1]);
+                               pyr_stride, w, h, pd.pitch[0], pd.w[1], pd.h[1], pd.pitch[1], apron_of(1));
         else
             hipLaunchKernelGGL(pyr_level1_fused<8>, dim3((pd.w[1] + kL1Cols - 1) / kL1Cols, (pd.h[1] + 7) / 8, frames),
                                dim3(kL1Cols), 0, stream, (const float *)(pyr + pd.offset[0]), pyr + pd.offset[1], pyr_stride,
-                               pyr_stride, w, h, pd.pitch[0], pd.w[1], pd.h[1], pd.pitch[1]);
-    // levels >= 2: binomial H at the resolution of level l-1, then V with 2x decimation; the small levels in one launch
-    int l0 = pd.levels;
-    while (l0 > 2 && pd.w[l0 - 2] * pd.h[l0 - 2] <= kTailPixels) --l0;
+                               pyr_stride, w, h, pd.pitch[0], pd.w[1], pd.h[1], pd.pitch[1], apron_of(1));
     for (int l = 2; l < l0; ++l)
         hipLaunchKernelGGL(pyr_down_fused, dim3((pd.w[l] + 255) / 256, (pd.h[l] + kDownRows - 1) / kDownRows, frames),
                            dim3(256), 0, stream, (const float *)(pyr + pd.offset[l - 1]), pyr + pd.offset[l], pyr_stride,
-                           pyr_stride, pd.w[l - 1], pd.h[l - 1], pd.pitch[l - 1], pd.w[l], pd.h[l], pd.pitch[l]);
-    if (l0 < pd.levels) hipLaunchKernelGGL(pyr_tail, dim3(frames), dim3(1024), 0, stream, pyr, pyr_stride, pd, l0);
-    // the mirrored apron of every level, once the last one is written
-    launch_apron_fill(pyr, pyr_stride, pd, frames, stream);
+                           pyr_stride, pd.w[l - 1], pd.h[l - 1], pd.pitch[l - 1], pd.w[l], pd.h[l], pd.pitch[l], apron_of(l));
+    if (l0 < pd.levels)
+        hipLaunchKernelGGL(pyr_tail, dim3(frames), dim3(1024), 0, stream, pyr, pyr_stride, pd, l0, tail_aprons ? 1 : 0);
+    launch_apron_fill(pyr, pyr_stride, pd, fill_from, fill_end, frames, stream);
     if (rest_stream) (void)hipEventRecord(join, rest_stream);
 }
 

@@ -411,16 +411,25 @@ def _adversarial_keypoints(w, h):
     return np.ascontiguousarray(np.concatenate([k, np.zeros((len(k), 1), np.float32)], axis=1))
 
 
-def test_pyramid_apron_is_mirrored_repeat(lfp):
+def test_pyramid_apron_is_mirrored_repeat(lfp, torch):
     """Every level of the patch pyramid carries an apron of 48 texels holding what MirroredRepeat addressing would fetch there
-    (several mirror periods on the small levels)."""
+    (several mirror periods on the small levels).  The kernels that produce a level write its apron with it; the shapes cover
+    each writer: levels at least as large as the apron (one reflection, written with the texels), the small end of the
+    pyramid (pyr_tail), levels narrower than the apron but too large for pyr_tail (the stand-alone fill: the two slim
+    shapes), and a batch of frames (its own level-1 kernel)."""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     from gen_golden import smooth_image
-    for w, hgt in ((640, 480), (333, 257), (40, 36), (1920, 1080)):
+    for w, hgt, frames in ((640, 480, 1), (333, 257, 1), (40, 36, 1), (1920, 1080, 1), (1500, 44, 1), (100, 700, 1),
+                           (640, 480, 8), (1500, 44, 8)):
         img = np.ascontiguousarray(smooth_image(hgt, w, w + 1), np.float32)
-        h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt)
-        h.set_image(img)
+        h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt, max_frames=frames)
+        if frames == 1:
+            h.set_image(img)
+        else:   # the level readers return frame 0 of the batch
+            d = torch.from_numpy(np.stack([img] + [img[::-1].copy()] * (frames - 1))).cuda()
+            h.set_images_device(d.data_ptr(), frames, w, hgt)
+            h.synchronize()
         l = 0
         while True:
             try:
@@ -429,9 +438,14 @@ def test_pyramid_apron_is_mirrored_repeat(lfp):
                 break
             padded, a = h.pyramid_level_apron(l)
             assert a == 48
-            assert np.array_equal(padded, np.pad(lvl, a, mode="symmetric")), (w, hgt, l)
+            assert np.array_equal(padded, np.pad(lvl, a, mode="symmetric")), (w, hgt, frames, l)
             l += 1
-        assert l >= 5
+        assert l >= 4
+        if frames > 1:   # the batch's pyramid of frame 0 is the single frame's
+            h1 = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt)
+            h1.set_image(img)
+            for k in range(l):
+                assert np.array_equal(h.pyramid_level_apron(k)[0], h1.pyramid_level_apron(k)[0]), k
 
 
 def test_the_fused_keypoint_kernel_describes_exactly_what_the_sampler_samples(lfp, torch, oracle):
