@@ -71,16 +71,23 @@ struct SamplePos { float ax, ay; int ix, iy; };
 
 __device__ __forceinline__ SamplePos sample_position(float ca, float sa, float rem, float cx, float cy, int lx, int ly) {
 #pragma clang fp contract(off)
+    // x and y halves of each step as one two-wide operation (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 round element by
+    // element like the scalar instructions; the producer waves of the describe kernel are bound by instruction issue):
+    //   rotated = (dx ca - dy sa, dx sa + dy ca), position = rotated rem + centre, then the +0.5 -0.5 of the normalised
+    //   coordinate, floor and fraction
+    typedef float v2 __attribute__((ext_vector_type(2)));
     const float dx = (float)lx - 16.f, dy = (float)ly - 16.f;
-    const float xx = __builtin_fmaf(dx, ca, -(dy * sa)), yy = __builtin_fmaf(dx, sa, dy * ca);
-    const float sx = __builtin_fmaf(xx, rem, cx), sy = __builtin_fmaf(yy, rem, cy);
-    const float fu = (sx + 0.5f) - 0.5f, fv = (sy + 0.5f) - 0.5f;
-    const float x0f = floorf(fu), y0f = floorf(fv);
+    const v2 cross = v2{-dy, dy} * v2{sa, ca};
+    const v2 rot = __builtin_elementwise_fma(v2{dx, dx}, v2{ca, sa}, cross);
+    const v2 s = __builtin_elementwise_fma(rot, v2{rem, rem}, v2{cx, cy});
+    const v2 f = (s + 0.5f) - 0.5f;
+    const v2 f0 = v2{floorf(f.x), floorf(f.y)};
+    const v2 a = f - f0;
     SamplePos p;
-    p.ax = fu - x0f;
-    p.ay = fv - y0f;
-    p.ix = (int)x0f;
-    p.iy = (int)y0f;
+    p.ax = a.x;
+    p.ay = a.y;
+    p.ix = (int)f0.x;
+    p.iy = (int)f0.y;
     return p;
 }
 

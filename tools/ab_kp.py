@@ -47,6 +47,8 @@ for tag, w, h, nk, nf, iters in (("configs2", 640, 480, 2000, 256, 10), ("config
         if it >= 2:
             tp += e0.elapsed_time(e1); td += e1.elapsed_time(e2)
     tp /= iters; td /= iters
+    import hashlib
+    digest = hashlib.md5(o.cpu().numpy().tobytes()).hexdigest()[:12]   # builds that claim the same bits show the same digest
     print(f"{label:28s} {tag}: pyramid {tp:.3f} ms, describe {td:.3f} ms = {n / td / 1e3:.1f} M desc/s; "
-          f"together {n / (tp + td) / 1e3:.1f} M desc/s", flush=True)
+          f"together {n / (tp + td) / 1e3:.1f} M desc/s; md5 {digest}", flush=True)
     del hnd
