@@ -17,11 +17,13 @@ namespace lfmkd {
 // a-trous layers into an LDS tile (the subtraction is the same single f32 operation either way).
 // Output per cube: count + up to 8 slots {x, y, size, contrast}; cubes_compact_* turn that into the ordered list.
 // ---------------------------------------------------------------------------------------------
-// Workgroup = a 32 x 8 pixel tile (8 x 2 cubes per cube layer): the tile's DoG volume (plus a one-texel rim) is
-// differenced into LDS once with row-contiguous loads, then each of the 4 waves walks its share of the cubes.
-constexpr int kScanTX = 32, kScanTY = 8, kScanMaxFine = 8;
-constexpr int kScanRowLen = kScanTX + 2, kScanPlane = (kScanTY + 2) * kScanRowLen;
+// Workgroup = a TX x 8 pixel tile (TX / 4 x 2 cubes per cube layer): the tile's DoG volume (plus a one-texel rim) is
+// differenced into LDS once with row-contiguous loads, then each of the 4 waves walks its share of the cubes.  TX = 32 for
+// a single frame (more workgroups), 64 for a batch of frames (row segments of 264 instead of 136 bytes: 6 % faster there,
+// 4-14 % slower on one frame).
+constexpr int kScanTY = 8, kScanMaxFine = 8;
 
+template <int kScanTX>
 __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ layer0, long layer0_stride, int layer0_pitch,
                                                     const float *__restrict__ coarse, long coarse_stride,
                                                     long layer_stride, int n_fine, int w, int h, int border,
@@ -29,6 +31,7 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
                                                     float *__restrict__ slots /*[frames*cubes][8][4]*/,
                                                     unsigned *__restrict__ counts /*[frames*cubes]*/) {
 #pragma clang fp contract(off)
+    constexpr int kScanRowLen = kScanTX + 2, kScanPlane = (kScanTY + 2) * kScanRowLen;
     __shared__ float s_dog[kScanMaxFine * kScanPlane];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned f = blockIdx.z;
@@ -556,10 +559,13 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, int layer0_p
     const long ncubes = (long)gx * gy * gz, n = ncubes * frames;
     const long nb = (n + 1023) / 1024;
     if (ncubes > 0) {
-        hipLaunchKernelGGL(scan_extrema, dim3((gx + kScanTX / 4 - 1) / (kScanTX / 4), (gy + kScanTY / 4 - 1) / (kScanTY / 4), frames),
-                           dim3(256), 0, stream, layer0,
-                           layer0_stride, layer0_pitch, coarse, coarse_stride, layer_stride, n_layers - 1, w, h, border, skip_layers,
-                           contrast_threshold, gx, gy, gz, slots, counts);
+        auto scan = [&](auto kernel, int tx) {
+            hipLaunchKernelGGL(kernel, dim3((gx + tx / 4 - 1) / (tx / 4), (gy + kScanTY / 4 - 1) / (kScanTY / 4), frames),
+                               dim3(256), 0, stream, layer0, layer0_stride, layer0_pitch, coarse, coarse_stride, layer_stride,
+                               n_layers - 1, w, h, border, skip_layers, contrast_threshold, gx, gy, gz, slots, counts);
+        };
+        if (frames >= 8) scan(scan_extrema<64>, 64);
+        else scan(scan_extrema<32>, 32);
         hipLaunchKernelGGL(cubes_block_sums, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts, n, sums);
     }
     if (ncubes > 0)
