@@ -121,7 +121,7 @@ long describe_pyramid(uint32_t w, uint32_t h, PyramidDesc &pd) {
         pd.offset[l] = off + long(pd.apron[l]) * pd.pitch[l] + pd.apron[l];
         off += long(pd.pitch[l]) * (pd.h[l] + 2 * pd.apron[l]);
     }
-    return off;
+    return (off + 63) / 64 * 64;   // frames 256 bytes apart at least: level 0 of every frame starts 16-byte aligned (pyr_swt_staged)
 }
 
 long pyramid_floats(uint32_t w, uint32_t h) {

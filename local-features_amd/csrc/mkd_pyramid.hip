@@ -113,6 +113,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 6))) voi
     }
 }
 
+// blur.glsl's two passes with the input rows staged in LDS (see pyr_swt_staged below for the why): 16-byte requests of whole
+// row segments, horizontal taps from LDS, horizontal results in registers, vertical pass on them.  A workgroup writes 248
+// columns (256 minus 4 texels of halo a side) and 12 rows.  Widths that are multiples of 4; tap offsets in (1, 2): the
+// vertical taps of output row y0 + k blend slots k, k + 1 and k + 3, k + 4 (floor(y -+ off) = y - 2, y + 1), which is what
+// lets the horizontal results live in registers.  Same arithmetic in the same order as pyr_sep3_fused: bit-identical.
+__global__ __launch_bounds__(256) void pyr_sep3_staged(const float *__restrict__ in, float *__restrict__ out, long in_stride,
+                                                       long out_stride, int w, int h, int opitch, int oapron, float w0, float w1,
+                                                       float off) {
+#pragma clang fp contract(off)
+    constexpr int kSlots = 16, kH4 = 4, kOutCols = 256 - 2 * kH4;
+    __shared__ __attribute__((aligned(16))) float s_raw[kSlots][256];
+    in += blockIdx.z * in_stride;
+    out += blockIdx.z * out_stride;
+    const int y0 = (int)blockIdx.y * 12, xs = (int)blockIdx.x * kOutCols;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = xs - kH4 + 4 * lane;
+    const bool whole = c0 >= 0 && c0 + 3 < w;
+    int cm[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cm[j] = mirror_idx(c0 + j, w);
+    f32x4 seg[kSlots / 4];
+#pragma unroll
+    for (int i = 0; i < kSlots / 4; ++i) {
+        const float *row = in + (size_t)mirror_idx(y0 - 2 + wave + 4 * i, h) * w;
+        if (whole) seg[i] = *reinterpret_cast<const f32x4 *>(row + c0);
+        else seg[i] = f32x4{row[cm[0]], row[cm[1]], row[cm[2]], row[cm[3]]};
+    }
+#pragma unroll
+    for (int i = 0; i < kSlots / 4; ++i) *reinterpret_cast<f32x4 *>(&s_raw[wave + 4 * i][4 * lane]) = seg[i];
+    __syncthreads();
+    const int t = (int)threadIdx.x, xr = xs + t;
+    if (t >= kOutCols || xr >= w) return;
+    // horizontal pass (sep3_pixel, horizontal): the side taps blend the columns floor(x -+ off) and the next one
+    int j0[2];
+    float a[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float c = (float)xr + 0.5f, u = k == 0 ? c - off : c + off;
+        const float fu = u - 0.5f, f0 = floorf(fu);
+        a[k] = fu - f0;
+        const int j = (int)f0 - (xs - kH4);
+        j0[k] = j < 0 ? 0 : (j > 254 ? 254 : j);   // never binding for off in (1, 2)
+    }
+    float hres[kSlots];
+#pragma unroll
+    for (int m = 0; m < kSlots; ++m) {
+        const float *row = s_raw[m];
+        const float side0 = row[j0[0]] * (1.f - a[0]) + row[j0[0] + 1] * a[0];
+        const float side1 = row[j0[1]] * (1.f - a[1]) + row[j0[1] + 1] * a[1];
+        float sum = row[t + kH4] * w0;
+        sum += (side0 + side1) * w1;
+        hres[m] = sum;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const int y = y0 + k;
+        if (y >= h) break;
+        const float c = (float)y + 0.5f;
+        const float fl = (c - off) - 0.5f, fh = (c + off) - 0.5f;
+        const float al = fl - floorf(fl), ah = fh - floorf(fh);
+        const float side0 = hres[k] * (1.f - al) + hres[k + 1] * al;
+        const float side1 = hres[k + 3] * (1.f - ah) + hres[k + 4] * ah;
+        float sum = hres[k + 2] * w0;
+        sum += (side0 + side1) * w1;
+        store_with_apron(out, opitch, w, h, oapron, xr, y, sum);
+    }
+}
+
 // swt.glsl:24-58, both passes in one launch: [1 4 6 4 1]/16 at texel centres, taps d = 2^in_level apart, mirrored,
 // horizontal pass then vertical pass.  The reference runs them as two dispatches through a scratch layer; here a
 // workgroup keeps the horizontal results it needs in LDS, so a layer costs one read and one write of the frame
@@ -162,6 +230,70 @@ __global__ __launch_bounds__(256) void pyr_swt_fused(const float *__restrict__ i
         sum += s_h[k + 4][threadIdx.x] * k2;
         sum += s_h[k + 3][threadIdx.x] * k1;
         if (xr < w) out[(size_t)y * w + xr] = sum;
+    }
+}
+
+// The same layer with the input rows staged in LDS: a wave requests whole 1 KB row segments, 16 bytes per lane, four rows
+// in flight (tools/micro/tile_copy.hip: this request shape streams frames at 5.6 TB/s, one dword per lane and five
+// overlapping taps per output at 4.0), the five horizontal taps are then LDS reads, the horizontal results stay in
+// registers and the vertical pass reads them there.  The segment is 256 texels -- the H4 texels of halo on either side
+// (H4 >= 2 d, a multiple of 4 so that the requests stay 16-byte aligned) come out of the strip's width: a workgroup writes
+// 256 - 2 H4 columns.  For d <= 32, widths and pitches that are multiples of 4 (pyr_swt_fused serves the rest); same
+// arithmetic in the same order: bit-identical.  Per layer of 256 frames 640 x 480: 174 -> 133 us (d = 1), 256 -> 187 (d = 32);
+// of a 4K frame: 19 -> 14 us.
+template <int H4>
+__global__ __launch_bounds__(256) void pyr_swt_staged(const float *__restrict__ in, float *__restrict__ out, long in_stride,
+                                                      long out_stride, int w, int h, int ipitch, int d, int blocks_per_class) {
+#pragma clang fp contract(off)
+    constexpr int kSlots = kSwtRows + 4, kOutCols = kSwtCols - 2 * H4;
+    __shared__ __attribute__((aligned(16))) float s_raw[kSlots][kSwtCols];
+    const float k0 = 6.f / 16.f, k1 = 4.f / 16.f, k2 = 1.f / 16.f;
+    in += blockIdx.z * in_stride;
+    out += blockIdx.z * out_stride;
+    const int r = blockIdx.y / blocks_per_class;
+    const int kb = (blockIdx.y - r * blocks_per_class) * kSwtRows;
+    const int xs = (int)blockIdx.x * kOutCols;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // this lane's four texels of a segment: columns c0 .. c0 + 3 (virtual: mirrored where they leave the frame)
+    const int c0 = xs - H4 + 4 * lane;
+    const bool whole = c0 >= 0 && c0 + 3 < w;
+    int cm[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cm[j] = mirror_idx(c0 + j, w);
+    f32x4 seg[kSlots / 4];
+#pragma unroll
+    for (int i = 0; i < kSlots / 4; ++i) {
+        const int m = wave + 4 * i;
+        const float *row = in + (size_t)mirror_idx(r + (kb + m - 2) * d, h) * ipitch;
+        if (whole) seg[i] = *reinterpret_cast<const f32x4 *>(row + c0);
+        else seg[i] = f32x4{row[cm[0]], row[cm[1]], row[cm[2]], row[cm[3]]};
+    }
+#pragma unroll
+    for (int i = 0; i < kSlots / 4; ++i) *reinterpret_cast<f32x4 *>(&s_raw[wave + 4 * i][4 * lane]) = seg[i];
+    __syncthreads();
+    const int t = (int)threadIdx.x, xr = xs + t;
+    if (t >= kOutCols || xr >= w) return;
+    float hres[kSlots];
+#pragma unroll
+    for (int m = 0; m < kSlots; ++m) {
+        const float *row = &s_raw[m][t + H4];
+        float sum = row[0] * k0;
+        sum += row[-2 * d] * k2;
+        sum += row[-d] * k1;
+        sum += row[d] * k1;
+        sum += row[2 * d] * k2;
+        hres[m] = sum;
+    }
+#pragma unroll
+    for (int k = 0; k < kSwtRows; ++k) {
+        const int y = r + (kb + k) * d;
+        if (y >= h) break;
+        float sum = hres[k + 2] * k0;
+        sum += hres[k + 1] * k1;
+        sum += hres[k] * k2;
+        sum += hres[k + 4] * k2;
+        sum += hres[k + 3] * k1;
+        out[(size_t)y * w + xr] = sum;
     }
 }
 
@@ -230,6 +362,64 @@ __global__ __launch_bounds__(kL1Cols) void pyr_level1_fused(const float *__restr
         sum += s_h[k + 4][threadIdx.x] * k2;
         sum += s_h[k + 3][threadIdx.x] * k1;
         if (xr < ow) store_with_apron(out, opitch, ow, oh, oapron, xr, y, sum);
+    }
+}
+
+// pyr_level1_fused with the source rows staged in LDS by 16-byte requests (pyr_swt_staged has the why), for even heights and
+// widths that are multiples of 4 (the blit then picks texel (2x + 1, 2y + 1) exactly).  A workgroup of two waves writes 124
+// columns and ROWS rows: the 256-texel segment starts at source column 2 x0 - 4, output column x0 + t reads its five taps at
+// segment texels 2t + 3 .. 2t + 7; slot m holds source row 2 y0 - 1 + m (mirrored), output row y0 + k reads slots 2k .. 2k + 4.
+// Same arithmetic in the same order: bit-identical.
+template <int ROWS>
+__global__ __launch_bounds__(128) void pyr_level1_staged(const float *__restrict__ in, float *__restrict__ out, long in_stride,
+                                                         long out_stride, int w, int h, int ipitch, int ow, int oh, int opitch,
+                                                         int oapron) {
+#pragma clang fp contract(off)
+    constexpr int kSlots = 2 * ROWS + 4, kOutCols = 124;
+    __shared__ __attribute__((aligned(16))) float s_raw[kSlots][256];
+    const float k0 = 6.f / 16.f, k1 = 4.f / 16.f, k2 = 1.f / 16.f;
+    in += blockIdx.z * in_stride;
+    out += blockIdx.z * out_stride;
+    const int y0 = (int)blockIdx.y * ROWS, x0 = (int)blockIdx.x * kOutCols;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = 2 * x0 - 4 + 4 * lane, v0 = 2 * y0 - 1;
+    const bool whole = c0 >= 0 && c0 + 3 < w;
+    int cm[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cm[j] = mirror_idx(c0 + j, w);
+    f32x4 seg[kSlots / 2];
+#pragma unroll
+    for (int i = 0; i < kSlots / 2; ++i) {
+        const float *row = in + (size_t)mirror_idx(v0 + wave + 2 * i, h) * ipitch;
+        if (whole) seg[i] = *reinterpret_cast<const f32x4 *>(row + c0);
+        else seg[i] = f32x4{row[cm[0]], row[cm[1]], row[cm[2]], row[cm[3]]};
+    }
+#pragma unroll
+    for (int i = 0; i < kSlots / 2; ++i) *reinterpret_cast<f32x4 *>(&s_raw[wave + 2 * i][4 * lane]) = seg[i];
+    __syncthreads();
+    const int t = (int)threadIdx.x, xr = x0 + t;
+    if (t >= kOutCols || xr >= ow) return;
+    float hres[kSlots];
+#pragma unroll
+    for (int m = 0; m < kSlots; ++m) {
+        const float *row = &s_raw[m][2 * t + 5];
+        float sum = row[0] * k0;
+        sum += row[-2] * k2;
+        sum += row[-1] * k1;
+        sum += row[1] * k1;
+        sum += row[2] * k2;
+        hres[m] = sum;
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        const int y = y0 + k;
+        if (y >= oh) break;
+        float sum = hres[2 * k + 2] * k0;
+        sum += hres[2 * k + 1] * k1;
+        sum += hres[2 * k] * k2;
+        sum += hres[2 * k + 4] * k2;
+        sum += hres[2 * k + 3] * k1;
+        store_with_apron(out, opitch, ow, oh, oapron, xr, y, sum);
     }
 }
 
@@ -434,6 +624,22 @@ static void launch_swt(const float *in, long in_stride, int in_pitch, float *out
     const int classes = d < h ? d : h;                                   // residue classes that hold rows
     const int lattice = (h + d - 1) / d;                                 // rows of the longest class
     const int per_class = (lattice + kSwtRows - 1) / kSwtRows;
+    // the staged form where its 16-byte requests are aligned and its halo fits
+    // (d = 32 leaves 128 of the segment's 256 columns to write: worth it for a batch of frames only)
+    if (d <= (frames >= 8 ? 32 : 16) && w % 4 == 0 && in_pitch % 4 == 0 && in_stride % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+        auto go = [&](auto kernel, int h4) {
+            const int oc = kSwtCols - 2 * h4;
+            hipLaunchKernelGGL(kernel, dim3((w + oc - 1) / oc, classes * per_class, frames), dim3(256), 0, stream, in, out,
+                               in_stride, out_stride, w, h, in_pitch, d, per_class);
+        };
+        if (d <= 2) go(pyr_swt_staged<4>, 4);
+        else if (d == 4) go(pyr_swt_staged<8>, 8);
+        else if (d == 8) go(pyr_swt_staged<16>, 16);
+        else if (d == 16) go(pyr_swt_staged<32>, 32);
+        else go(pyr_swt_staged<64>, 64);
+        return;
+    }
     hipLaunchKernelGGL(pyr_swt_fused, dim3((w + kSwtCols - 1) / kSwtCols, classes * per_class, frames), dim3(256), 0, stream,
                        in, out, in_stride, out_stride, w, h, in_pitch, d, per_class);
 }
@@ -470,9 +676,14 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     while (fill_from < n_direct && std::min(pd.w[fill_from], pd.h[fill_from]) >= pd.apron[fill_from]) ++fill_from;
     auto apron_of = [&](int l) { return l < fill_from ? pd.apron[l] : 0; };
     // level 0: sigma-0.6 blur, H then V (tasks_detect.rs:150-161, mod.rs:1043-1067)
-    hipLaunchKernelGGL(pyr_sep3_fused, dim3((w + 255) / 256, (h + 11) / 12, frames), dim3(256), 0, stream, image,
-                       pyr + pd.offset[0], image_stride, pyr_stride, w, h, pd.pitch[0], apron_of(0), 0.66381836f, 0.16809084f,
-                       1.015267163f);
+    if (w % 4 == 0 && image_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(image) & 15) == 0)
+        hipLaunchKernelGGL(pyr_sep3_staged, dim3((w + 247) / 248, (h + 11) / 12, frames), dim3(256), 0, stream, image,
+                           pyr + pd.offset[0], image_stride, pyr_stride, w, h, pd.pitch[0], apron_of(0), 0.66381836f,
+                           0.16809084f, 1.015267163f);
+    else
+        hipLaunchKernelGGL(pyr_sep3_fused, dim3((w + 255) / 256, (h + 11) / 12, frames), dim3(256), 0, stream, image,
+                           pyr + pd.offset[0], image_stride, pyr_stride, w, h, pd.pitch[0], apron_of(0), 0.66381836f,
+                           0.16809084f, 1.015267163f);
     if (pd.levels < 2) {
         launch_apron_fill(pyr, pyr_stride, pd, fill_from, fill_end, frames, stream);
         return;
@@ -493,7 +704,17 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     if (need_layer1)
         hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)l1, pyr + pd.offset[1],
                            l1s, pyr_stride, w, h, pd.w[1], pd.h[1], pd.pitch[1], apron_of(1));
-    else
+    else if (w % 4 == 0 && h % 2 == 0 && pd.pitch[0] % 4 == 0 && pyr_stride % 4 == 0 &&
+             (reinterpret_cast<uintptr_t>(pyr + pd.offset[0]) & 15) == 0) {
+        if (frames >= 8)
+            hipLaunchKernelGGL(pyr_level1_staged<16>, dim3((pd.w[1] + 123) / 124, (pd.h[1] + 15) / 16, frames), dim3(128), 0,
+                               stream, (const float *)(pyr + pd.offset[0]), pyr + pd.offset[1], pyr_stride, pyr_stride, w, h,
+                               pd.pitch[0], pd.w[1], pd.h[1], pd.pitch[1], apron_of(1));
+        else
+            hipLaunchKernelGGL(pyr_level1_staged<8>, dim3((pd.w[1] + 123) / 124, (pd.h[1] + 7) / 8, frames), dim3(128), 0,
+                               stream, (const float *)(pyr + pd.offset[0]), pyr + pd.offset[1], pyr_stride, pyr_stride, w, h,
+                               pd.pitch[0], pd.w[1], pd.h[1], pd.pitch[1], apron_of(1));
+    } else
         if (frames >= 8)
             hipLaunchKernelGGL(pyr_level1_fused<16>, dim3((pd.w[1] + kL1Cols - 1) / kL1Cols, (pd.h[1] + 15) / 16, frames),
                                dim3(kL1Cols), 0, stream, (const float *)(pyr + pd.offset[0]), pyr + pd.offset[1], pyr_stride,
