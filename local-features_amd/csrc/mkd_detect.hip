@@ -28,28 +28,63 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
                                                     const float *__restrict__ coarse, long coarse_stride,
                                                     long layer_stride, int n_fine, int w, int h, int border,
                                                     int skip_layers, float contrast_threshold, int gx, int gy, int gz,
+                                                    int aligned,
                                                     float *__restrict__ slots /*[frames*cubes][8][4]*/,
                                                     unsigned *__restrict__ counts /*[frames*cubes]*/) {
 #pragma clang fp contract(off)
-    constexpr int kScanRowLen = kScanTX + 2, kScanPlane = (kScanTY + 2) * kScanRowLen;
-    __shared__ float s_dog[kScanMaxFine * kScanPlane];
+    // a row of the LDS tile: the TX + 2 texels the cubes reach, inside a window of TX + 8 that starts on a multiple of four
+    // texels when the layers can be read 16 bytes at a time (`aligned`: widths and strides multiples of 4)
+    constexpr int kScanRowLen = kScanTX + 8, kScanPlane = (kScanTY + 2) * kScanRowLen, kRowF4 = kScanRowLen / 4;
+    __shared__ __attribute__((aligned(16))) float s_dog[kScanMaxFine * kScanPlane];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned f = blockIdx.z;
     const int tx0 = blockIdx.x * kScanTX + border, ty0 = blockIdx.y * kScanTY + border;   // first candidate texel
     const float *l0 = layer0 + f * layer0_stride, *cs = coarse + f * coarse_stride;
+    const int seg0 = aligned ? (tx0 - 1) & ~3 : tx0 - 1;   // frame column of the window's first texel
+    const int shift = tx0 - 1 - seg0;
     // fine[z] = coarse[z] - coarse[z+1] (swt_sub.glsl:24-29) for the tile and its rim; outside the frame: 0
-    for (int i = threadIdx.x; i < kScanPlane; i += 256) {
-        const int yy = i / kScanRowLen, xx = i - yy * kScanRowLen;
-        const int x = tx0 - 1 + xx, y = ty0 - 1 + yy;
-        const bool in = x >= 0 && x < w && y >= 0 && y < h;
-        const size_t o = in ? (size_t)y * w + x : 0;
-        float c[kScanMaxFine + 1];   // all layers of this texel requested at once
-        c[0] = in ? l0[(size_t)y * layer0_pitch + x] : 0.f;   // layer 0 = pyramid level 0, stored with its apron
+    if (aligned) {
+        // 16 bytes per lane and layer, all layers of a lane's four texels requested at once (whole row segments per request:
+        // tools/micro/tile_copy.hip)
+        for (int i = threadIdx.x; i < (kScanTY + 2) * kRowF4; i += 256) {
+            const int yy = i / kRowF4, q4 = i - yy * kRowF4;
+            const int x = seg0 + 4 * q4, y = ty0 - 1 + yy;
+            const bool row_in = y >= 0 && y < h;
+            f32x4 c[kScanMaxFine + 1];
+            if (row_in && x >= 0 && x + 3 < w) {
+                const size_t o = (size_t)y * w + x;
+                c[0] = *reinterpret_cast<const f32x4 *>(l0 + (size_t)y * layer0_pitch + x);
 #pragma unroll
-        for (int z = 0; z < kScanMaxFine; ++z) c[z + 1] = (in && z < n_fine) ? cs[(size_t)z * layer_stride + o] : 0.f;
+                for (int z = 0; z < kScanMaxFine; ++z)
+                    c[z + 1] = z < n_fine ? *reinterpret_cast<const f32x4 *>(cs + (size_t)z * layer_stride + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
 #pragma unroll
-        for (int z = 0; z < kScanMaxFine; ++z)
-            if (z < n_fine) s_dog[z * kScanPlane + i] = c[z] - c[z + 1];
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = row_in && x + e >= 0 && x + e < w;
+                    const size_t o = in ? (size_t)y * w + x + e : 0;
+                    c[0][e] = in ? l0[(size_t)y * layer0_pitch + x + e] : 0.f;
+#pragma unroll
+                    for (int z = 0; z < kScanMaxFine; ++z) c[z + 1][e] = (in && z < n_fine) ? cs[(size_t)z * layer_stride + o] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int z = 0; z < kScanMaxFine; ++z)
+                if (z < n_fine) *reinterpret_cast<f32x4 *>(&s_dog[z * kScanPlane + yy * kScanRowLen + 4 * q4]) = c[z] - c[z + 1];
+        }
+    } else {
+        for (int i = threadIdx.x; i < (kScanTY + 2) * (kScanTX + 2); i += 256) {
+            const int yy = i / (kScanTX + 2), xx = i - yy * (kScanTX + 2);
+            const int x = tx0 - 1 + xx, y = ty0 - 1 + yy;
+            const bool in = x >= 0 && x < w && y >= 0 && y < h;
+            const size_t o = in ? (size_t)y * w + x : 0;
+            float c[kScanMaxFine + 1];   // all layers of this texel requested at once
+            c[0] = in ? l0[(size_t)y * layer0_pitch + x] : 0.f;   // layer 0 = pyramid level 0, stored with its apron
+#pragma unroll
+            for (int z = 0; z < kScanMaxFine; ++z) c[z + 1] = (in && z < n_fine) ? cs[(size_t)z * layer_stride + o] : 0.f;
+#pragma unroll
+            for (int z = 0; z < kScanMaxFine; ++z)
+                if (z < n_fine) s_dog[z * kScanPlane + yy * kScanRowLen + xx] = c[z] - c[z + 1];
+        }
     }
     __syncthreads();
     const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
@@ -64,7 +99,7 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
         const int x = tx0 + qx * 4 + lx, y = ty0 + qy * 4 + ly, z = qz * 4 + lz + 1 + skip_layers;
         const bool inside = !(x < b1 || x >= w - b1 || y < b1 || y >= h - b1 || z <= 0 || z >= n_fine - 1);
         // LDS index of this voxel; out-of-range lanes are parked on a valid interior voxel and never become candidates
-        const int c = (inside ? z : 1) * kScanPlane + (qy * 4 + ly + 1) * kScanRowLen + (qx * 4 + lx + 1);
+        const int c = (inside ? z : 1) * kScanPlane + (qy * 4 + ly + 1) * kScanRowLen + (qx * 4 + lx + 1) + shift;
         auto at = [&](int dz, int dy, int dx) { return s_dog[c + dz * kScanPlane + dy * kScanRowLen + dx]; };
         const float val = s_dog[c];
         // a candidate needs |val| above the contrast threshold (line 95): a cube without such a voxel -- most cubes of a
@@ -559,10 +594,14 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, int layer0_p
     const long ncubes = (long)gx * gy * gz, n = ncubes * frames;
     const long nb = (n + 1023) / 1024;
     if (ncubes > 0) {
+        // layers readable 16 bytes at a time: rows start on multiples of four texels in every layer of every frame
+        const int aligned = w % 4 == 0 && layer0_pitch % 4 == 0 && layer0_stride % 4 == 0 && coarse_stride % 4 == 0 &&
+                            layer_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(layer0) & 15) == 0 &&
+                            (reinterpret_cast<uintptr_t>(coarse) & 15) == 0;
         auto scan = [&](auto kernel, int tx) {
             hipLaunchKernelGGL(kernel, dim3((gx + tx / 4 - 1) / (tx / 4), (gy + kScanTY / 4 - 1) / (kScanTY / 4), frames),
                                dim3(256), 0, stream, layer0, layer0_stride, layer0_pitch, coarse, coarse_stride, layer_stride,
-                               n_layers - 1, w, h, border, skip_layers, contrast_threshold, gx, gy, gz, slots, counts);
+                               n_layers - 1, w, h, border, skip_layers, contrast_threshold, gx, gy, gz, aligned, slots, counts);
         };
         if (frames >= 8) scan(scan_extrema<64>, 64);
         else scan(scan_extrema<32>, 32);
