@@ -131,4 +131,23 @@ void launch_match_verify(const float *a, long na, const float *b, const float *a
                          const void *rec, const void *rec_info, int splits, float ratio, int *match, float *best,
                          float *second, int *n_over, int *over_rows, hipStream_t stream);
 
+#ifdef __HIPCC__
+// Which tile a workgroup takes, for the row-tiled pyramid and a-trous kernels: workgroups are dealt to the 8 XCDs round-robin by their
+// linear id, so the tiles above and below a tile -- which read the same halo rows -- would sit on other XCDs, behind other
+// L2s, and every halo row would come from HBM once per tile.  The remap (bijective for any workgroup count) hands each
+// group of workgroups that share an XCD a contiguous run of tiles in (x fastest, then y, then frame) order.  (Measured on the
+// staged kernels of mkd_pyramid.hip: the frame is then read from HBM once, 0.315 instead of 0.459 GB per 256 frames, and
+// the launch is ~5 % shorter; the extremum scan and the decimating kernel did not gain and keep blockIdx.)
+struct TileId { unsigned x, y, z; };
+__device__ __forceinline__ TileId xcd_tile() {
+    const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = id % 8u, q = nwg / 8u, r = nwg % 8u;
+    const unsigned t = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + id / 8u;
+    const unsigned row = t / gridDim.x;
+    return TileId{t - row * gridDim.x, row % gridDim.y, row / gridDim.y};
+}
+
+#endif
+
 }  // namespace lfmkd

@@ -124,9 +124,10 @@ __global__ __launch_bounds__(256) void pyr_sep3_staged(const float *__restrict__
 #pragma clang fp contract(off)
     constexpr int kSlots = 16, kH4 = 4, kOutCols = 256 - 2 * kH4;
     __shared__ __attribute__((aligned(16))) float s_raw[kSlots][256];
-    in += blockIdx.z * in_stride;
-    out += blockIdx.z * out_stride;
-    const int y0 = (int)blockIdx.y * 12, xs = (int)blockIdx.x * kOutCols;
+    const TileId tile = xcd_tile();
+    in += tile.z * in_stride;
+    out += tile.z * out_stride;
+    const int y0 = (int)tile.y * 12, xs = (int)tile.x * kOutCols;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = xs - kH4 + 4 * lane;
     const bool whole = c0 >= 0 && c0 + 3 < w;
@@ -248,11 +249,12 @@ __global__ __launch_bounds__(256) void pyr_swt_staged(const float *__restrict__ 
     constexpr int kSlots = kSwtRows + 4, kOutCols = kSwtCols - 2 * H4;
     __shared__ __attribute__((aligned(16))) float s_raw[kSlots][kSwtCols];
     const float k0 = 6.f / 16.f, k1 = 4.f / 16.f, k2 = 1.f / 16.f;
-    in += blockIdx.z * in_stride;
-    out += blockIdx.z * out_stride;
-    const int r = blockIdx.y / blocks_per_class;
-    const int kb = (blockIdx.y - r * blocks_per_class) * kSwtRows;
-    const int xs = (int)blockIdx.x * kOutCols;
+    const TileId tile = xcd_tile();
+    in += tile.z * in_stride;
+    out += tile.z * out_stride;
+    const int r = tile.y / blocks_per_class;
+    const int kb = (tile.y - r * blocks_per_class) * kSwtRows;
+    const int xs = (int)tile.x * kOutCols;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // this lane's four texels of a segment: columns c0 .. c0 + 3 (virtual: mirrored where they leave the frame)
     const int c0 = xs - H4 + 4 * lane;
@@ -378,9 +380,10 @@ __global__ __launch_bounds__(128) void pyr_level1_staged(const float *__restrict
     constexpr int kSlots = 2 * ROWS + 4, kOutCols = 124;
     __shared__ __attribute__((aligned(16))) float s_raw[kSlots][256];
     const float k0 = 6.f / 16.f, k1 = 4.f / 16.f, k2 = 1.f / 16.f;
-    in += blockIdx.z * in_stride;
-    out += blockIdx.z * out_stride;
-    const int y0 = (int)blockIdx.y * ROWS, x0 = (int)blockIdx.x * kOutCols;
+    const TileId tile = xcd_tile();
+    in += tile.z * in_stride;
+    out += tile.z * out_stride;
+    const int y0 = (int)tile.y * ROWS, x0 = (int)tile.x * kOutCols;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = 2 * x0 - 4 + 4 * lane, v0 = 2 * y0 - 1;
     const bool whole = c0 >= 0 && c0 + 3 < w;

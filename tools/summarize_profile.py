@@ -163,42 +163,52 @@ if kp_stats:
     per_call = {}
     if fetch and write:
         out += ["## HBM traffic per batch (separate `--pmc` passes), the library's kernels.  FETCH_SIZE / WRITE_SIZE in KiB as counted.",
-                "The gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts half of a wide streaming read) is stated for 16-byte-per-lane",
-                "streaming loads; none of these kernels reads that way from HBM -- the describe kernel's HBM reads are the producers'",
-                "8-byte gathers (its 16-byte LDS-DMA requests fetch the LUT, which stays in L2), the pyramid kernels read 4 bytes per lane --",
-                "widths the guide calls uncalibrated: figures are given as counted, and the total once more with the describe",
-                "kernel's reads doubled as an upper bound.", "",
-                "| kernel | FETCH_SIZE KiB | read GB | WRITE_SIZE KiB | written GB | L1 accesses per keypoint |", "|---|---|---|---|---|---|"]
-        tot = pool_read = 0.0
+                "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts half the bytes of a 16-byte-per-lane streaming read, WRITE_SIZE is exact,",
+                "other widths are to be calibrated on a known byte count.  Calibration (`tools/calibrate_fetch.sh`,",
+                f"`profiles/{tag}_fetch_calibration.txt`: `tools/micro/tile_copy` moves a known 314.6 MB each way in the pyramid kernels' access",
+                "shapes): FETCH_SIZE counts exactly 0.500 x the bytes of EVERY row-contiguous read, 4 bytes per lane and 16 bytes per lane",
+                "alike, WRITE_SIZE 1.000 x.  So the pyramid kernels' reads are doubled in the `read GB` column.  The describe kernel's",
+                "reads are the producers' 8-byte gathers (its 16-byte LDS-DMA requests fetch the LUT, which stays in L2): not calibrated",
+                "(no known byte count for a gather); given as counted and, in the second total, doubled like the rest.", "",
+                "| kernel | FETCH_SIZE KiB | read GB (corrected) | WRITE_SIZE KiB | written GB | L1 accesses per keypoint |", "|---|---|---|---|---|---|"]
+        tot = tot_counted = pool_read = 0.0
         for k in sorted((k for k in set(fetch) | set(write) if ours(k)), key=lambda k: -(fetch.get(k, 0) + write.get(k, 0))):
             rb, wb = fetch.get(k, 0) / calls * 1024, write.get(k, 0) / calls * 1024
-            tot += rb + wb
+            tot_counted += rb + wb
             if k.startswith("mkd_pool"):
                 pool_read += rb
+                shown = f"{rb / 1e9:.3f} (as counted)"
+            else:
+                rb *= 2.0
+                shown = f"{rb / 1e9:.3f}"
+            tot += rb + wb
             acc = f"{tcp[k] / calls / n_kp:.0f}" if k in tcp else ""
-            out.append(f"| `{k}` | {fetch.get(k, 0) / calls:.0f} | {rb / 1e9:.3f} | {write.get(k, 0) / calls:.0f} | {wb / 1e9:.3f} | {acc} |")
+            out.append(f"| `{k}` | {fetch.get(k, 0) / calls:.0f} | {shown} | {write.get(k, 0) / calls:.0f} | {wb / 1e9:.3f} | {acc} |")
         alg = n_kp * (16 + 512) + frames * w * h * 4
-        out += ["", f"Total {tot / 1e9:.2f} GB per batch = {tot / n_kp:.0f} B per descriptor as counted ({(tot + pool_read) / n_kp:.0f} B with the describe "
-                f"kernel's reads doubled); algorithmic {alg / 1e9:.3f} GB = {alg / n_kp:.0f} B per descriptor",
-                f"(16 B keypoint + 512 B descriptor + frame bytes / keypoints, SURVEY 8d) -> ratio {tot / alg:.1f}.  Round 2, with the sampled",
-                "patches written by `sample_patches` and read back by `mkd_pool`: 14121 B per descriptor.  What is left above the algorithmic",
-                "bytes is the pyramid: level 0 written once and read again for level 1, every level's mirrored apron written (and its source read),",
-                "each pyramid read once by the producers.", ""]
+        out += ["", f"Total {tot / 1e9:.2f} GB per batch = {tot / n_kp:.0f} B per descriptor with the calibrated correction ({(tot + pool_read) / n_kp:.0f} B with the describe "
+                f"kernel's reads doubled too); algorithmic {alg / 1e9:.3f} GB = {alg / n_kp:.0f} B per descriptor",
+                f"(16 B keypoint + 512 B descriptor + frame bytes / keypoints, SURVEY 8d) -> ratio {tot / alg:.1f}.",
+                f"In the units of the earlier rounds (every counter as counted, no correction): {tot_counted / n_kp:.0f} B per descriptor; round 2, with the",
+                "sampled patches written by `sample_patches` and read back by `mkd_pool`: 14121 B in those units.  What is left above the",
+                "algorithmic bytes is the pyramid: the frame read with the halo rows of its row tiles (each tile's halo is fetched again: the",
+                "tiles of a frame run on different XCDs), level 0 written once and read again for level 1, every level written with its",
+                "mirrored apron, each pyramid read once by the producers.", ""]
         per_call["configs2_256x640x480_2k_keypoints"] = tot
     # configs[1]: one 1080p frame, 10 000 keypoints
     f1, w1 = per_kernel("kp1_fetch", "FETCH_SIZE"), per_kernel("kp1_write", "WRITE_SIZE")
     if f1 and w1:
-        tot1 = sum(v for k, v in f1.items() if ours(k)) / calls * 1024 + sum(v for k, v in w1.items() if ours(k)) / calls * 1024
+        rd1 = lambda k, v: v * (1.0 if k.startswith("mkd_pool") else 2.0)      # the same correction
+        tot1 = sum(rd1(k, v) for k, v in f1.items() if ours(k)) / calls * 1024 + sum(v for k, v in w1.items() if ours(k)) / calls * 1024
         alg1 = 10000 * (16 + 512) + 1920 * 1080 * 4
         out += [f"configs[1] (one 1920 x 1080 frame, 10 000 keypoints; `prof_keypoints.py configs1`): {tot1 / 1e6:.1f} MB per call = "
-                f"{tot1 / 10000:.0f} B per descriptor as counted; algorithmic {alg1 / 1e6:.1f} MB = {alg1 / 10000:.0f} B per descriptor "
+                f"{tot1 / 10000:.0f} B per descriptor (same correction); algorithmic {alg1 / 1e6:.1f} MB = {alg1 / 10000:.0f} B per descriptor "
                 f"-> ratio {tot1 / alg1:.1f}.", ""]
         per_call["configs1_1080p_10k_keypoints"] = tot1
     if per_call:
         json.dump({"tag": tag, "source_sha256": stamp(("mkd_describe.hip", "mkd_pyramid.hip", "mkd_sample.h", "mkd_device.h", "lf_mkd.cpp")),
                    "git_head_at_summary": head, "hbm_bytes_per_call": per_call,
-                   "note": "FETCH_SIZE + WRITE_SIZE of the library's kernels as counted (8-byte gathers and 4-byte row reads: widths "
-                           "MI355X_MICROARCH.md calls uncalibrated; no 16-byte streaming read from HBM is involved)"},
+                   "note": "WRITE_SIZE as counted + FETCH_SIZE doubled for the pyramid kernels (row-contiguous reads count 0.500 x their "
+                           "bytes on gfx950: profiles/r03_fetch_calibration.txt), as counted for the describe kernel's 8-byte gathers"},
                   open(os.path.join(ROOT, "profiles", "traffic_keypoint_mode.json"), "w"), indent=1)
     shutil.copy(kp_stats, os.path.join(ROOT, "profiles", f"{tag}_keypoint_mode_kernel_stats.csv"))
     open(os.path.join(ROOT, "profiles", f"{tag}_keypoint_mode.md"), "w").write("\n".join(out) + "\n")
