@@ -105,7 +105,11 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
         // a candidate needs |val| above the contrast threshold (line 95): a cube without such a voxel -- most cubes of a
         // natural image -- is done after this one read per lane
         const bool hot = inside && fabsf(val) > contrast_threshold;
+#ifdef LF_SCAN_ABLATE_HOT   // timing-only build: every cube taken for cold
+        if (true) {
+#else
         if (__ballot(hot) == 0ull) {   // uniform
+#endif
             if (lane == 0) counts[(size_t)f * ncubes + ((size_t)qz * gy + cy) * gx + cx] = 0u;
             continue;
         }
