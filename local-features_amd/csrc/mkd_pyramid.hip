@@ -242,9 +242,14 @@ __global__ __launch_bounds__(256) void pyr_swt_fused(const float *__restrict__ i
 // 256 - 2 H4 columns.  For d <= 32, widths and pitches that are multiples of 4 (pyr_swt_fused serves the rest); same
 // arithmetic in the same order: bit-identical.  Per layer of 256 frames 640 x 480: 174 -> 133 us (d = 1), 256 -> 187 (d = 32);
 // of a 4K frame: 19 -> 14 us.
+// `blit` (dilation 1, even frame sizes): the Nearest blit of patch_pyramid.rs:251-285 picks texel (2x + 1, 2y + 1) of this
+// layer for pyramid level 1 -- stored from here, with its apron, instead of by a launch of pyr_decimate that reads the layer back.
+struct SwtBlit { float *out; long stride; int pitch, apron; };
+
 template <int H4>
 __global__ __launch_bounds__(256) void pyr_swt_staged(const float *__restrict__ in, float *__restrict__ out, long in_stride,
-                                                      long out_stride, int w, int h, int ipitch, int d, int blocks_per_class) {
+                                                      long out_stride, int w, int h, int ipitch, int d, int blocks_per_class,
+                                                      SwtBlit blit) {
 #pragma clang fp contract(off)
     constexpr int kSlots = kSwtRows + 4, kOutCols = kSwtCols - 2 * H4;
     __shared__ __attribute__((aligned(16))) float s_raw[kSlots][kSwtCols];
@@ -296,6 +301,8 @@ __global__ __launch_bounds__(256) void pyr_swt_staged(const float *__restrict__ 
         sum += hres[k + 4] * k2;
         sum += hres[k + 3] * k1;
         out[(size_t)y * w + xr] = sum;
+        if (H4 == 4 && blit.out && (xr & 1) && (y & 1))
+            store_with_apron(blit.out + tile.z * blit.stride, blit.pitch, w / 2, h / 2, blit.apron, xr >> 1, y >> 1, sum);
     }
 }
 
@@ -622,8 +629,9 @@ void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc 
 // Builds the pyramids of `frames` frames (image_stride floats apart) into pyr (pyr_stride apart); tmp_a and tmp_b
 // hold frames x w x h floats each.
 // one a-trous layer (both passes) for `frames` frames
-static void launch_swt(const float *in, long in_stride, int in_pitch, float *out, long out_stride, int w, int h, int d,
-                       int frames, hipStream_t stream) {
+// returns whether the launch also wrote `blit` (pyramid level 1, from the dilation-1 layer)
+static bool launch_swt(const float *in, long in_stride, int in_pitch, float *out, long out_stride, int w, int h, int d,
+                       int frames, hipStream_t stream, SwtBlit blit = SwtBlit{nullptr, 0, 0, 0}) {
     const int classes = d < h ? d : h;                                   // residue classes that hold rows
     const int lattice = (h + d - 1) / d;                                 // rows of the longest class
     const int per_class = (lattice + kSwtRows - 1) / kSwtRows;
@@ -631,20 +639,23 @@ static void launch_swt(const float *in, long in_stride, int in_pitch, float *out
     // (d = 32 leaves 128 of the segment's 256 columns to write: worth it for a batch of frames only)
     if (d <= (frames >= 8 ? 32 : 16) && w % 4 == 0 && in_pitch % 4 == 0 && in_stride % 4 == 0 &&
         (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+        const bool with_blit = blit.out && d == 1 && w % 2 == 0 && h % 2 == 0;
+        if (!with_blit) blit.out = nullptr;
         auto go = [&](auto kernel, int h4) {
             const int oc = kSwtCols - 2 * h4;
             hipLaunchKernelGGL(kernel, dim3((w + oc - 1) / oc, classes * per_class, frames), dim3(256), 0, stream, in, out,
-                               in_stride, out_stride, w, h, in_pitch, d, per_class);
+                               in_stride, out_stride, w, h, in_pitch, d, per_class, blit);
         };
         if (d <= 2) go(pyr_swt_staged<4>, 4);
         else if (d == 4) go(pyr_swt_staged<8>, 8);
         else if (d == 8) go(pyr_swt_staged<16>, 16);
         else if (d == 16) go(pyr_swt_staged<32>, 32);
         else go(pyr_swt_staged<64>, 64);
-        return;
+        return with_blit;
     }
     hipLaunchKernelGGL(pyr_swt_fused, dim3((w + kSwtCols - 1) / kSwtCols, classes * per_class, frames), dim3(256), 0, stream,
                        in, out, in_stride, out_stride, w, h, in_pitch, d, per_class);
+    return false;
 }
 
 // (blockIdx.x = a row of the upper / lower band or a group of eight rows of the side bands; sized for level `first`, the
@@ -696,7 +707,10 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     const bool need_layer1 = layer1 != nullptr;
     float *l1 = layer1 ? layer1 : tmp_b;
     const long l1s = layer1 ? layer1_stride : ts;
-    if (need_layer1) launch_swt(pyr + pd.offset[0], pyr_stride, pd.pitch[0], l1, l1s, w, h, 1, frames, stream);
+    bool level1_done = false;
+    if (need_layer1)
+        level1_done = launch_swt(pyr + pd.offset[0], pyr_stride, pd.pitch[0], l1, l1s, w, h, 1, frames, stream,
+                                 SwtBlit{pyr + pd.offset[1], pyr_stride, pd.pitch[1], apron_of(1)});
     // Levels >= 1 are only read by the patch sampler: a caller whose next steps need level 0 and layer 1 alone (the
     // detector) can have them built on `rest_stream` beside those steps and wait for `join` before it samples.
     if (rest_stream) {
@@ -704,7 +718,9 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
         (void)hipStreamWaitEvent(rest_stream, fork, 0);
         stream = rest_stream;
     }
-    if (need_layer1)
+    if (level1_done) {
+        // level 1 came with layer 1
+    } else if (need_layer1)
         hipLaunchKernelGGL(pyr_decimate, grid(pd.w[1], pd.h[1]), blk, 0, stream, (const float *)l1, pyr + pd.offset[1],
                            l1s, pyr_stride, w, h, pd.w[1], pd.h[1], pd.pitch[1], apron_of(1));
     else if (w % 4 == 0 && h % 2 == 0 && pd.pitch[0] % 4 == 0 && pyr_stride % 4 == 0 &&
