@@ -421,7 +421,7 @@ def test_pyramid_apron_is_mirrored_repeat(lfp, torch):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     from gen_golden import smooth_image
     for w, hgt, frames in ((640, 480, 1), (333, 257, 1), (40, 36, 1), (1920, 1080, 1), (1500, 44, 1), (100, 700, 1),
-                           (640, 480, 8), (1500, 44, 8)):
+                           (640, 480, 8), (1500, 44, 8), (640, 480, 3), (334, 258, 8)):
         img = np.ascontiguousarray(smooth_image(hgt, w, w + 1), np.float32)
         h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt, max_frames=frames)
         if frames == 1:
@@ -446,6 +446,12 @@ def test_pyramid_apron_is_mirrored_repeat(lfp, torch):
             h1.set_image(img)
             for k in range(l):
                 assert np.array_equal(h.pyramid_level_apron(k)[0], h1.pyramid_level_apron(k)[0]), k
+        else:            # and so is the pyramid of a handle whose detector shares a-trous layer 1 with it (level 1 is then
+            before = [h.pyramid_level_apron(k)[0] for k in range(l)]   # stored by the layer's kernel, or blitted from it)
+            h.detect_extrema()
+            h.set_image(img)
+            for k in range(l):
+                assert np.array_equal(h.pyramid_level_apron(k)[0], before[k]), (w, hgt, k)
 
 
 def test_the_fused_keypoint_kernel_describes_exactly_what_the_sampler_samples(lfp, torch, oracle):
