@@ -42,6 +42,16 @@ constexpr int kOriWin = 15, kOriPx = kOriWin * kOriWin, kOriBins = 36, kOriMaxPe
 
 }  // namespace
 
+// A wave's LDS arrays are its own here (one extremum per wave): what its lanes exchange through them needs program order
+// and nothing else -- the LDS executes a wave's operations in the order they were issued -- so the workgroup barrier is
+// replaced by a fence at wavefront scope, which only keeps the compiler from moving LDS accesses across it.  The four
+// waves of a workgroup (four extrema with different numbers of voters) then no longer wait for each other six times.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(256) void orient_peaks(const float *__restrict__ layer0, long layer0_stride, int layer0_pitch,
                                                     const float *__restrict__ coarse, long coarse_stride,
                                                     long layer_stride, int n_layers, int w, int h,
@@ -52,15 +62,16 @@ __global__ __launch_bounds__(256) void orient_peaks(const float *__restrict__ la
                                                     unsigned *__restrict__ counts /*[n]*/) {
 #pragma clang fp contract(off)
     const long n = n_dev ? (long)*n_dev : n_host;
-    if (n <= 0) return;   // uniform: no barrier is skipped by part of a block
+    if (n <= 0) return;
     __shared__ float s_patch[4][kOriPx];
     __shared__ float s_weight[4][kOriPx];
     __shared__ int s_bin[4][kOriPx];
     __shared__ float s_hist[4][kOriBins];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long kk = (long)blockIdx.x * 4 + wave;
-    const bool live = kk < n;
-    const long k = live ? kk : n - 1;   // idle waves redo the last extremum so that the barriers stay uniform
+    if (kk >= n) return;   // (whole waves leave: the kernel has no workgroup barrier)
+    const bool live = true;
+    const long k = kk;
     const float *ex = extrema + k * 4;
     const int kx = (int)ex[0], ky = (int)ex[1];
     const float size = ex[2];
@@ -92,7 +103,7 @@ __global__ __launch_bounds__(256) void orient_peaks(const float *__restrict__ la
             if (valid && inner && abs(xd) <= radius && abs(yd) <= radius) ingrad |= 1u << j;
         }
     }
-    __syncthreads();
+    wave_sync();
     int voters = 0;   // uniform over the wave
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -123,26 +134,41 @@ __global__ __launch_bounds__(256) void orient_peaks(const float *__restrict__ la
             voters += __popcll(vm);
         }
     }
-    __syncthreads();
+    wave_sync();
+    // still the reference's single-thread, row-major addition order per bin.  Branch-free, eight voters' records read
+    // together: a voter of another bin adds +0 (the sums are of non-negative weights: x + 0 == x bit for bit), and the
+    // LDS latency is paid once per eight voters instead of twice per voter.
     float raw = 0.f;
-    if (lane < kOriBins)
-        for (int i = 0; i < voters; ++i)   // still the reference's single-thread, row-major addition order per bin
-            if (bin[i] == lane) raw += weight[i];
-    __syncthreads();
+    if (lane < kOriBins) {
+        int i = 0;
+        for (; i + 8 <= voters; i += 8) {
+            int bb[8];
+            float ww[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                bb[u] = bin[i + u];
+                ww[u] = weight[i + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) raw += bb[u] == lane ? ww[u] : 0.f;
+        }
+        for (; i < voters; ++i) raw += bin[i] == lane ? weight[i] : 0.f;
+    }
+    wave_sync();
     if (lane < kOriBins) hist[lane] = raw;   // raw histogram, circular
-    __syncthreads();
+    wave_sync();
     float hv = 0.f;
     if (lane < kOriBins) {
         auto at = [&](int b) { return hist[b < 0 ? b + kOriBins : (b >= kOriBins ? b - kOriBins : b)]; };
         hv = (at(lane - 2) + at(lane + 2)) * (1.0f / 16.0f) + (at(lane - 1) + at(lane + 1)) * (4.0f / 16.0f) +
              at(lane) * (6.0f / 16.0f);
     }
-    __syncthreads();
+    wave_sync();
     if (lane < kOriBins) hist[lane] = hv;    // smoothed histogram
     float mx = hv;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    __syncthreads();
+    wave_sync();
     bool peak = false;
     float angle = 0.f;
     if (lane < kOriBins) {
