@@ -24,6 +24,16 @@ namespace lfmkd {
 // out = w0 * tex(c) + w1 * (tex(c - off) + tex(c + off)) along one axis.  The bilinear fetch is evaluated exactly as
 // a bilinear fetch (mkd_sample.h) does, minus the terms that are multiplied by a weight of exactly 0: the centre tap sits on a texel
 // centre (both fractions 0), the side taps have fraction 0 across the pass direction.
+// MirroredRepeat index for an offset of at most two texels past either edge of a line of n >= 2 texels: one reflection
+// (the same index mirror_idx gives there, in a third of its instructions); REFLECT = false: any offset, any n.
+template <bool REFLECT>
+__device__ __forceinline__ int edge_idx(int i, int n) {
+    if (!REFLECT) return mirror_idx(i, n);
+    i = i < 0 ? -1 - i : i;
+    return i >= n ? 2 * n - 1 - i : i;
+}
+
+template <bool REFLECT = false>
 __device__ __forceinline__ float sep3_pixel(const float *__restrict__ in, int w, int h, int pitch, int x, int y, float w0,
                                             float w1, float off, int vertical) {
 #pragma clang fp contract(off)   // the detector's decisions sit on these values: round like the restatement they are tested against
@@ -38,7 +48,7 @@ __device__ __forceinline__ float sep3_pixel(const float *__restrict__ in, int w,
         const float fu = u - 0.5f;
         const float f0 = floorf(fu);
         const float a = fu - f0;
-        const int i0 = mirror_idx((int)f0, n), i1 = mirror_idx((int)f0 + 1, n);
+        const int i0 = edge_idx<REFLECT>((int)f0, n), i1 = edge_idx<REFLECT>((int)f0 + 1, n);
         side[k] = line[i0 * stride] * (1.f - a) + line[i1 * stride] * a;
     }
     float s = in[(size_t)y * pitch + x] * w0;
@@ -434,10 +444,11 @@ __global__ __launch_bounds__(128) void pyr_level1_staged(const float *__restrict
 }
 
 // blur_pyramid.glsl:36-49 vertical pass: binomial taps centred on texel (2x, 2y) of the H result.
+template <bool REFLECT = false>
 __device__ __forceinline__ float down_v_pixel(const float *__restrict__ in, int w, int h, int x, int y) {
 #pragma clang fp contract(off)
     // taps centred on texel (2x, 2y): same arithmetic as a bilinear fetch, zero-weight terms left out (see sep3_pixel)
-    const int sx = mirror_idx(2 * x, w);
+    const int sx = edge_idx<REFLECT>(2 * x, w);
     const float cy = 2.f * (float)y + 0.5f;
     float side[2];
 #pragma unroll
@@ -446,10 +457,10 @@ __device__ __forceinline__ float down_v_pixel(const float *__restrict__ in, int 
         const float fu = u - 0.5f;
         const float f0 = floorf(fu);
         const float a = fu - f0;
-        const int i0 = mirror_idx((int)f0, h), i1 = mirror_idx((int)f0 + 1, h);
+        const int i0 = edge_idx<REFLECT>((int)f0, h), i1 = edge_idx<REFLECT>((int)f0 + 1, h);
         side[k] = in[(size_t)i0 * w + sx] * (1.f - a) + in[(size_t)i1 * w + sx] * a;
     }
-    float s = in[(size_t)mirror_idx(2 * y, h) * w + sx] * 0.375f;
+    float s = in[(size_t)edge_idx<REFLECT>(2 * y, h) * w + sx] * 0.375f;
     s += (side[0] + side[1]) * 0.3125f;
     return s;
 }
@@ -510,15 +521,30 @@ __global__ __launch_bounds__(1024) void pyr_tail(float *__restrict__ pyr, long p
     for (int l = l0; l < pd.levels; ++l) {
         const int pw = pd.w[l - 1], ph = pd.h[l - 1], ow = pd.w[l], oh = pd.h[l];
         const float *in = base + pd.offset[l - 1];
+        // this workgroup is one CU's worth of arithmetic per frame: the taps reach two texels past an edge at most, so one
+        // reflection stands for MirroredRepeat on all but one-texel-wide levels, and the row of a flat index comes from a
+        // reciprocal (indices stay below 2^14: exact up to the fix-up)
+        const bool reflect = pw >= 2 && ph >= 2;
+        auto row_of = [](int i, int n, float inv, int &x) {
+            int y = (int)((float)i * inv);
+            x = i - y * n;
+            if (x < 0) { --y; x += n; }
+            if (x >= n) { ++y; x -= n; }
+            return y;
+        };
+        const float inv_pw = 1.f / (float)pw, inv_ow = 1.f / (float)ow;
         for (int i = threadIdx.x; i < pw * ph; i += 1024) {
-            const int y = i / pw, x = i - y * pw;
-            s_tmp[i] = sep3_pixel(in, pw, ph, pd.pitch[l - 1], x, y, 0.375f, 0.3125f, 1.2f, 0);
+            int x;
+            const int y = row_of(i, pw, inv_pw, x);
+            s_tmp[i] = reflect ? sep3_pixel<true>(in, pw, ph, pd.pitch[l - 1], x, y, 0.375f, 0.3125f, 1.2f, 0)
+                               : sep3_pixel<false>(in, pw, ph, pd.pitch[l - 1], x, y, 0.375f, 0.3125f, 1.2f, 0);
         }
         __syncthreads();
         float *out = base + pd.offset[l];
         for (int i = threadIdx.x; i < ow * oh; i += 1024) {
-            const int y = i / ow, x = i - y * ow;
-            out[(size_t)y * pd.pitch[l] + x] = down_v_pixel(s_tmp, pw, ph, x, y);
+            int x;
+            const int y = row_of(i, ow, inv_ow, x);
+            out[(size_t)y * pd.pitch[l] + x] = reflect ? down_v_pixel<true>(s_tmp, pw, ph, x, y) : down_v_pixel<false>(s_tmp, pw, ph, x, y);
         }
         __threadfence_block();   // level l is the input of level l + 1, read by other threads of this workgroup
         __syncthreads();
