@@ -662,8 +662,8 @@ static bool launch_swt(const float *in, long in_stride, int in_pitch, float *out
     const int lattice = (h + d - 1) / d;                                 // rows of the longest class
     const int per_class = (lattice + kSwtRows - 1) / kSwtRows;
     // the staged form where its 16-byte requests are aligned and its halo fits
-    // (d = 32 leaves 128 of the segment's 256 columns to write: worth it for a batch of frames only)
-    if (d <= (frames >= 8 ? 32 : 16) && w % 4 == 0 && in_pitch % 4 == 0 && in_stride % 4 == 0 &&
+    // (d = 32 leaves 128 of the segment's 256 columns to write and is still ahead: 17 against 21 us on a 4K frame)
+    if (d <= 32 && w % 4 == 0 && in_pitch % 4 == 0 && in_stride % 4 == 0 &&
         (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
         const bool with_blit = blit.out && d == 1 && w % 2 == 0 && h % 2 == 0;
         if (!with_blit) blit.out = nullptr;
