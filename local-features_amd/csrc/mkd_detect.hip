@@ -18,9 +18,9 @@ namespace lfmkd {
 // Output per cube: count + up to 8 slots {x, y, size, contrast}; cubes_compact_* turn that into the ordered list.
 // ---------------------------------------------------------------------------------------------
 // Workgroup = a TX x 8 pixel tile (TX / 4 x 2 cubes per cube layer): the tile's DoG volume (plus a one-texel rim) is
-// differenced into LDS once with row-contiguous loads, then each of the 4 waves walks its share of the cubes.  TX = 32 for
-// a single frame (more workgroups), 64 for a batch of frames (row segments of 264 instead of 136 bytes: 6 % faster there,
-// 4-14 % slower on one frame).
+// differenced into LDS once with row-contiguous loads, then each of the 4 waves walks its share of the cubes.  TX = 64 from
+// two megapixels per launch on (a 1080p frame, a 4K frame, a batch of small frames: longer row segments, 6-8 % faster there),
+// 32 below (a 640 x 480 frame: more workgroups, 15 % faster than 64).
 constexpr int kScanTY = 8, kScanMaxFine = 8;
 
 template <int kScanTX>
@@ -607,7 +607,7 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, int layer0_p
                                dim3(256), 0, stream, layer0, layer0_stride, layer0_pitch, coarse, coarse_stride, layer_stride,
                                n_layers - 1, w, h, border, skip_layers, contrast_threshold, gx, gy, gz, aligned, slots, counts);
         };
-        if (frames >= 8) scan(scan_extrema<64>, 64);
+        if ((long)frames * w * h >= 2000000L) scan(scan_extrema<64>, 64);
         else scan(scan_extrema<32>, 32);
         hipLaunchKernelGGL(cubes_block_sums, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts, n, sums);
     }
