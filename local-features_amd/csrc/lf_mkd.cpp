@@ -931,11 +931,14 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
     if (fork)
         if (int rc = ensure_side_stream(h, 2)) return rc;
     LF_HIP(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    // (the a-trous stack is queued from inside, ahead of the branch: see launch_build_pyramid)
     launch_build_pyramid(d_image, long(width) * height, h->d_pyr, h->pyr_stride, h->d_tmp_a, h->d_tmp_b, h->pd, 1,
                          h->pd.levels >= 2 ? h->d_coarse : nullptr, h->coarse_stride, s, fork ? h->side_stream : nullptr,
-                         fork ? h->side_events[0] : nullptr, fork ? h->side_events[1] : nullptr);
-    launch_build_coarse_stack(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride,
-                              h->d_tmp_a, h->n_layers, h->pd.levels >= 2 ? 1 : 0, int(width), int(height), 1, s);
+                         fork ? h->side_events[0] : nullptr, fork ? h->side_events[1] : nullptr, [&] {
+                             launch_build_coarse_stack(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse,
+                                                       h->coarse_stride, h->layer_stride, h->d_tmp_a, h->n_layers,
+                                                       h->pd.levels >= 2 ? 1 : 0, int(width), int(height), 1, s);
+                         });
     launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride,
                           h->n_layers, int(width), int(height), 1, kBorder, kSkipLayers, kContrastThreshold, h->d_slots,
                           h->d_cube_counts, h->d_cube_sums, h->d_det_extrema, nullptr, nullptr, h->max_extrema, cnt + 0, s);

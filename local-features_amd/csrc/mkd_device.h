@@ -2,6 +2,8 @@
 // mkd_orient.hip, mkd_detect.hip, mkd_match.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <functional>
 #include <stdint.h>
 
 #define LF_ANGLE_SHADER 0
@@ -63,7 +65,7 @@ void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidD
 void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,
                           float *tmp_b, const PyramidDesc &pd, int frames, float *layer1, long layer1_stride,
                           hipStream_t stream, hipStream_t rest_stream = nullptr, hipEvent_t fork = nullptr,
-                          hipEvent_t join = nullptr);
+                          hipEvent_t join = nullptr, const std::function<void()> &main_next = {});
 
 // a-trous layers 1 .. n_layers-1 over layer0 (= pyramid level 0); tmp holds frames x w x h floats
 void launch_build_coarse_stack(const float *layer0, long layer0_stride, int layer0_pitch, float *coarse, long coarse_stride,
