@@ -791,13 +791,22 @@ int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height
     const bool share = h->d_coarse != nullptr && h->pd.levels >= 2;
     if (share)
         if (int rc = ensure_side_stream(h, 2)) return rc;
+    // (with the branch, the rest of the a-trous stack is queued from inside, ahead of it: see launch_build_pyramid)
+    bool stack_queued = false;
+    std::function<void()> stack_first;
+    if (share)
+        stack_first = [&] {
+            launch_build_coarse_stack(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride,
+                                      h->layer_stride, h->d_tmp_a, h->n_layers, 1, int(width), int(height), 1, s);
+            stack_queued = true;
+        };
     launch_build_pyramid(h->d_image, long(width) * height, h->d_pyr, h->pyr_stride, h->d_tmp_a, h->d_tmp_b, h->pd, 1,
                          share ? h->d_coarse : nullptr, h->coarse_stride, s, share ? h->side_stream : nullptr,
-                         share ? h->side_events[0] : nullptr, share ? h->side_events[1] : nullptr);
+                         share ? h->side_events[0] : nullptr, share ? h->side_events[1] : nullptr, stack_first);
     LF_HIP(h, hipGetLastError());
     h->coarse_l1_valid = share;
     h->have_image = true;
-    h->coarse_valid = false;
+    h->coarse_valid = stack_queued;
     h->n_frames = 1;
     // detect graph: extrema, at most max_extrema of them (mod.rs:625-633)
     if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, h->max_extrema, sizeof(lf_mkd_extremum))) return rc;
