@@ -418,52 +418,60 @@ __global__ __launch_bounds__(1024) void topk_filter(const float *__restrict__ ex
     }
 }
 
-// The same selection for ONE long list (a 4K frame yields tens of thousands of extrema), spread over the chip, in six
-// launches: one histogram launch per radix byte, then the ordered compaction in two.  There is no launch that "picks the
-// bin" between them: each byte has its own histogram, and every workgroup of a later launch replays the picks of the
-// bytes before (a 256-bin scan each) -- a dependent launch costs ~5 us of the frame's critical path, the replay a
-// fraction of a microsecond.  work (u32): [0, 1024) the four histograms (zeroed by the scatter launch when everybody
-// is done with them, and by the host when the buffer is allocated), [1024] cutoff key, [1040...) block sums of the compaction.
-constexpr int kTopkState = 1024, kTopkSums = 1040;
+// The same selection for ONE long list (a 4K frame yields tens of thousands of extrema), spread over the chip, in five
+// launches: one histogram launch per radix digit, then the ordered compaction in two.  The key (float bits of a
+// non-negative contrast: bit 31 clear) is cut into digits of 11, 11 and 9 bits -- three histogram launches instead of one per
+// byte (a dependent launch costs ~5 us of the frame's critical path; the top BYTE of such keys takes three values and
+// selects next to nothing).  There is no launch that "picks the bin" between them: each digit has its own histogram, and
+// every workgroup of a later launch replays the picks of the digits before (a scan of <= 2048 bins each).
+// work (u32): [0, 3 x 2048) the three histograms (zeroed by the scatter launch when everybody is done with them, and by
+// the host when the buffer is allocated), [kTopkState] cutoff key, [kTopkSums...) block sums of the compaction.
+constexpr int kTopkDigits = 3, kTopkBins = 2048;
+constexpr int kTopkState = kTopkDigits * kTopkBins, kTopkSums = kTopkState + 16;
+__device__ __forceinline__ constexpr int topk_shift(int q) { return q == 0 ? 20 : (q == 1 ? 9 : 0); }
+__device__ __forceinline__ constexpr unsigned topk_digit_mask(int q) { return q == 2 ? 511u : 2047u; }
+// bits above digit q (they must equal the prefix found so far)
+__device__ __forceinline__ constexpr unsigned topk_above(int q) { return q == 0 ? 0u : (q == 1 ? 0xFFF00000u : 0xFFFFFE00u); }
 
-// the state after `passes` bytes: prefix of the wanted key, its rank inside that prefix; done = everything that passes
-// min_size is kept (first byte only).  All threads of the workgroup call it (>= 256 threads).
+// the state after `passes` digits: prefix of the wanted key, its rank inside that prefix; done = everything that passes
+// min_size is kept (first digit only).  All 1024 threads of the workgroup call it; thread t owns bins 2047 - 2t and
+// 2046 - 2t (prefix sums walk down from the top bin).
 __device__ void topk_replay(const unsigned *__restrict__ hist, int passes, unsigned n_keep, unsigned &prefix,
                             unsigned &rank, bool &done) {
-    __shared__ unsigned ws[4], s_prefix, s_rank, s_done;
+    __shared__ unsigned ws[16], s_prefix, s_rank, s_done;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     prefix = 0;
     rank = n_keep;          // rank wanted (0-based, descending)
     done = false;
     for (int q = 0; q < passes; ++q) {
-        const int shift = 24 - 8 * q;
-        unsigned c = 0, incl = 0;
-        if (threadIdx.x < 256) {
-            c = hist[q * 256 + 255 - threadIdx.x];   // thread t takes bin 255 - t: prefix sums walk down from the top
-            incl = c;
+        const int shift = topk_shift(q);
+        const int hi_bin = kTopkBins - 1 - 2 * (int)threadIdx.x;
+        const unsigned c_hi = hist[q * kTopkBins + hi_bin], c_lo = hist[q * kTopkBins + hi_bin - 1];
+        const unsigned c = c_hi + c_lo;
+        unsigned incl = c;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned t = __shfl_up(incl, o);
-                if (lane >= o) incl += t;
-            }
-            if (lane == 63) ws[wave] = incl;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
         }
+        if (lane == 63) ws[wave] = incl;
         if (threadIdx.x == 0) s_done = 0;
         __syncthreads();
-        if (threadIdx.x < 256) {
-            unsigned before = 0, all = 0;
+        unsigned before = 0, all = 0;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                before += v < wave ? ws[v] : 0u;
-                all += ws[v];
-            }
-            const unsigned excl = before + incl - c;
-            if (q == 0 && all <= n_keep) {               // the first histogram counts everything that passes min_size
-                if (threadIdx.x == 0) s_done = 1;
-            } else if (c != 0 && rank >= excl && rank < excl + c) {
-                s_prefix = prefix | ((255u - threadIdx.x) << shift);
-                s_rank = rank - excl;
-            }
+        for (int v = 0; v < 16; ++v) {
+            before += v < wave ? ws[v] : 0u;
+            all += ws[v];
+        }
+        const unsigned excl = before + incl - c;
+        if (q == 0 && all <= n_keep) {               // the first histogram counts everything that passes min_size
+            if (threadIdx.x == 0) s_done = 1;
+        } else if (c_hi != 0 && rank >= excl && rank < excl + c_hi) {
+            s_prefix = prefix | ((unsigned)hi_bin << shift);
+            s_rank = rank - excl;
+        } else if (c_lo != 0 && rank >= excl + c_hi && rank < excl + c) {
+            s_prefix = prefix | ((unsigned)(hi_bin - 1) << shift);
+            s_rank = rank - excl - c_hi;
         }
         __syncthreads();
         done = s_done != 0;
@@ -478,16 +486,16 @@ __device__ void topk_replay(const unsigned *__restrict__ hist, int passes, unsig
 __global__ __launch_bounds__(1024) void topk_hist(const float *__restrict__ extrema, const unsigned long long *__restrict__ n_in,
                                                   unsigned long long n_host, float min_size, int pass, unsigned n_keep,
                                                   unsigned *__restrict__ work) {
-    __shared__ unsigned lh[16][256];   // one histogram per wave: lanes of different waves never collide
+    __shared__ unsigned lh[4][kTopkBins];   // one histogram per four waves (32 KiB)
     unsigned prefix, rank;
     bool done;
     topk_replay(work, pass, n_keep, prefix, rank, done);
     if (done) return;
-    const int shift = 24 - 8 * pass;
+    const int shift = topk_shift(pass);
     const unsigned n = (unsigned)(n_in ? n_in[0] : n_host);
-    const unsigned mask = shift == 24 ? 0u : 0xFFFFFFFFu << (shift + 8);
-    const int wave = threadIdx.x >> 6;
-    for (int b = threadIdx.x; b < 16 * 256; b += 1024) (&lh[0][0])[b] = 0;
+    const unsigned above = topk_above(pass), dmask = topk_digit_mask(pass);
+    const int copy = threadIdx.x >> 8;
+    for (int b = threadIdx.x; b < 4 * kTopkBins; b += 1024) (&lh[0][0])[b] = 0;
     __syncthreads();
     float sz[4], ct[4];
 #pragma unroll
@@ -500,14 +508,12 @@ __global__ __launch_bounds__(1024) void topk_hist(const float *__restrict__ extr
     for (int j = 0; j < 4; ++j) {
         const unsigned i = blockIdx.x * 4096u + threadIdx.x + 1024u * j;
         const unsigned k = __float_as_uint(fabsf(ct[j]));
-        if (i < n && sz[j] >= min_size && (k & mask) == prefix) atomicAdd(&lh[wave][(k >> shift) & 255u], 1u);
+        if (i < n && sz[j] >= min_size && (k & above) == prefix) atomicAdd(&lh[copy][(k >> shift) & dmask], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 256) {
-        unsigned t = 0;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) t += lh[v][threadIdx.x];
-        if (t) atomicAdd(&work[pass * 256 + threadIdx.x], t);
+    for (int b = threadIdx.x; b < kTopkBins; b += 1024) {
+        const unsigned t = lh[0][b] + lh[1][b] + lh[2][b] + lh[3][b];
+        if (t) atomicAdd(&work[pass * kTopkBins + b], t);
     }
 }
 
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(1024) void topk_sums(const float *__restrict__ extr
     __shared__ unsigned ws[16];
     unsigned prefix, rank;
     bool done;
-    topk_replay(work, 4, n_keep, prefix, rank, done);
+    topk_replay(work, kTopkDigits, n_keep, prefix, rank, done);
     const unsigned cutoff = done ? 0u : prefix;      // key threshold; 0 keeps everything that passes min_size
     if (blockIdx.x == 0 && threadIdx.x == 0) work[kTopkState] = cutoff;
     const unsigned n = (unsigned)(n_in ? n_in[0] : n_host);
@@ -578,7 +584,8 @@ __global__ __launch_bounds__(1024) void topk_scatter(const float *__restrict__ e
         }
     }
     // the histograms were last read by the launch before this one: ready for the next list
-    if (blockIdx.x == 0) work[threadIdx.x] = 0;
+    if (blockIdx.x == 0)
+        for (int b = threadIdx.x; b < kTopkDigits * kTopkBins; b += 1024) work[b] = 0;
 }
 
 void scan_grid(int w, int h, int n_fine, int border, int skip_layers, int &gx, int &gy, int &gz) {
@@ -626,7 +633,7 @@ void launch_topk_filter(const float *extrema, const unsigned *seg_start, const u
     // one frame with a long list and scratch to work in: the multi-workgroup form; otherwise one workgroup per frame
     if (n_frames == 1 && !seg_start && work && n_cap > 8192 && seg_cap >= n_cap) {
         const unsigned nb4 = (unsigned)((n_cap + 4095) / 4096), nb1 = (unsigned)((n_cap + 1023) / 1024);
-        for (int pass = 0; pass < 4; ++pass)
+        for (int pass = 0; pass < kTopkDigits; ++pass)
             hipLaunchKernelGGL(topk_hist, dim3(nb4), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, pass, n_keep,
                                work);
         hipLaunchKernelGGL(topk_sums, dim3(nb1), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, n_keep, work);
