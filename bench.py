@@ -85,19 +85,77 @@ def cpu_baseline(seconds, seed):
                       "LUTs and whitening matrix built once (the reference rebuilds them per patch)"}
 
 
+def smooth_frames(torch, count, h, w, sigma, seed):
+    """`count` frames of smooth noise in [0, 1] (uniform noise blurred with a Gaussian of `sigma`), synthesised on the GPU
+    (keypoint-mode inputs)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.rand((count, 1, h, w), device="cuda", generator=g)
+    r = int(3 * sigma)
+    k = torch.exp(-0.5 * (torch.arange(-r, r + 1, device="cuda") / sigma) ** 2)
+    k /= k.sum()
+    x = torch.nn.functional.conv2d(x, k.view(1, 1, 1, -1), padding=(0, r))
+    x = torch.nn.functional.conv2d(x, k.view(1, 1, -1, 1), padding=(r, 0))
+    lo, hi = x.amin(dim=(2, 3), keepdim=True), x.amax(dim=(2, 3), keepdim=True)
+    return ((x - lo) / (hi - lo))[:, 0].contiguous()
+
+
+def configs3_keypoint_leg(args, lfp, torch, sharding, rank, world, local_rank):
+    """BASELINE configs[3] in its own form, this rank's share: frames shard by image (sharding.frames_of_rank: global frame
+    f lives on rank f mod N), every rank builds the pyramids of ITS frames only and describes their given
+    keypoints -- 128 frames of 1920x1080 with 8192 keypoints each per GPU = 2^20 descriptors, one set_images + one describe
+    call per step (the reference's unit of work is an image: vulkan/mod.rs:363-453).  No collective inside: the rank's own
+    HIP-event time; the caller gathers the per-rank results."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gen_golden import random_keypoints
+    w, h = 1920, 1080
+    nf, nk = args.frames_per_gpu, args.kpts_per_image
+    mine = sharding.frames_of_rank(nf * world, rank, world)              # global indices of this rank's frames
+    n = nf * nk
+    hnd = lfp.MkdHandle(max_features=n, max_image_width=w, max_image_height=h, max_frames=nf, device=local_rank,
+                        flags=lfp.FLAG_KERNEL_TIMING)
+    # 16 distinct frames per rank (seeded by the global frame index they stand for), each used for nf / 16 of the rank's
+    # frames; every frame has its own keypoints (seeded by ITS global index)
+    nd = min(nf, 16)
+    base = smooth_frames(torch, nd, h, w, 2.0, 3000 + mine[0])
+    imgs = base[torch.arange(nf, device="cuda") % nd].contiguous()
+    del base
+    kps = torch.from_numpy(np.concatenate(
+        [np.concatenate([random_keypoints(nk, w, h, 7000 + g, margin=64.0), np.zeros((nk, 1), np.float32)], axis=1)
+         for g in mine]).astype(np.float32)).cuda()
+    fid = torch.arange(nf, device="cuda", dtype=torch.int32).repeat_interleave(nk).contiguous()
+    out = torch.empty((n, 128), device="cuda")
+    side = torch.cuda.current_stream()
+    s = side.cuda_stream
+
+    def one():
+        hnd.set_images_device(imgs.data_ptr(), nf, w, h, s)
+        hnd.describe_keypoints_frames_device(kps.data_ptr(), fid.data_ptr(), n, out.data_ptr(), s)
+    for _ in range(2):
+        one()
+    side.synchronize()
+    hnd.kernel_times()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = max(2, min(args.steps, 5))
+    e0.record(side)
+    for _ in range(iters):
+        one()
+    e1.record(side)
+    side.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    pool_ms, _, launches = hnd.kernel_times()
+    nrm = out.norm(dim=1)
+    ok = bool(torch.isfinite(out).all().item()) and float((nrm - 1).abs().max().item()) < 1e-4
+    alg = n * (16 + 512) + nf * w * h * 4
+    return {"ok": ok, "ms_per_call": ms, "descriptors": n, "frames": nf, "first_global_frames": mine[:3],
+            "describe_kernel_ms": pool_ms / max(launches, 1), "algorithmic_bytes_per_call": alg}
+
+
 def pipeline_extras(lfp, torch, device):
     """Secondary figures (rank 0, N = 1, never allowed to break the headline line): the rows built around the describe
     path, on BASELINE.json's other configurations.  Smooth-noise frames synthesised on the GPU."""
     def frames(count, h, w, sigma, seed):
-        g = torch.Generator(device="cuda").manual_seed(seed)
-        x = torch.rand((count, 1, h, w), device="cuda", generator=g)
-        r = int(3 * sigma)
-        k = torch.exp(-0.5 * (torch.arange(-r, r + 1, device="cuda") / sigma) ** 2)
-        k /= k.sum()
-        x = torch.nn.functional.conv2d(x, k.view(1, 1, 1, -1), padding=(0, r))
-        x = torch.nn.functional.conv2d(x, k.view(1, 1, -1, 1), padding=(r, 0))
-        lo, hi = x.amin(dim=(2, 3), keepdim=True), x.amax(dim=(2, 3), keepdim=True)
-        return ((x - lo) / (hi - lo))[:, 0].contiguous()
+        return smooth_frames(torch, count, h, w, sigma, seed)
 
     side = torch.cuda.Stream()       # the library reads a NULL stream as "its own": time on a real one
     out = {}
@@ -314,6 +372,10 @@ def planted_descriptors(torch, n, per_img, rank, world):
     return out, want, crowded
 
 
+class StageFailed(Exception):
+    """A self-check of the match stage failed on some rank; raised on EVERY rank by match_stage's agree()."""
+
+
 def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehearsal, gathered, out, n):
     """configs[3] after the describe: descriptor shards -> all-gather -> cross-image brute-force match, once, timed.
     Every rank's `out` is already its own view of `gathered` (the describe wrote there), so the gather copies nothing
@@ -347,6 +409,18 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
         mine = (time.perf_counter() - t0) * 1e3
         return sharding.max_over_ranks(mine / 1e3, "cpu" if rehearsal else "cuda") * 1e3, mine
 
+    def agree(ok_local, what):
+        """Every rank calls this at the same points with its own verdict: one all-reduce (MIN) of an ok flag, so that a
+        failed self-check on ONE rank makes EVERY rank leave the stage together instead of the failing rank stopping to
+        issue collectives while its peers wait in the next one."""
+        good = bool(ok_local)
+        if dist is not None:
+            flag = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            good = bool(int(flag.item()))
+        if not good:
+            raise StageFailed(what + ("" if ok_local else f" [failed on rank {rank}]"))
+
     comm = None
     if world > 1:
         # the gather goes through the C boundary (lf_mkd_allgather_descriptors over RCCL: what the Rust crate calls);
@@ -358,6 +432,14 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
             except Exception as e:
                 res["comm_error"] = f"{type(e).__name__}: {e}"
                 comm = None
+            # every rank takes the same branch (sharding.py): the C-boundary transport only if EVERY rank has its
+            # communicator; otherwise those that have one close it and all fall back to torch.distributed together
+            made = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(made, op=dist.ReduceOp.MIN)
+            if not int(made.item()) and comm is not None:
+                comm.close()
+                comm = None
+                res["comm_error"] = "another rank could not create its communicator"
         res["allgather_transport"] = "lf_mkd_allgather_descriptors (RCCL, C boundary)" if comm else "torch.distributed"
         for mode in ("direct", "ring"):
             run = lambda: sharding.all_gather_descriptors(out, mode=mode, out=gathered, counts=counts, comm=comm)
@@ -369,8 +451,7 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
         res["allgather_ms"] = min(res["allgather_direct_ms"], res["allgather_ring_ms"])
         # every shard must have arrived: row norms of the whole gathered set are 1
         nrm = gathered.norm(dim=1)
-        if not bool(((nrm - 1).abs() < 1e-4).all().item()):
-            raise SystemExit("bench.py: gathered descriptors are not all unit norm (a shard did not arrive)")
+        agree(bool(((nrm - 1).abs() < 1e-4).all().item()), "gathered descriptors are not all unit norm (a shard did not arrive)")
     else:
         res["allgather_ms"] = 0.0
     lo, hi = sharding.exclusion_ranges(sizes, rank * n, "cuda")
@@ -393,8 +474,8 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
         # accepted matches point outside the query's own image, and every best similarity is a valid cosine
         acc = m >= 0
         bad = acc & (m >= lo) & (m < hi)
-        if bool(bad.any().item()) or not bool((best.abs() <= 1.0 + 1e-4).all().item()):
-            raise SystemExit(f"bench.py: cross-image match ({tag}) returned a candidate inside the query's own image")
+        agree(not bool(bad.any().item()) and bool((best.abs() <= 1.0 + 1e-4).all().item()),
+              f"cross-image match ({tag}) returned a candidate inside the query's own image")
         r["accepted_fraction"] = float(acc.float().mean().item())
         return r, acc
 
@@ -405,16 +486,15 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
     hm.match_device(out.data_ptr(), n, gathered.data_ptr(), world * n, m.data_ptr(), 0.0, lo.data_ptr(), hi.data_ptr(),
                     best.data_ptr(), None, s)
     torch.cuda.synchronize()
-    if not bool((m >= 0).all().item()) or bool(((m >= lo) & (m < hi)).any().item()):
-        raise SystemExit("bench.py: with ratio 0 every row must return a candidate outside its own image")
+    agree(bool((m >= 0).all().item()) and not bool(((m >= lo) & (m < hi)).any().item()),
+          "with ratio 0 every row must return a candidate outside its own image")
     pick = torch.arange(0, n, max(1, n // 64), device="cuda")[:64]
     sim = out[pick] @ gathered.T
     for i, row in enumerate(pick.tolist()):
         sim[i, int(lo[row]):int(hi[row])] = -2.0
     ref = sim.argmax(dim=1)
     same = (ref == m[pick].long()) | ((sim.gather(1, m[pick].long()[:, None])[:, 0] - sim.max(dim=1).values).abs() < 2e-6)
-    if not bool(same.all().item()):
-        raise SystemExit("bench.py: the matcher's best candidate differs from a plain matrix product")
+    agree(bool(same.all().item()), "the matcher's best candidate differs from a plain matrix product")
     res.update(r1)
     res["what"] = ("each rank: its descriptors x the gathered set, own image excluded, ratio 0.8 "
                    "(examples/match_images/src/main.rs:8-27); ms = slowest rank; best candidates checked at ratio 0")
@@ -435,8 +515,8 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
         r2["what"] = ("image g's first quarter = image g-1's second quarter perturbed at 1e-2 (one partner per planted row, "
                       "either direction); rank 0 also holds 1024 near-duplicates of one vector and 12 288 queries next to it, "
                       "whose candidate rings overflow: those rows are redone by the full-precision scan")
-        if r2["planted_rows_recovered"] < 0.999:
-            raise SystemExit(f"bench.py: only {r2['planted_rows_recovered']:.4f} of the planted correspondences were matched")
+        agree(r2["planted_rows_recovered"] >= 0.999,
+              f"only {r2['planted_rows_recovered']:.4f} of the planted correspondences were matched")
         res["planted"] = r2
         del gathered_p, view
     if comm is not None:
@@ -448,7 +528,7 @@ def headline_line(args, world, n, total, dt, kern_s, achieved, alt, alt_f32, clo
     """The bench line without its match_stage / pipelines / cpu_baseline objects."""
     # HBM traffic of the kernel comes from rocprofv3 PMC passes (tools/profile_round.sh), which cannot run inside
     # this process: the committed figure is quoted only if it was measured on this very kernel source and workload
-    traffic = mfma_busy = projection = None
+    traffic = mfma_busy = projection = counters_from = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
@@ -458,6 +538,7 @@ def headline_line(args, world, n, total, dt, kern_s, achieved, alt, alt_f32, clo
                 traffic = tj.get("hbm_bytes_per_launch")
                 mfma_busy = tj.get("mfma_busy_frac")          # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles)
                 projection = tj.get("projection")             # the whitening stage on its own (phase clocks)
+                counters_from = f"profiles/traffic_latest.json@{tj.get('source_sha256')} (rocprofv3 --pmc, builder's box)"
         except Exception:
             traffic = None
     line = {
@@ -480,12 +561,16 @@ def headline_line(args, world, n, total, dt, kern_s, achieved, alt, alt_f32, clo
                      # constant 100 MHz counter; MI355X_MICROARCH.md DVFS give-back) -- boxes differ by several per cent
                      "shader_clock_mhz": clock_mhz, "workgroup0_ms": wg0_ms,
                      "mfma_busy_frac": mfma_busy, "projection": projection,
-                     # beside it, the arithmetic view (informative): the path's f32 arithmetic is a
-                     # [n x 1024] x [1024 x 238] pooling product + the 238 x 128 whitening; the matrix cores have no
-                     # f32-input rate above 157.3 TFLOP/s (MI355X_MICROARCH.md), the kernel buys its rate with f16 splits
-                     "f32_matrix_view": {"flop_per_descriptor": FLOP_PER_DESC,
-                                         "achieved": FLOP_PER_DESC * n / kern_s / 1e12, "peak": 157.3,
-                                         "unit": "TFLOP/s", "frac": FLOP_PER_DESC * n / kern_s / 1e12 / 157.3}},
+                     # achieved / kernel_ms / shader_clock_mhz are measured in THIS run; traffic, mfma_busy_frac and
+                     # projection are quoted from the committed rocprofv3 PMC passes of the same kernel source
+                     "counters_from": counters_from,
+                     # NOT a roofline of the kernel that ran (it issues f16 MFMAs): where an f32-input MFMA formulation of
+                     # the same arithmetic would be capped -- the path's nominal f32 flops over the f32 matrix peak
+                     "f32_formulation_bound": {"what": "bound of an f32-MFMA formulation (not the one that ran): nominal f32 "
+                                                       "flops of the path / this launch's time, against the f32 matrix peak",
+                                               "flop_per_descriptor": FLOP_PER_DESC,
+                                               "nominal_tflops": FLOP_PER_DESC * n / kern_s / 1e12, "f32_mfma_peak": 157.3,
+                                               "unit": "TFLOP/s"}},
         "match_stage": None,
     }
     return line
@@ -519,8 +604,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="seconds of CPU work for the CPU baseline (default ~12; 0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary pipeline figures")
     ap.add_argument("--no-match", action="store_true", help="skip the all-gather + cross-image match stage")
-    ap.add_argument("--kpts-per-image", type=int, default=8192, help="descriptors per image in the match stage "
-                    "(configs[3]: 8M keypoints over 1024 frames)")
+    ap.add_argument("--kpts-per-image", type=int, default=8192, help="descriptors per image in the match stage and "
+                    "keypoints per frame in the configs[3] keypoint-mode leg (configs[3]: 8M keypoints over 1024 frames)")
+    ap.add_argument("--frames-per-gpu", type=int, default=128, help="1920x1080 frames per GPU in the configs[3] "
+                    "keypoint-mode leg (configs[3]: 1024 frames over 8 GPUs); 0: skip the leg")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -626,28 +713,85 @@ def main():
     line = {}
 
     def emit_and_leave(reason):
+        """Watchdog: a rank stuck in a collective its peers never entered.  Rank 0 prints the headline line with the stage
+        marked, then every rank leaves at once with a NON-ZERO status (no destroy_process_group: it would wait for the stuck
+        collective; os._exit from this timer thread ends the process without re-executing anything)."""
         if rank == 0:
             line["match_stage"] = {"error": reason}
             print(json.dumps(line), flush=True)
-        os._exit(0)      # (no destroy_process_group: it would wait for the stuck collective)
+        sys.stderr.write(f"bench.py rank {rank}: {reason}\n")
+        sys.stderr.flush()
+        os._exit(3)
 
     import threading
     # the other ranks leave a little later than rank 0, so that the launcher does not tear rank 0 down before it has printed
     limit = float(os.environ.get("LF_BENCH_STAGE_LIMIT_S", "300")) + (0.0 if rank == 0 else 20.0)
     stage = None
+    failed = None          # why this run must end with a non-zero status although its line was printed
+    desync = False         # an exception on this rank alone: its peers may be waiting in a collective
     if rank == 0:
         line.update(headline_line(args, world, n, total, dt, kern_s, achieved, alt, alt_f32, clock_mhz, wg0_ms))
+
+    # configs[3] in its own form (keypoint mode, frames sharded by image): every rank runs its share, with no collective
+    # inside; one object gather afterwards, reached by every rank whatever happened locally
+    if args.frames_per_gpu > 0:
+        dog = threading.Timer(limit, emit_and_leave, args=(f"configs[3] keypoint-mode leg did not finish within {limit:.0f} s",))
+        dog.daemon = True
+        dog.start()
+        try:
+            leg = configs3_keypoint_leg(args, lfp, torch, sharding, rank, world, local_rank)
+        except Exception as e:
+            leg = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+        legs = [leg]
+        if dist is not None:
+            legs = [None] * world
+            dist.all_gather_object(legs, leg)
+        dog.cancel()
+        torch.cuda.empty_cache()
+        if rank == 0:
+            good = [g for g in legs if g.get("ok")]
+            kp = {"what": "BASELINE configs[3] as written, per GPU: frames sharded by image (frame f on rank f mod N), "
+                          f"{args.frames_per_gpu} frames 1920x1080 x {args.kpts_per_image} given keypoints, keypoint mode: "
+                          "set_images (pyramids of the rank's own frames) + describe (one launch, patches sampled inside the "
+                          "describe kernel), one call each per step; every rank's own HIP-event time, no collective",
+                  "ranks_ok": len(good), "ranks": world,
+                  "ms_per_call_per_rank": [round(g["ms_per_call"], 3) if g.get("ok") else None for g in legs],
+                  "describe_kernel_ms_per_rank": [round(g["describe_kernel_ms"], 3) if g.get("ok") else None for g in legs],
+                  "errors": [g.get("error") for g in legs if not g.get("ok")] or None}
+            if len(good) == world:
+                slow = max(g["ms_per_call"] for g in good)
+                ndesc = sum(g["descriptors"] for g in good)
+                alg = good[0]["algorithmic_bytes_per_call"]
+                ach = alg / (slow * 1e-3) / 1e9
+                kp.update({"descriptors_per_s": ndesc / (slow * 1e-3), "descriptors_per_s_per_gpu": ndesc / world / (slow * 1e-3),
+                           "describe_only_descriptors_per_s_per_gpu":
+                               good[0]["descriptors"] / (max(g["describe_kernel_ms"] for g in good) * 1e-3),
+                           "frames_of_rank0": good[0]["first_global_frames"],
+                           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                        "algorithmic_bytes_per_call": alg,
+                                        "algorithmic_bytes_per_descriptor": alg / good[0]["descriptors"],
+                                        "what": "per GPU: 528 B per keypoint (16 in, 512 out) + the frames' bytes, over the "
+                                                "slowest rank's set_images + describe time",
+                                        "kernels": "pyr_* + mkd_pool<.., keypoints> (no patch crosses HBM)"}})
+            else:
+                failed = "configs[3] keypoint-mode leg failed on a rank"
+            line["configs3_keypoint_mode"] = kp
+
     if not args.no_match:
         dog = threading.Timer(limit, emit_and_leave, args=(f"match stage did not finish within {limit:.0f} s",))
         dog.daemon = True
         dog.start()
         try:
             stage = match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehearsal, gathered, out, n)
-        except SystemExit as e:          # a failed self-check of the stage: reported in its place, loudly
+        except StageFailed as e:         # a failed self-check, agreed by every rank (match_stage.agree): all are in step
             stage = {"error": f"FAILED CHECK: {e}"}
-            sys.stderr.write(f"bench.py rank {rank}: match stage failed a self-check: {e}\n")
-        except Exception as e:           # reported, not fatal: the headline is the describe figure
+            failed = f"match stage failed a self-check: {e}"
+            sys.stderr.write(f"bench.py rank {rank}: {failed}\n")
+        except Exception as e:           # on this rank alone: reported in the stage's place; the peers may be mid-collective
             stage = {"error": f"{type(e).__name__}: {e}"}
+            failed = f"match stage raised {type(e).__name__}"
+            desync = world > 1
         finally:
             dog.cancel()
 
@@ -664,8 +808,18 @@ def main():
             if args.cpu_sample != 0:                                  # seconds of CPU work (default about 12; 0: skip)
                 line["cpu_baseline"] = cpu_baseline(12.0 if args.cpu_sample < 0 else float(args.cpu_sample), 0x4D4B44)
         print(json.dumps(line), flush=True)
+    # The line is out.  A failed stage ends the run with status 3 so that the driver's rc shows it (the line itself carries
+    # the reason).  If only this rank failed, its peers may sit in a collective: leave without the group's teardown, which
+    # would wait for them (their own watchdogs end them, also with 3).  Never a re-exec: a plain exit of this process.
+    if desync:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(3)
     if dist is not None:
         dist.destroy_process_group()
+    if failed:
+        sys.stderr.write(f"bench.py rank {rank}: exiting 3: {failed}\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

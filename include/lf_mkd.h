@@ -333,7 +333,8 @@ int lf_mkd_sample_patches_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64
                                  float *d_patches, void *stream);
 /* Copies pyramid level `level` ((w>>level) x (h>>level) f32) to a host buffer. */
 int lf_mkd_get_pyramid_level(lf_mkd *h, uint32_t level, float *out, uint32_t *w, uint32_t *hgt);
-/* The same level as the sampler addresses it: with its apron of *apron texels on every side (0 for level 0), which holds
+/* The same level as the sampler addresses it: with its apron of *apron texels on every side (48 on EVERY level, level 0 included: size
+ * the buffer from the returned *apron, never from a constant), which holds
  * what MirroredRepeat addressing (mod.rs:940-943) would fetch there -- (hgt + 2 apron) rows of (w + 2 apron) floats.
  * Any of out / w / hgt / apron may be NULL. */
 int lf_mkd_get_pyramid_level_apron(lf_mkd *h, uint32_t level, float *out, uint32_t *w, uint32_t *hgt, uint32_t *apron);

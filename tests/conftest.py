@@ -56,6 +56,17 @@ def golden(name):
 #   * different input bits (keypoint mode: the sampler rounds differently) -> descriptors of unsettled patches,
 #     in either side's patch, are set aside (and must be few).
 GATE = 1e-4
+# Drift bar: the worst SETTLED error any parity helper has seen stays well inside the gate (round 3's worst: 3.5e-5, the 4K
+# frame end to end, where a sample coordinate near 3840 has a 2.4e-4-texel ulp).  A helper call whose settled rows exceed
+# this fails its own test, so a drift toward the gate shows up long before the gate does.
+DRIFT = 5e-5
+WORST = {"value": 0.0, "what": "-", "test": "-"}
+
+
+def _note_worst(value, what):
+    if value > WORST["value"]:
+        WORST.update(value=float(value), what=str(what),
+                     test=os.environ.get("PYTEST_CURRENT_TEST", "-").split(" ")[0])
 
 
 # every parity helper call leaves one line here; printed at the end of the run (also under -q) and appended to
@@ -79,6 +90,14 @@ def pytest_terminal_summary(terminalreporter):
         terminalreporter.write_sep("-", "parity helpers: patches set aside, and why")
         for line in PARITY_REPORT:
             terminalreporter.write_line(line)
+        line = (f"[parity margin] worst settled relative L2 of this run: {WORST['value']:.2e} ({WORST['what']}; {WORST['test']}); "
+                f"drift bar {DRIFT:.0e}, gate {GATE:.0e}")
+        terminalreporter.write_line(line)
+        try:
+            with open(os.path.join(ROOT, "gpurun_out", "parity_report.txt"), "a") as f:
+                f.write(line + "\n")
+        except OSError:
+            pass
 
 
 def settled_detail(oracle, patches, atan_mode, gate=GATE):
@@ -119,7 +138,10 @@ def assert_patch_parity(oracle, patches, desc, atan_mode, gate=GATE, what="", mi
     assert e_c.max(initial=0.0) < gate, (what, "contracted", int(e_c.argmax()), e_c.max())
     assert clean.mean() > min_settled, (what, clean.mean())
     assert e_s[clean].max(initial=0.0) < gate, (what, "uncontracted", e_s[clean].max())
-    return max(e_c.max(initial=0.0), e_s[clean].max(initial=0.0))
+    worst = max(e_c.max(initial=0.0), e_s[clean].max(initial=0.0))
+    _note_worst(worst, what or "patch parity")
+    assert worst < min(gate, DRIFT), (what, "drift bar", worst)
+    return worst
 
 
 def assert_keypoint_parity(oracle, handle, img, kps5, desc, gate=GATE, what="", patch_tol=1e-5, min_settled=0.97):
@@ -150,3 +172,5 @@ def assert_keypoint_parity(oracle, handle, img, kps5, desc, gate=GATE, what="", 
             f"worst settled {e[clean].max(initial=0.0):.2e}")
     assert clean.mean() > min_settled, (what, clean.mean())
     assert e[clean].max(initial=0.0) < gate, (what, "end to end", e[clean].max())
+    _note_worst(e[clean].max(initial=0.0), (what or "keypoint parity") + " (end to end)")
+    assert e[clean].max(initial=0.0) < min(gate, DRIFT), (what, "drift bar, end to end", e[clean].max())

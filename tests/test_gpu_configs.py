@@ -1,6 +1,7 @@
 """BASELINE.json's configurations at their own sizes, against the oracle (GPU).
 
-configs[1]: 10 000 keypoints on one 1920x1080 frame      configs[3]: the per-GPU share, 2^20 patches
+configs[1]: 10 000 keypoints on one 1920x1080 frame      configs[3]: the per-GPU share, in its own form (128 frames of
+1920x1080 with 8192 given keypoints each, keypoint mode) and as 2^20 patches (SURVEY 8(d)'s headline form)
 (configs[2] and configs[4] live in test_gpu_detector.py / test_gpu_parity.py next to the pipelines they exercise;
  configs[0] -- the reference's match_images on its own two photographs -- is below.)"""
 import os
@@ -59,6 +60,66 @@ def test_configs3_per_gpu_share_of_2pow20_patches(lfp, torch, oracle):
     assert torch.equal(out, out3)
 
 
+def test_configs3_own_form_128_frames_1080p_8192_keypoints_each(lfp, torch, oracle):
+    """BASELINE configs[3] as it is written, the share of one GPU: "8M kpts over 1024 1080p frames sharded by image across
+    8 x MI355X" = 128 frames of 1920x1080 with 8192 given keypoints each (2^20 descriptors), keypoint mode, through
+    set_images_device + describe_keypoints_frames_device in ONE call (the reference's unit of work is an image:
+    vulkan/mod.rs:363-453).  Finite and unit-norm over all of them, a 1000-row re-request and a second run give the same
+    bits, 256 rows of each of 8 frames against the oracle end to end (pyramid -> sampling -> describe).  The frames a rank
+    holds are those of sharding.frames_of_rank: here rank 3 of 8, i.e. global frames 3, 11, 19, ..."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gen_golden import random_keypoints, smooth_image
+    from local_features_python import sharding
+    w, hgt, nf, nk, world, rank = 1920, 1080, 128, 8192, 8, 3
+    n = nf * nk
+    mine = sharding.frames_of_rank(nf * world, rank, world)                # global indices of this rank's frames
+    assert len(mine) == nf and mine[0] == rank and mine[1] == rank + world
+    # 8 distinct frames (a 1080p frame takes the CPU 0.4 s), each used for 16 of the rank's frames with its own keypoints
+    base = [np.ascontiguousarray(smooth_image(hgt, w, 500 + f), np.float32) for f in range(8)]
+    k5 = np.concatenate([np.concatenate([random_keypoints(nk, w, hgt, 9000 + g, margin=64.0), np.zeros((nk, 1), np.float32)],
+                                        axis=1) for g in mine]).astype(np.float32)
+    fid = np.repeat(np.arange(nf, dtype=np.int32), nk)
+    d_img = torch.stack([torch.from_numpy(base[g % 8]) for g in mine]).cuda().contiguous()      # 1.06 GB
+    d_k, d_f = torch.from_numpy(k5).cuda(), torch.from_numpy(fid).cuda()
+    out = torch.empty((n, 128), device="cuda")
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    h = lfp.MkdHandle(max_features=n, max_image_width=w, max_image_height=hgt, max_frames=nf)
+    h.set_images_device(d_img.data_ptr(), nf, w, hgt, stream.cuda_stream)
+    h.describe_keypoints_frames_device(d_k.data_ptr(), d_f.data_ptr(), n, out.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    assert bool(torch.isfinite(out).all())
+    assert float((out.norm(dim=1) - 1).abs().max()) < 1e-5
+    # a descriptor depends on its own keypoint and frame only: 1000 rows from all over the batch in a request of their own
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    idx = torch.sort(torch.randint(0, n, (1000,), device="cuda", generator=gen)).values
+    idx[0], idx[-1] = 0, n - 1
+    sub_k, sub_f = d_k[idx].contiguous(), d_f[idx].contiguous()
+    out2 = torch.empty((1000, 128), device="cuda")
+    torch.cuda.synchronize()
+    h.describe_keypoints_frames_device(sub_k.data_ptr(), sub_f.data_ptr(), 1000, out2.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    assert torch.equal(out2, out[idx])
+    # a second run of the whole call (pyramids rebuilt) gives the same bits
+    out3 = torch.empty_like(out)
+    h.set_images_device(d_img.data_ptr(), nf, w, hgt, stream.cuda_stream)
+    h.describe_keypoints_frames_device(d_k.data_ptr(), d_f.data_ptr(), n, out3.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    assert torch.equal(out, out3)
+    got = out.cpu().numpy()
+    del h, out, out3, d_img
+    torch.cuda.empty_cache()
+    # 256 rows of each of 8 of the rank's frames against the oracle, end to end
+    one = lfp.MkdHandle(max_features=256, max_image_width=w, max_image_height=hgt)
+    rng = np.random.default_rng(7)
+    for f in (0, 1, 9, 42, 64, 77, 126, 127):
+        rows = f * nk + np.sort(rng.choice(nk, 256, replace=False))
+        one.set_image(base[mine[f] % 8])
+        # (coordinates reach 1920: see test_configs1)
+        assert_keypoint_parity(oracle, one, base[mine[f] % 8], k5[rows], got[rows], what=f"configs[3] local frame {f}",
+                               patch_tol=5e-5)
+
+
 def test_configs1_10k_keypoints_on_a_1080p_frame(lfp, torch, oracle):
     """10 000 keypoints on one 1920x1080 frame: unit norm and batch-independence over all of them, a 1000-row sample
     against the oracle end to end (pyramid -> sampling -> describe)."""
@@ -105,10 +166,12 @@ def test_configs0_match_images_on_the_reference_photographs(lfp, oracle):
     hgt, w = img2.shape
     h = lfp.MkdHandle(max_features=3000, max_image_width=w, max_image_height=hgt, n_scales=5)
     h.set_image(img2)
-    pick = np.arange(0, len(got), max(1, len(got) // 512))[:512]
-    # (an 8-bit photograph has flat areas -- sky, walls -- where gx is 0 up to the rounding of the bilinear blend: more
-    #  patches than on synthetic frames sit on the shader's gx == 0 discontinuity and are set aside, ~5 %)
-    assert_keypoint_parity(oracle, h, img2, got[pick], d2[pick], what="houses", patch_tol=1e-4, min_settled=0.9)
+    pick = np.arange(0, len(got), max(1, len(got) // 1024))[:1024]
+    # (an 8-bit photograph has flat areas -- sky, walls -- where gx is EXACTLY 0 after the blur of equal 8-bit values: more
+    #  patches than on synthetic frames sit on the shader's gx == 0 discontinuity and are set aside, 5 % of this
+    #  photograph's keypoints (profiles/r04_parity_report.txt); the bar for a photograph is therefore 0.93 on 1024 rows,
+    #  for synthetic frames the helper's default 0.97)
+    assert_keypoint_parity(oracle, h, img2, got[pick], d2[pick], what="houses", patch_tol=1e-4, min_settled=0.93)
     # the match lists are the oracle's on the same descriptors
     assert m12 == [(i, int(j)) for i, j in enumerate(oracle.match(d1, d2)[0]) if j >= 0]
     assert m21 == [(i, int(j)) for i, j in enumerate(oracle.match(d2, d1)[0]) if j >= 0]
@@ -117,7 +180,7 @@ def test_configs0_match_images_on_the_reference_photographs(lfp, oracle):
 def test_configs2_256_frames_640x480_2000_keypoints_each(lfp, torch, oracle):
     """BASELINE configs[2] at its own size: 256 frames of 640x480 with 2000 given keypoints each (512 000 descriptors)
     through set_images_device + describe_keypoints_frames_device in one call: finite and unit-norm over all of them, a
-    1000-row re-request gives the same bits, and 64 rows of each of 8 frames against the oracle end to end (pyramid ->
+    1000-row re-request gives the same bits, and 256 rows of each of 8 frames against the oracle end to end (pyramid ->
     sampling -> describe) through the same helper the small keypoint tests use."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from gen_golden import random_keypoints, smooth_image
@@ -156,14 +219,14 @@ def test_configs2_256_frames_640x480_2000_keypoints_each(lfp, torch, oracle):
     assert torch.equal(out, out3)
     got = out.cpu().numpy()
     del h, out, out3, d_img
-    # 64 rows of each of 8 frames against the oracle (a single-frame handle samples the same bits: one sampling arithmetic)
-    one = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt)
+    # 256 rows of each of 8 frames against the oracle (a single-frame handle samples the same bits: one sampling arithmetic);
+    # at 256 rows the settled fraction means something: the helper's default bar (0.97) applies
+    one = lfp.MkdHandle(max_features=256, max_image_width=w, max_image_height=hgt)
     rng = np.random.default_rng(6)
     for f in (0, 1, 17, 100, 129, 200, 254, 255):
-        rows = f * nk + np.sort(rng.choice(nk, 64, replace=False))
+        rows = f * nk + np.sort(rng.choice(nk, 256, replace=False))
         one.set_image(base[f % 16])
-        # (64 rows: three patches on the atan2 discontinuity are already 5 %)
-        assert_keypoint_parity(oracle, one, base[f % 16], k5[rows], got[rows], what=f"configs[2] frame {f}", min_settled=0.9)
+        assert_keypoint_parity(oracle, one, base[f % 16], k5[rows], got[rows], what=f"configs[2] frame {f}")
 
 
 def test_large_keypoint_batches_fused_and_two_launch_forms_agree(lfp, torch, oracle):
@@ -195,9 +258,9 @@ def test_large_keypoint_batches_fused_and_two_launch_forms_agree(lfp, torch, ora
     assert np.array_equal(a, b)                                            # one sampling arithmetic: the same bits
     # a sample of every chunk against the oracle, end to end, through the helper: the GPU-sampled patches of the picked
     # rows must meet the gate on every settled row (no allowance)
-    pick = np.arange(0, n, 160)
+    pick = np.arange(0, n, 64)                  # 312 rows of every frame: enough for the helper's default bar (0.97)
     one = lfp.MkdHandle(max_features=len(pick), max_image_width=w, max_image_height=hgt)
     for f in range(nf):
         sel = pick[fid[pick] == f]
         one.set_image(imgs[f])
-        assert_keypoint_parity(oracle, one, imgs[f], k5[sel], a[sel], what=f"large batch, frame {f}", min_settled=0.9)
+        assert_keypoint_parity(oracle, one, imgs[f], k5[sel], a[sel], what=f"large batch, frame {f}")
