@@ -141,6 +141,7 @@ class Comm:
     def __init__(self, handle, unique_id, n_ranks, rank):
         self._c = None
         self.handle, self.n_ranks, self.rank = handle, n_ranks, rank
+        self.calls = 0                  # lf_mkd_allgather_descriptors calls made through this communicator
         c = ctypes.c_void_p()
         ident = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
         handle._check(handle.L.lf_mkd_comm_create(handle._h, ident, n_ranks, rank, ctypes.byref(c)), "lf_mkd_comm_create")
@@ -156,6 +157,7 @@ class Comm:
     def allgather_descriptors(self, d_buf, counts, mode=GATHER_DIRECT, stream=None):
         """d_buf: device pointer of the [sum(counts)][128] f32 gathered set, this rank's rows already at their offset."""
         arr = (ctypes.c_uint64 * len(counts))(*[int(c) for c in counts])
+        self.calls += 1
         self.handle._device_call(stream, lambda s: self.handle.L.lf_mkd_allgather_descriptors(
             self.handle._h, self._c, arr, d_buf, mode, s), "lf_mkd_allgather_descriptors")
 

@@ -138,7 +138,9 @@ def cross_image_match(desc_local, image_sizes_local, match_fn, ratio=0.8, group=
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if sum(int(s) for s in image_sizes_local) != desc_local.shape[0]:
         raise ValueError("image_sizes_local must add up to the number of local descriptors")
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or comm is not None):
+        # (a world of one with a communicator still goes through the transport: lf_mkd_allgather_descriptors is then the
+        #  identity on the buffer, but it is the call a larger world makes)
         gathered, counts = all_gather_descriptors(desc_local, group, mode=mode, out=out, comm=comm)
     else:
         gathered, counts = desc_local, [desc_local.shape[0]]

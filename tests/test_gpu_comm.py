@@ -79,6 +79,7 @@ def test_cross_image_match_over_the_boundary_transport(lfp, torch):
             match, gathered, base = sharding.cross_image_match(mine, sizes, sharding.gpu_match_fn(h), out=buf, comm=comm)
         torch.cuda.synchronize()
         assert base == 0 and gathered.data_ptr() == buf.data_ptr() and torch.equal(gathered, local)
+        assert comm.calls >= 1          # the gather went through lf_mkd_allgather_descriptors, world of one or not
         m = match.cpu().numpy()
         starts = np.cumsum([0] + sizes)
         img_of = np.repeat(np.arange(3), sizes)
@@ -92,3 +93,81 @@ def test_cross_image_match_over_the_boundary_transport(lfp, torch):
         comm.close()
     finally:
         dist.destroy_process_group()
+
+
+_TWO_RANK_CHILD = r"""
+import os, sys
+rank, world, port, root = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+sys.path.insert(0, os.path.join(root, "local-features_amd"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+import torch
+import torch.distributed as dist
+import local_features_python as lfp
+from local_features_python import sharding
+torch.cuda.set_device(rank)
+dist.init_process_group("gloo", rank=rank, world_size=world)          # carries the 128-byte identifier and the checks
+h = lfp.MkdHandle(max_features=64, device=rank)
+comm = sharding.make_comm(h)
+assert comm.info()[1:] == (world, rank)
+torch.cuda.set_stream(torch.cuda.Stream())
+def rows(r, n):            # rank r's shard: recognisable rows
+    return (torch.arange(n, dtype=torch.float32)[:, None] + 1000.0 * r + torch.arange(128, dtype=torch.float32)[None, :] / 256).cuda()
+for counts in ([3000, 3000], [4097, 130], [0, 777], [513, 0]):
+    want = torch.cat([rows(r, c) for r, c in enumerate(counts)])
+    for mode in ("direct", "ring"):
+        buf, mine = sharding.gathered_buffer(counts, rank)
+        buf.fill_(-1.0)
+        mine.copy_(rows(rank, counts[rank]))
+        out, got_counts = sharding.all_gather_descriptors(mine, mode=mode, out=buf, counts=counts, comm=comm)
+        torch.cuda.synchronize()
+        assert got_counts == counts and torch.equal(out, want), (rank, counts, mode)
+# and the cross-image match over it equals the single-process answer
+g = torch.Generator().manual_seed(7)
+allv = torch.nn.functional.normalize(torch.randn((600, 128), generator=g), dim=1)
+allv[300:320] = torch.nn.functional.normalize(allv[10:30] + 0.02 * torch.randn((20, 128), generator=g), dim=1)
+sizes = [[100, 200], [120, 180]]
+lo = 0 if rank == 0 else 300
+local = allv[lo:lo + 300].cuda()
+match, gathered, base = sharding.cross_image_match(local, sizes[rank], sharding.gpu_match_fn(h), comm=comm)
+torch.cuda.synchronize()
+assert base == lo and torch.equal(gathered.cpu(), allv)
+elo, ehi = sharding.exclusion_ranges(sizes[rank], base, "cuda")
+want = torch.empty(300, dtype=torch.int32, device="cuda")
+h.match_device(local.data_ptr(), 300, gathered.data_ptr(), 600, want.data_ptr(), 0.8, elo.data_ptr(), ehi.data_ptr())
+h.synchronize()
+assert torch.equal(match.cpu(), want.cpu().long())
+if rank == 1:
+    assert int((match[0:20].cpu() == torch.arange(10, 30)).sum()) == 20       # the planted partners, across the rank boundary
+comm.close()
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok", flush=True)
+"""
+
+
+def test_two_ranks_over_rccl_uneven_and_empty_shards():
+    """lf_mkd_allgather_descriptors with MORE than one rank: two fresh child processes, one GPU each, started
+    before anything in them touches the GPU; both forms, equal / uneven / empty shards against the concatenation, and the
+    cross-image match over the transport against the direct call.  Needs two GPUs: skipped on a one-GPU box (where the
+    grouped send / recv offsets are covered over gloo by tests/test_distributed.py)."""
+    import subprocess
+    import sys
+    import torch as t
+    if t.cuda.device_count() < 2:          # (counting devices does not initialise the GPU on this image)
+        pytest.skip("needs two GPUs")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", _TWO_RANK_CHILD, str(r), "2", str(port), root], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append("TIMEOUT " + p.communicate()[0])
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
