@@ -254,18 +254,20 @@ int lf_mkd_stream_frame(lf_mkd *h, void *stream);
  * (examples/webcam/src/main.rs:261-265).  d_exclude_lo / d_exclude_hi (may both be NULL): b rows [lo[i], hi[i]) are not candidates for
  * a row i -- the cross-image form of BASELINE configs[3], where b is the all-gathered descriptor set and a row
  * must not match its own image.  nb must be at least 2 (the reference indexes the second-to-last candidate).
- * Similarities come from the matrix cores in one of two forms, both within ~1e-7 of an f32 dot product, so that decisions
+ * Similarities come from the matrix cores in one of three forms, all within ~1e-7 of an f32 dot product, so that decisions
  * can differ from the reference's only where two similarities, or best*ratio and second, agree to that level:
+ *   small   -- na * nb <= 2^23 and nb <= 4096 (the reference's own 2000 x 2000): ONE launch straight from the f32 rows, the
+ *              scan's three terms formed in registers, no operand tiles and no scratch buffer;
  *   scan    -- every pair from f16 hi+lo splits of both sides (three MFMA terms; ~2^-21 relative for rows of unit norm or
  *              larger -- the lo parts of much smaller elements fall below the f16 grid); ~1.7e12 pairs/s on an MI355X;
- *              used for small problems (the reference's 2000 x 2000 takes 0.06 ms);
+ *              used for mid-sized problems;
  *   screen  -- two passes, for na >= 16384 and na * nb >= 2^29: every pair is screened with the f16 roundings of both sides
  *              (one term; error bounded by ~1e-3 |a||b|, from the rows' norms), every candidate within that bound of a row's
  *              second best is re-scored as an f32 dot product, and the decision is taken on the re-scored values, i.e. the
  *              result of an exhaustive f32 scan; ~5.9e12 pairs/s.  A row with more than 64 such candidates in one lane's
  *              share of b (hundreds of near-duplicates of its best match) is redone by the scan form inside the same call,
  *              decided on the device.
- * LF_MKD_MATCH=scan or =screen in the environment forces a form.  Elements must be finite and below 65504 in magnitude
+ * LF_MKD_MATCH=small, =scan or =screen in the environment forces a form (small: where it fits, else scan).  Elements must be finite and below 65504 in magnitude
  * (f16 range).
  * Device pointers, asynchronous on `stream`. */
 int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d_b, uint64_t nb,

@@ -1015,10 +1015,20 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
     // without splitting b many ways (every b split starts its candidate lists from nothing); below that -- the reference's
     // own 2000 x 2000 included -- the three-term scan alone is faster.  LF_MKD_MATCH=scan / =screen in the environment
     // force one form (A/B runs, tests).
+    // Small problems -- the reference's own 2000 x 2000 (examples/match_images/src/main.rs:62-76) -- take ONE launch that
+    // reads the f32 rows directly (match_small: no operand tiles, no partials, no merge kernel): below ~10^4 rows the chain
+    // of split / scan / merge launches is launch cadence, not arithmetic.  LF_MKD_MATCH=small forces it where it fits.
     const char *form = getenv("LF_MKD_MATCH");
+    const bool want_small = form ? (form[0] == 's' && form[1] == 'm') : true;
+    if (want_small && match_small_fits(long(na), long(nb))) {
+        launch_match_small(d_a, long(na), d_b, long(nb), d_exclude_lo, d_exclude_hi, ratio, d_match, d_best, d_second,
+                           h->d_match_misc ? h->d_match_misc + 2 : nullptr, s);
+        LF_HIP(h, hipGetLastError());
+        return LF_MKD_OK;
+    }
     const bool three_term_only = form && form[0] == 's' && form[1] == 'c' && form[2] == 'a'
                                      ? true
-                                     : (form && form[0] == 's' ? false : !(na >= 16384 && na * nb >= (1ull << 29)));
+                                     : (form && form[0] == 's' && form[1] == 'c' ? false : !(na >= 16384 && na * nb >= (1ull << 29)));
     // a goes through in chunks, so that the per-row scratch (2 KiB of candidate records per a row and b split) stays bounded
     const uint64_t chunk = three_term_only ? na : std::min<uint64_t>(na, kMatchChunk);
     const int splits = match_splits(long(chunk), long(nb), h->num_cus);

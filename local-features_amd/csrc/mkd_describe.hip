@@ -17,6 +17,7 @@
 
 #include <type_traits>
 
+#include "mkd_ablate.h"
 #include "mkd_device.h"
 #include "mkd_sample.h"
 
@@ -140,6 +141,11 @@ __device__ __forceinline__ void issue_raw_row(const RawSrc &src, int row, unsign
 // (tests/test_gpu_parity.py::test_full_size_properties compares the two forms bit for bit).
 #pragma clang fp contract(off)
 
+// max(a, b, 1e-30) in one instruction (a, b >= 0): the larger gradient component as a divisor that is never 0
+__device__ __forceinline__ float max3_tiny(float a, float b) {
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), 1e-30f);   // v_max3_f32, with the |.| of its operands folded in
+}
+
 // cos/sin of the gradient angle theta = -atan2(gy over gx), for a pair of pixels.
 template <int ANGLE>
 __device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 r2, f32x2 &ct, f32x2 &st) {
@@ -160,9 +166,12 @@ __device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 r2,
         //   (|cos res|, |sin res|) = swap ? (sin p', cos p') : (cos p', sin p'),  sign(cos res) = sign(x),  sign(sin res) = sign(y)
         // (case by case from the three lines above), and the first octant needs no signs and no select of num / den:
         const float ax0 = fabsf(gx.x), ay0 = fabsf(gy.x), ax1 = fabsf(gx.y), ay1 = fabsf(gy.y);
-        const bool sw0 = ax0 < ay0, sw1 = ax1 < ay1;
+        // gx == 0: the shader returns angle 0 both for atan2(0, 0) and (its quirk) for atan2(0, y != 0), i.e.
+        // (cos, sin) = (1, 0).  That is the un-swapped branch at a = 0 (p = 0: cos p = 1, sin p = 0), so such a pixel simply
+        // does not swap, and the denominator is kept away from 0 (0 x rcp(0) would be NaN) -- no selects afterwards
+        const bool sw0 = ax0 < ay0 && gx.x != 0.f, sw1 = ax1 < ay1 && gx.y != 0.f;
         const f32x2 mn = {__builtin_fminf(ax0, ay0), __builtin_fminf(ax1, ay1)};
-        const f32x2 mx = {__builtin_fmaxf(ax0, ay0), __builtin_fmaxf(ax1, ay1)};
+        const f32x2 mx = {max3_tiny(ax0, ay0), max3_tiny(ax1, ay1)};
         const f32x2 a = mn * f32x2{__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
         const f32x2 s = a * a;
         f32x2 p = pk_fma(s, pk_set(-0.0117212f), pk_set(0.05265332f));
@@ -187,9 +196,6 @@ __device__ __forceinline__ void gradient_direction(f32x2 gx, f32x2 gy, f32x2 r2,
         float cr1 = __uint_as_float(__float_as_uint(sw1 ? sn.y : cs.y) | (__float_as_uint(gx.y) & sgn));
         float sr0 = __uint_as_float(__float_as_uint(sw0 ? cs.x : sn.x) | (~__float_as_uint(gy.x) & sgn));
         float sr1 = __uint_as_float(__float_as_uint(sw1 ? cs.y : sn.y) | (~__float_as_uint(gy.y) & sgn));
-        // gx == 0: the shader returns 0 both for atan2(0, 0) and (its quirk) for atan2(0, y != 0)
-        if (gx.x == 0.f) { cr0 = 1.f; sr0 = 0.f; }
-        if (gx.y == 0.f) { cr1 = 1.f; sr1 = 0.f; }
         ct = f32x2{cr0, cr1};
         st = f32x2{sr0, sr1};
     }
@@ -212,10 +218,10 @@ __device__ __forceinline__ void gradient_direction4(const f32x2 (&gx)[4], const 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float ax0 = fabsf(gx[e].x), ay0 = fabsf(gy[e].x), ax1 = fabsf(gx[e].y), ay1 = fabsf(gy[e].y);
-        sw0[e] = ax0 < ay0;
-        sw1[e] = ax1 < ay1;
+        sw0[e] = ax0 < ay0 && gx[e].x != 0.f;   // gx == 0 -> (1, 0): the un-swapped branch at a = 0 (see gradient_direction)
+        sw1[e] = ax1 < ay1 && gx[e].y != 0.f;
         const f32x2 mn = {__builtin_fminf(ax0, ay0), __builtin_fminf(ax1, ay1)};
-        const f32x2 mx = {__builtin_fmaxf(ax0, ay0), __builtin_fmaxf(ax1, ay1)};
+        const f32x2 mx = {max3_tiny(ax0, ay0), max3_tiny(ax1, ay1)};
         a[e] = mn * f32x2{__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
     }
 #pragma unroll
@@ -258,8 +264,6 @@ __device__ __forceinline__ void gradient_direction4(const f32x2 (&gx)[4], const 
         float cr1 = __uint_as_float(__float_as_uint(sw1[e] ? sn[e].y : cs[e].y) | (__float_as_uint(gx[e].y) & sgn));
         float sr0 = __uint_as_float(__float_as_uint(sw0[e] ? cs[e].x : sn[e].x) | (~__float_as_uint(gy[e].x) & sgn));
         float sr1 = __uint_as_float(__float_as_uint(sw1[e] ? cs[e].y : sn[e].y) | (~__float_as_uint(gy[e].y) & sgn));
-        if (gx[e].x == 0.f) { cr0 = 1.f; sr0 = 0.f; }
-        if (gx[e].y == 0.f) { cr1 = 1.f; sr1 = 0.f; }
         ct[e] = f32x2{cr0, cr1};
         st[e] = f32x2{sr0, sr1};
     }
@@ -272,9 +276,11 @@ struct BFrag { u32x4 p0, p1; };
 
 __device__ __forceinline__ BFrag load_b(const unsigned char *brow, int ut) {   // ut: a constant after unrolling
     BFrag b;
-#ifdef LF_ABLATE_BLOAD  // timing-only build: no LUT fragment reads
-    b.p0 = u32x4{(unsigned)ut, 1u, 2u, 3u}; b.p1 = b.p0; return b;
-#endif
+    if constexpr (ablate::kNoFragmentReads) {
+        b.p0 = u32x4{(unsigned)ut, 1u, 2u, 3u};
+        b.p1 = b.p0;
+        return b;
+    }
     b.p0 = *reinterpret_cast<const u32x4 *>(brow + (ut * 2 + 0) * 1024);
     b.p1 = *reinterpret_cast<const u32x4 *>(brow + (ut * 2 + 1) * 1024);
     return b;
@@ -298,11 +304,11 @@ template <> struct AFrag<LF_POOL_F16X3> {
     __device__ __forceinline__ void set(const f32x2 (&a)[4]) {
         // residual a - hi as ONE v_fma_mix_f32 (f32 x f32 - f16); the factor 1 is hidden from hipcc, which otherwise
         // folds the fma into an unpack plus a subtract
-#ifdef LF_ABLATE_SPLIT  // timing-only build: no hi-lo split
+        if constexpr (ablate::kNoSplit) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { hi[e] = __float_as_uint(a[e].x); lo[e] = __float_as_uint(a[e].y); }
-        return;
-#endif
+            for (int e = 0; e < 4; ++e) { hi[e] = __float_as_uint(a[e].x); lo[e] = __float_as_uint(a[e].y); }
+            return;
+        }
         // (written step by step across the four pairs: conversion, residuals, conversion are each one dependent on the
         // other; across the pairs they are not)
         float one = 1.f;
@@ -322,9 +328,11 @@ template <> struct AFrag<LF_POOL_F16X3> {
     }
     // two streams at once (the cos and sin streams of a harmonic): twice as many independent operations per step
     __device__ __forceinline__ static void set2(AFrag &x, const f32x2 (&a)[4], AFrag &y, const f32x2 (&b)[4]) {
-#ifdef LF_ABLATE_SPLIT
-        x.set(a); y.set(b); return;
-#endif
+        if constexpr (ablate::kNoSplit) {
+            x.set(a);
+            y.set(b);
+            return;
+        }
         float one = 1.f;
         asm("" : "+v"(one));
         float ra0[4], ra1[4], rb0[4], rb1[4];
@@ -349,9 +357,10 @@ template <> struct AFrag<LF_POOL_F16X3> {
 // dependent MFMAs of one tile.
 template <int POOL, int PART>
 __device__ __forceinline__ void mma_part(const AFrag<POOL> &a, const BFrag &b, f32x4 &acc) {
-#ifdef LF_ABLATE_MMA   // timing-only build: no matrix instructions, operands kept alive
-    if constexpr (POOL == LF_POOL_F16X3) { asm volatile("" ::"v"(a.hi), "v"(a.lo), "v"(b.p0), "v"(b.p1)); return; }
-#endif
+    if constexpr (ablate::kNoMma && POOL == LF_POOL_F16X3) {   // (operands kept alive)
+        asm volatile("" ::"v"(a.hi), "v"(a.lo), "v"(b.p0), "v"(b.p1));
+        return;
+    }
     if constexpr (POOL == LF_POOL_F32) {
         const f32x4 b0 = __builtin_bit_cast(f32x4, b.p0), b1 = __builtin_bit_cast(f32x4, b.p1);
         if (PART == 0) {
@@ -381,6 +390,16 @@ __device__ __forceinline__ void mma_part(const AFrag<POOL> &a, const BFrag &b, f
 template <class SlotOfTap>
 __device__ __forceinline__ void blur_row_impl(const unsigned char *ring_lane, SlotOfTap slot_of_tap, int addr_l, int addr_r,
                                               bool has_l, bool has_r, float (&out)[8], float &out_l, float &out_r) {
+    if constexpr (ablate::kNoFrontEnd) {   // no blur: the first tap's raw row as it is
+        const int sl = slot_of_tap(0);
+        const f32x4 a_ = *reinterpret_cast<const f32x4 *>(ring_lane + sl * 2048);
+        const f32x4 b_ = *reinterpret_cast<const f32x4 *>(ring_lane + sl * 2048 + 256);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { out[x] = a_[x]; out[4 + x] = b_[x]; }
+        out_l = out[0];
+        out_r = out[7];
+        return;
+    }
     float vb[8];
     {
         const float kk[5] = {kB0, kB1, kB2, kB1, kB0};
@@ -451,28 +470,13 @@ __device__ __forceinline__ void pool_harmonics(const f32x2 (&m)[4], const f32x2 
         if (k < 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-#ifdef LF_SCALAR_RECURRENCE   // A/B build: the recurrence between the harmonics' MFMAs as scalar f32 instead of packed f32
-                const f32x2 pm = k == 0 ? m[e] : pp[e];
-                const f32x2 pn = {__builtin_fmaf(tc[e].x, pk[e].x, -pm.x), __builtin_fmaf(tc[e].y, pk[e].y, -pm.y)};
-                const f32x2 qn = k == 0 ? f32x2{tc[e].x * qk[e].x, tc[e].y * qk[e].y}
-                                        : f32x2{__builtin_fmaf(tc[e].x, qk[e].x, -qp[e].x), __builtin_fmaf(tc[e].y, qk[e].y, -qp[e].y)};
-#else
                 const f32x2 pn = pk_fma(tc[e], pk[e], k == 0 ? -m[e] : -pp[e]);
                 const f32x2 qn = k == 0 ? tc[e] * qk[e] : pk_fma(tc[e], qk[e], -qp[e]);
-#endif
                 pp[e] = pk[e]; qp[e] = qk[e];
                 pk[e] = pn; qk[e] = qn;
             }
         }
         const int a0 = 3 + 7 * k, u0 = 3 + 4 * k;
-#ifdef LF_ABLATE_HALF_MMA   // timing-only build: what a formulation with half the matrix work and half the fragment reads would cost
-        const BFrag p0 = g, q0 = load_b(brow, u0 + 1);
-        if (k < 2) g = load_b(brow, u0 + 4);
-        mma_part<POOL, 0>(ac, p0, acc[a0 + 0]); mma_part<POOL, 0>(as, p0, acc[a0 + 2]); mma_part<POOL, 0>(as, q0, acc[a0 + 1]);
-        mma_part<POOL, 1>(ac, p0, acc[a0 + 0]); mma_part<POOL, 1>(as, p0, acc[a0 + 2]); mma_part<POOL, 1>(as, q0, acc[a0 + 1]);
-        mma_part<POOL, 2>(ac, p0, acc[a0 + 0]); mma_part<POOL, 2>(as, p0, acc[a0 + 2]); mma_part<POOL, 2>(as, q0, acc[a0 + 1]);
-        mma_part<POOL, 0>(ac, q0, acc[a0 + 2]); mma_part<POOL, 1>(ac, q0, acc[a0 + 2]); mma_part<POOL, 2>(ac, q0, acc[a0 + 2]);
-#else
         const BFrag p0 = g, q0 = load_b(brow, u0 + 1), r = load_b(brow, u0 + 2), sf = load_b(brow, u0 + 3);
         if (k < 2) g = load_b(brow, u0 + 4);
         // cos x P0 -> a0 | sin x P0 -> a0+2 | sin x Q0 -> a0+1 | cos x R, sin x R -> a0+3, a0+4 | cos x S, sin x S -> a0+5, a0+6
@@ -487,7 +491,6 @@ __device__ __forceinline__ void pool_harmonics(const f32x2 (&m)[4], const f32x2 
         mma_part<POOL, 2>(ac, sf, acc[a0 + 5]); mma_part<POOL, 2>(as, sf, acc[a0 + 6]);
         // cos x Q0: the second product of relsin[0:16], into the accumulator of the first
         mma_part<POOL, 0>(ac, q0, acc[a0 + 2]); mma_part<POOL, 1>(ac, q0, acc[a0 + 2]); mma_part<POOL, 2>(ac, q0, acc[a0 + 2]);
-#endif
     }
 }
 
@@ -788,9 +791,7 @@ struct KpSampler {
     }
     // requests the taps of a quarter (fetch_covered of mkd_sample.h: indices clamped into the level's allocation)
     __device__ __forceinline__ void request(int quarter, int set, KpTaps &t) const {
-#ifdef LF_KP_ABLATE_PRODUCER   // timing-only build: the describe waves alone (their rings hold whatever was there)
-        return;
-#endif
+        if constexpr (ablate::kNoProducer) return;
         const int q = quarter & 3, ly = 4 * (quarter >> 2) + r;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -807,11 +808,11 @@ struct KpSampler {
                 t.ay[2 * i + hh] = p.ay;
                 const int ix = min(max(p.ix + apron, 0), xmax), iy = min(max(p.iy + apron, 0), ymax);
                 const unsigned off = __umul24((unsigned)iy, (unsigned)pitch4) + 4u * (unsigned)ix;   // both < 2^24: full-rate multiply
-#ifdef LF_KP_ABLATE_TAPS       // timing-only build: everything but the loads of a sample
-                t.top[2 * i + hh] = f32x2{__uint_as_float(off), p.ax};
-                t.bot[2 * i + hh] = f32x2{p.ay, (float)pitch4};
-                continue;
-#endif
+                if constexpr (ablate::kNoTaps) {
+                    t.top[2 * i + hh] = f32x2{__uint_as_float(off), p.ax};
+                    t.bot[2 * i + hh] = f32x2{p.ay, (float)pitch4};
+                    continue;
+                }
                 t.top[2 * i + hh] = load2_sv(a0, off);
                 t.bot[2 * i + hh] = load2_sv(a0, off + (unsigned)pitch4);
             }
@@ -819,9 +820,7 @@ struct KpSampler {
     }
     // blends them and writes the quarter's rows into the ring
     __device__ __forceinline__ void finish(int quarter, int set, int slot0, const KpTaps &t) const {
-#ifdef LF_KP_ABLATE_PRODUCER
-        return;
-#endif
+        if constexpr (ablate::kNoProducer) return;
         const int G = quarter >> 2, q = quarter & 3;
         // (slot0 + 4G) mod 12 is a multiple of 4: the group's four rows sit in consecutive slots.  Ring slot layout:
         // [half 2][16-byte chunk of the half-row 4][patch 16][4 pixels]; this lane's pixel c (+16) of patch 4q + i
@@ -868,10 +867,7 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
                                            int pw, int lane) {
     // The producer is the shorter instruction stream of the two waves on its SIMD, but its step ends in the barrier the
     // describe waves of all four SIMDs wait at: served first, it keeps out of their way (same-box A/B: +4 %)
-#ifndef LF_KP_PRODUCER_PRIO
-#define LF_KP_PRODUCER_PRIO 2
-#endif
-    __builtin_amdgcn_s_setprio(LF_KP_PRODUCER_PRIO);
+    __builtin_amdgcn_s_setprio(ablate::kProducerPrio);
     KpSampler<W> sm(ks, lt, lvl_offset, n, s_mem, pw, lane);
     KpTaps ta, tb;
     int set = 0, slot0 = 0;
@@ -929,14 +925,6 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
 // Algorithmic HBM bytes per patch: 4096 read + 512 written; the kernel moves nothing else.
 // W = waves per workgroup: 8 (128 patches, two waves per SIMD) for throughput; 4 (64 patches) when the whole request
 // fits one round of workgroups anyway, so that it spreads over twice as many CUs with a SIMD to each wave.
-#ifdef LF_PHASE_TIMING   // timing-only build (tools/phase_timing.py): per-wave wall clock of the phases of a patch row,
-                         // left by workgroup 0 in out[wave * 128 + phase]
-#define LF_PT(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
-                      phase_clk[i] += t_ - phase_prev; phase_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define LF_PT(i) do { } while (0)
-#endif
-
 // SRC = kSrcKeypoints (keypoint mode, f16x3 pooling): the workgroup has 2 W waves.  Waves 0 .. W-1 are the describe waves
 // of the text above; waves W .. 2W-1 are their producers (kp_produce): wave W + i samples the patches of describe wave i from
 // the pyramid straight into its row ring, so a sampled patch never leaves the CU.  `patches` is unused, `ks` says what to
@@ -992,9 +980,7 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
             return;
         }
 
-#ifdef LF_KP_CONSUMER_PRIO
-        __builtin_amdgcn_s_setprio(LF_KP_CONSUMER_PRIO);
-#endif
+        if constexpr (ablate::kConsumerPrio >= 0) __builtin_amdgcn_s_setprio(ablate::kConsumerPrio);
     }
     // DMA writes are lane-linear (lane l -> bytes [16l, 16l+16) of a 1 KiB piece): lane (p, q) moves the 16-B
     // chunk q of its patch's half-row; the reader (p, q) needs chunks 2(q&1), 2(q&1)+1 of half q>>1.
@@ -1019,9 +1005,8 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
     }
     int slot0 = 0;   // keypoint mode: ring slot of raw row 0 of the current batch
     unsigned par = 0;  // LUT row buffer holding the row about to be consumed
-#ifdef LF_PHASE_TIMING
-    unsigned long long phase_clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, phase_prev = __builtin_readcyclecounter();
-#endif
+    ablate::PhaseClock phase;   // (instrument builds only: tools/phase_timing.py)
+    phase.start();
 
     for (; batch < walk.end; batch += walk.step) {
         // Launder the (uniform) table and buffer pointers once per batch.  Otherwise hipcc hoists one 64-bit per-lane VGPR
@@ -1055,12 +1040,12 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
             constexpr bool kFirst = decltype(kind)::value == 0, kLast = decltype(kind)::value == 2;
 
             // LUT row g and ring row g+3 have landed (own DMA: vmcnt; everyone's: barrier); row g-1 is done
-            LF_PT(7);
-#ifndef LF_ABLATE_SYNC
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-#endif
-            LF_PT(0);
+            phase.mark(7);
+            if constexpr (!ablate::kNoRowSync) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            phase.mark(0);
             const unsigned char *brow = s_mem + par * kRowBytes + lane * 16;
             // row buffer par ^ 1 is free: next LUT row; during row 31 the f16 epilogue's first whitening step instead
             // (keypoint mode: the producer waves request LUT rows 1..31 -- an LDS-DMA request stalls its issuer for 60-180
@@ -1073,9 +1058,6 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
             par ^= 1;
             BFrag bm[3] = {load_b(brow, 0), load_b(brow, 1), load_b(brow, 2)};   // m-stream fragments
 
-#ifdef LF_ABLATE_FRONT  // timing-only build: no blur, no gradient direction
-#define blur_row(rl, s, al, ar, hl, hr, o, ol, or_) do { const f32x4 a_ = *reinterpret_cast<const f32x4 *>(rl + (s) * 2048); const f32x4 b_ = *reinterpret_cast<const f32x4 *>(rl + (s) * 2048 + 256); for (int x_ = 0; x_ < 4; ++x_) { o[x_] = a_[x_]; o[4 + x_] = b_[x_]; } ol = o[0]; or_ = o[7]; } while (0)
-#endif
             // Raw row g+4 goes into the slot of row g-2, whose last reader was the blur of the previous iteration: for
             // g >= 1 it is requested here, a whole row before the vmcnt(0) that waits for it (counters: the waves spend
             // 29 % of their time in s_waitcnt and only 2 % of that on LDS), for g == 0 after the first blur below.
@@ -1119,7 +1101,7 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
                 }
             }
             s0 = s0 == kRingSlots - 1 ? 0 : s0 + 1;
-            LF_PT(1);
+            phase.mark(1);
 
             f32x2 m[4], c1[4], s1[4];
             {
@@ -1136,12 +1118,12 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
                     m[e] = f32x2{__builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(r2.x)),
                                  __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(r2.y))};
                 }
-#ifdef LF_ABLATE_FRONT
+                if constexpr (ablate::kNoFrontEnd) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { c1[e] = gx[e]; s1[e] = gy[e]; }
-#else
-                gradient_direction4<ANGLE>(gx, gy, r2n, c1, s1);
-#endif
+                    for (int e = 0; e < 4; ++e) { c1[e] = gx[e]; s1[e] = gy[e]; }
+                } else {
+                    gradient_direction4<ANGLE>(gx, gy, r2n, c1, s1);
+                }
             }
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
@@ -1150,7 +1132,7 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
             }
             cur_l = nxt_l;
             cur_r = nxt_r;
-            LF_PT(2);
+            phase.mark(2);
 
             // m stream x (polar | cartesian) kernels: accumulator tiles 0-2
             BFrag gfrag = load_b(brow, 3);   // first harmonic: P0
@@ -1164,31 +1146,31 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
 #pragma unroll
                 for (int t = 0; t < 3; ++t) mma_part<POOL, 2>(am, bm[t], acc[t]);
             }
-            LF_PT(3);
+            phase.mark(3);
             // cos / sin streams of the three harmonics x their four LUT tiles: accumulator tiles 3-23
             pool_harmonics<POOL>(m, c1, s1, brow, gfrag, acc);
-            LF_PT(4);
-            LF_PT(5);
+            phase.mark(4);
+            phase.mark(5);
         };
         patch_row(std::integral_constant<int, 0>(), 0);
 #pragma unroll 1
         for (int g = 1; g < 31; ++g) patch_row(std::integral_constant<int, 1>(), g);
         patch_row(std::integral_constant<int, 2>(), 31);
-#ifdef LF_ABLATE_EPILOGUE  // timing-only build
-        { f32x4 sum = acc[0]; for (int t = 1; t < kAccTiles; ++t) sum += acc[t];
-          if (base + p < n) *reinterpret_cast<f32x4 *>(out + (base + p) * 128 + 4 * q) = sum;
-          if (POOL == LF_POOL_F16X3) { __syncthreads(); if (more) issue_lut_row<W>(lr, 0, s_mem, wave, lane); } }
-#else
-        finish_descriptors<POOL, W>(acc, lane, wave, base + p < n, base + p, cm, wf, bs, o, ro, s_mem, lr, more);
-#endif
-        LF_PT(6);
+        if constexpr (ablate::kNoEpilogue) {
+            f32x4 sum = acc[0];
+            for (int t = 1; t < kAccTiles; ++t) sum += acc[t];
+            if (base + p < n) *reinterpret_cast<f32x4 *>(out + (base + p) * 128 + 4 * q) = sum;
+            if (POOL == LF_POOL_F16X3) {
+                __syncthreads();
+                if (more) issue_lut_row<W>(lr, 0, s_mem, wave, lane);
+            }
+        } else {
+            finish_descriptors<POOL, W>(acc, lane, wave, base + p < n, base + p, cm, wf, bs, o, ro, s_mem, lr, more);
+        }
+        phase.mark(6);
         if constexpr (kKp) slot0 = (slot0 + 8) % kRingSlotsKp;
     }
-#ifdef LF_PHASE_TIMING
-    __syncthreads();
-    if (blockIdx.x == 0 && lane == 0)
-        for (int i = 0; i < 8; ++i) out[wave * 128 + i] = (float)phase_clk[i];
-#endif
+    phase.dump(out, wave, lane);
     if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
         clk[2] = __builtin_readcyclecounter();
         clk[3] = __builtin_amdgcn_s_memrealtime();
@@ -1209,11 +1191,7 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
                      unsigned long long *clk) {
     if (n <= 0) return;
     // one 100-152 KiB-LDS workgroup per CU; requests of at most one round of 64-patch workgroups take the 4-wave form
-#ifdef LF_ABLATE_FORCE_W4   // timing-only build: the 4-wave form at every size
-    const bool small = true;
-#else
-    const bool small = waves == 4 || (waves != 8 && n <= 64L * num_cus);
-#endif
+    const bool small = ablate::kForceFourWaves || waves == 4 || (waves != 8 && n <= 64L * num_cus);
     const long nbatch = small ? (n + 63) / 64 : (n + 127) / 128;
     const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);
     const bool f16 = pool_mode == LF_POOL_F16X3;

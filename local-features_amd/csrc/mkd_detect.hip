@@ -4,6 +4,7 @@
 //   topk_*            the host blob filter of detect_top_n (vulkan/mod.rs:1753-1786) on the device; segments_* batch it
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mkd_device.h"
 
@@ -191,6 +192,9 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
     }
 }
 
+// (Round 4 tried to drop the first of the two launches below, twice, and measured both on a 4K frame: an atomic per
+//  extremum-holding cube inside the scan -- scan 71 -> 109 us; a decoupled look-back inside cubes_scatter with device-scope
+//  flags -- 15 -> 31 us, the flag reads go past the XCDs' L2s.  Two launches it stays.)
 // Ordered compaction of per-cube slots, two small launches: (1) sums of 1024 counts, (2) every workgroup adds up the sums
 // before its own (a few hundred to a few thousand words from L2: cheaper than a third launch in between, which costs
 // ~5 us of a frame's critical path), rescans its 1024 counts from that base and copies the slots; the last workgroup
@@ -588,6 +592,166 @@ __global__ __launch_bounds__(1024) void topk_scatter(const float *__restrict__ e
         for (int b = threadIdx.x; b < kTopkDigits * kTopkBins; b += 1024) work[b] = 0;
 }
 
+// The same selection for one list of at most 32 768 extrema (a 1080p frame yields about ten thousand) in ONE launch of ONE
+// workgroup: the five launches above are ~5 us of launch cadence each on a frame's critical path, and such a list is small
+// enough to live in the registers of 1024 threads -- wave w owns the contiguous range [64 K w, 64 K (w + 1)) of the list,
+// K = ceil(n / 1024) <= 32, lane l its items 64 K w + 64 j + l (coalesced loads, read once).  (Beyond that one CU is the
+// wrong place: measured with 64 items per thread, a 4K frame's 41 k extrema took 36 us against the five launches' 29;
+// tools/bench_topk.py: level at 32 k, 2-6 us ahead below 24 k.)  Key = float bits of the
+// non-negative contrast with bit 31 set if the blob passes min_size, 0 otherwise.  Radix select with LDS histograms over
+// 11-bit digits of the bits in which the keys differ, then the ordered compaction: ballots inside a wave, one scan over the 16 waves.
+// Same result as topk_hist / topk_sums / topk_scatter (and as one workgroup of topk_filter), decision for decision.
+constexpr int kTopkOneMaxK = 32;
+template <int KMAX>
+__global__ __launch_bounds__(1024) void topk_one(const float *__restrict__ extrema, const unsigned long long *__restrict__ n_in,
+                                                 unsigned long long n_host, float min_size, unsigned n_keep,
+                                                 float *__restrict__ out, unsigned *__restrict__ out_index,
+                                                 unsigned *__restrict__ out_count, unsigned long long *__restrict__ out_count64) {
+    __shared__ unsigned hist[kTopkBins];
+    __shared__ unsigned ws[16], s_prefix, s_rank, s_m, s_min, s_max;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned n = (unsigned)(n_in ? n_in[0] : n_host);
+    const unsigned K = (n + 1023u) / 1024u;                      // <= KMAX (the launcher's contract)
+    const unsigned first = (unsigned)wave * 64u * K + (unsigned)lane;
+    unsigned key[KMAX];
+    // sixteen items per lane at a time: the loads of a group are all requested before the first is looked at (the values
+    // pass through an opaque statement: hipcc otherwise makes the contrast's load conditional on the size's test and waits
+    // for every item in turn -- 41 dependent round trips on a 4K frame's list)
+#pragma unroll
+    for (int j0 = 0; j0 < KMAX; j0 += 16) {
+        if ((unsigned)j0 < K) {   // uniform
+            unsigned long long raw[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const unsigned i = first + 64u * (j0 + j);
+                const unsigned ii = i < n ? i : n - 1u;      // lanes past the end read the last item and drop it
+                // (uniform base + 32-bit byte offset: i < 65 536, so no 64-bit address arithmetic per item)
+                raw[j] = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(extrema) + (ii * 16u + 8u));
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(raw[j]));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const unsigned i = first + 64u * (j0 + j);
+                const float size = __uint_as_float((unsigned)raw[j]), contrast = __uint_as_float((unsigned)(raw[j] >> 32));
+                key[j0 + j] = ((unsigned)(j0 + j) < K && i < n && size >= min_size) ? (__float_as_uint(fabsf(contrast)) | 0x80000000u) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) key[j0 + j] = 0u;
+        }
+    }
+    // how many pass min_size, and the range of their keys
+    unsigned mine = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        const unsigned k = key[j];
+        mine += k >> 31;
+        kmax = k > kmax ? k : kmax;
+        kmin = (k >> 31) && k < kmin ? k : kmin;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mine += __shfl_xor(mine, o);
+        const unsigned a = __shfl_xor(kmin, o), b = __shfl_xor(kmax, o);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    if (threadIdx.x == 0) { s_m = 0; s_min = 0xFFFFFFFFu; s_max = 0u; }
+    __syncthreads();
+    if (lane == 0) { atomicAdd(&s_m, mine); atomicMin(&s_min, kmin); atomicMax(&s_max, kmax); }
+    __syncthreads();
+    unsigned cutoff = 0x80000000u;    // keep every blob that passes min_size
+    if (s_m > n_keep) {
+        // Radix select of the key of rank n_keep (0-based, descending) over the bits in which the keys DIFFER: the bits
+        // above the highest differing one are common to all (contrasts of one frame span a few binades: digits taken from
+        // bit 30 down would put every key into a handful of bins, and same-address LDS atomics serialise), so the first
+        // 11-bit digit starts there and the keys spread over its 2048 bins.
+        const unsigned diff = (s_min ^ s_max) & 0x7FFFFFFFu;
+        unsigned prefix = s_max, rank = n_keep;
+        if (diff != 0u) {
+            int hi = 32 - __builtin_clz(diff);            // undecided bits: [hi - 1 : 0]
+            prefix = s_max & ~((1u << hi) - 1u);
+#pragma unroll 1
+            while (hi > 0) {
+                const int bits = hi < 11 ? hi : 11, shift = hi - bits;
+                const unsigned above = ~((1u << hi) - 1u), dmask = (1u << bits) - 1u;
+                for (int b = threadIdx.x; b < kTopkBins; b += 1024) hist[b] = 0;
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < KMAX; ++j) {
+                    const unsigned k = key[j];
+                    if ((k >> 31) && (k & above) == prefix) atomicAdd(&hist[(k >> shift) & dmask], 1u);
+                }
+                __syncthreads();
+                // thread t owns bins 2047 - 2t and 2046 - 2t: prefix sums walk down from the top bin (as topk_replay)
+                const int hi_bin = kTopkBins - 1 - 2 * (int)threadIdx.x;
+                const unsigned c_hi = hist[hi_bin], c_lo = hist[hi_bin - 1];
+                const unsigned c = c_hi + c_lo;
+                unsigned incl = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned t = __shfl_up(incl, o);
+                    if (lane >= o) incl += t;
+                }
+                if (lane == 63) ws[wave] = incl;
+                __syncthreads();
+                unsigned before = 0;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) before += v < wave ? ws[v] : 0u;
+                const unsigned excl = before + incl - c;
+                if (c_hi != 0 && rank >= excl && rank < excl + c_hi) {
+                    s_prefix = prefix | ((unsigned)hi_bin << shift);
+                    s_rank = rank - excl;
+                } else if (c_lo != 0 && rank >= excl + c_hi && rank < excl + c) {
+                    s_prefix = prefix | ((unsigned)(hi_bin - 1) << shift);
+                    s_rank = rank - excl - c_hi;
+                }
+                __syncthreads();
+                prefix = s_prefix;
+                rank = s_rank;
+                __syncthreads();
+                hi = shift;
+            }
+        }
+        cutoff = prefix;
+    }
+    // ordered compaction of {key >= cutoff}: first the waves' totals, then every wave walks its range again
+    unsigned total = 0;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) total += (unsigned)__popcll(__ballot(key[j] >= cutoff));
+    if (lane == 0) ws[wave] = total;
+    __syncthreads();
+    unsigned at = 0, all = 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        at += v < wave ? ws[v] : 0u;
+        all += ws[v];
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned first2 = first;
+    asm volatile("" : "+v"(first2));   // (the item addresses are formed again here, not kept alive from the loads above)
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        const bool take = key[j] >= cutoff;
+        const unsigned long long bm = __ballot(take);
+        const unsigned o = at + (unsigned)__popcll(bm & below);
+        if (take && o < n_keep) {
+            const unsigned i = first2 + 64u * j;
+            *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(out) + o * 16u) =
+                *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(extrema) + i * 16u);
+            if (out_index) out_index[o] = i;
+        }
+        at += (unsigned)__popcll(bm);
+        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // (keeps the copies of later items from being hoisted: registers)
+    }
+    if (threadIdx.x == 0) {
+        const unsigned kept = all < n_keep ? all : n_keep;
+        out_count[0] = kept;
+        if (out_count64) out_count64[0] = kept;
+    }
+}
+
 void scan_grid(int w, int h, int n_fine, int border, int skip_layers, int &gx, int &gy, int &gz) {
     gx = w - 2 * border > 0 ? (w - 2 * border + 3) / 4 : 0;
     gy = h - 2 * border > 0 ? (h - 2 * border + 3) / 4 : 0;
@@ -631,6 +795,14 @@ void launch_topk_filter(const float *extrema, const unsigned *seg_start, const u
                         float *out, unsigned *out_index, unsigned *out_count, unsigned long long *out_count64,
                         unsigned long long n_cap, unsigned *work, hipStream_t stream) {
     // one frame with a long list and scratch to work in: the multi-workgroup form; otherwise one workgroup per frame
+    const char *form = getenv("LF_MKD_TOPK");          // "multi": the five-launch form at every size (A/B runs, tests)
+    const bool multi = form && form[0] == 'm';
+    if (n_frames == 1 && !seg_start && n_cap > 8192 && n_cap <= 1024ull * kTopkOneMaxK && seg_cap >= n_cap && !multi) {
+        // one list that fits the registers of one workgroup (K = ceil(n / 1024) <= 32 items per thread): one launch
+        hipLaunchKernelGGL(topk_one<kTopkOneMaxK>, dim3(1), dim3(1024), 0, stream, extrema, n_in, n_host, min_size, n_keep, out,
+                           out_index, out_count, out_count64);
+        return;
+    }
     if (n_frames == 1 && !seg_start && work && n_cap > 8192 && seg_cap >= n_cap) {
         const unsigned nb4 = (unsigned)((n_cap + 4095) / 4096), nb1 = (unsigned)((n_cap + 1023) / 1024);
         for (int pass = 0; pass < kTopkDigits; ++pass)

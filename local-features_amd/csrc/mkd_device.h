@@ -116,6 +116,11 @@ void launch_match_split(const float *x, long n, unsigned char *tiles, float *nor
 void launch_match(const unsigned char *a_tiles, long na, const unsigned char *b_tiles, long nb, const unsigned *excl_lo,
                   const unsigned *excl_hi, float ratio, int splits, float *p_best, int *p_index, float *p_second,
                   int *match, float *best, float *second, const int *n_over, hipStream_t stream);
+// small problems (match_small_fits: na * nb <= 2^23, nb <= 4096) in ONE launch straight from the f32 rows, no scratch; the
+// three terms of the scan in its order.  overflowed_word (nullable): zeroed by the launch (this form redoes no row)
+bool match_small_fits(long na, long nb);
+void launch_match_small(const float *a, long na, const float *b, long nb, const unsigned *excl_lo, const unsigned *excl_hi,
+                        float ratio, int *match, float *best, float *second, unsigned *overflowed_word, hipStream_t stream);
 // the same scan over the overflowed rows alone (few_words: their indices first, written by launch_match_verify)
 size_t match_few_tiles_bytes();
 size_t match_few_words();

@@ -31,6 +31,7 @@ namespace {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTileRows = 32;                 // rows of a / b per MFMA tile
 constexpr int kTileBytes = 2 * 8 * 2 * 32 * 16;  // [hi|lo][k-step 8][k-half 2][row 32][8 f16] = 16 KiB
@@ -287,6 +288,136 @@ __global__ __launch_bounds__(256) void match_merge(const float *__restrict__ p_b
 }
 
 
+// ---- small problems in ONE launch ------------------------------------------------------------------------------------
+// The reference's own use is 2000 x 2000 (examples/match_images/src/main.rs:62-76): there the split / scan / merge chain is
+// four dependent launches of a few microseconds each, i.e. launch cadence, not arithmetic.  `match_small` does the whole
+// match in one launch with no scratch: a workgroup owns 16 a rows (the B operand of v_mfma_f32_16x16x32_f16: column = a row)
+// and reads ALL of b straight from the caller's f32 rows, its 16 waves taking the 16-row b tiles round-robin (the next
+// tile's rows are requested before the current one is processed); both sides are split into f16 hi / lo in registers
+// (hi = truncation, lo = f16 of the residual, as the describe kernel splits its streams) and every pair gets the scan's
+// three terms in the scan's order (lo*hi, hi*lo, hi*hi, f32 accumulate); the waves' (best, index, second) meet in LDS.
+// Ties as everywhere: the higher b index wins.
+// Cost: every workgroup converts all of b (64 vector instructions per tile and lane beside 12 matrix instructions), which
+// is why this form is for small problems only (match_small_fits).  (Cutting b into ranges per a block, the ranges' results
+// folded by whichever workgroup of the block finishes last, was built and measured in round 4: the release / acquire
+// fences between workgroups on different XCDs write back and invalidate their L2s -- 4000 x 4000 took 300 us instead of
+// 62.  One range it stays.)
+constexpr int kSmallWaves = 16;
+
+__global__ __launch_bounds__(64 * kSmallWaves) void match_small(const float *__restrict__ a, long na,
+                                                                const float *__restrict__ b, long nb,
+                                                                const unsigned *__restrict__ excl_lo,
+                                                                const unsigned *__restrict__ excl_hi, float ratio,
+                                                                int *__restrict__ match, float *__restrict__ best_out,
+                                                                float *__restrict__ second_out,
+                                                                unsigned *__restrict__ overflowed_word) {
+    __shared__ float s_best[kSmallWaves][16], s_second[kSmallWaves][16];
+    __shared__ int s_idx[kSmallWaves][16];
+    if (overflowed_word && blockIdx.x == 0 && threadIdx.x == 0) *overflowed_word = 0u;   // this form redoes nothing
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = lane & 15, g = lane >> 4;
+    const long arow = (long)blockIdx.x * 16 + n;
+    const long arow_c = arow < na ? arow : na - 1;
+    struct Raw { f32x4 v[8]; };   // a row's share of the four k-steps: k = 32 s + 8 g .. + 7
+    auto load_row = [&](const float *row) {
+        Raw r;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            r.v[2 * s] = *reinterpret_cast<const f32x4 *>(row + 32 * s + 8 * g);
+            r.v[2 * s + 1] = *reinterpret_cast<const f32x4 *>(row + 32 * s + 8 * g + 4);
+        }
+        return r;
+    };
+    float one = 1.f;
+    asm("" : "+v"(one));   // (keeps the residual a single v_fma_mix_f32: see AFrag in mkd_describe.hip)
+    auto split8 = [&](const f32x4 &v0, const f32x4 &v1, h8 &hi, h8 &lo) {
+        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        u32x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2 * e], v[2 * e + 1]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float r0 = __builtin_fmaf(v[2 * e], one, -(float)__builtin_bit_cast(_Float16, (unsigned short)(h[e] & 0xffffu)));
+            const float r1 = __builtin_fmaf(v[2 * e + 1], one, -(float)__builtin_bit_cast(_Float16, (unsigned short)(h[e] >> 16)));
+            l[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+        }
+        hi = __builtin_bit_cast(h8, h);
+        lo = __builtin_bit_cast(h8, l);
+    };
+    // a fragments: lane (n, g) holds a[row n][32 s + 8 g + j] of k-step s
+    h8 ah[4], al[4];
+    {
+        const Raw ra = load_row(a + arow_c * 128);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) split8(ra.v[2 * s], ra.v[2 * s + 1], ah[s], al[s]);
+    }
+    const unsigned lo_x = excl_lo && arow < na ? excl_lo[arow] : 0u, hi_x = excl_lo && arow < na ? excl_hi[arow] : 0u;
+    float best = -INFINITY, second = -INFINITY;
+    int best_i = -1;
+    const long b_tiles = (nb + 15) / 16, t_first = 0;
+    auto b_row = [&](long t) {   // as A operand: lane (n, g) brings b row n of tile t (clamped: masked below)
+        const long r = t * 16 + n;
+        return b + (r < nb ? r : nb - 1) * 128;
+    };
+    Raw cur = load_row(b_row(t_first + wave < b_tiles ? t_first + wave : 0));
+    for (long t = t_first + wave; t < b_tiles; t += kSmallWaves) {
+        const long tn = t + kSmallWaves < b_tiles ? t + kSmallWaves : t;
+        const Raw nxt = load_row(b_row(tn));                // in flight while this tile is split and multiplied
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            h8 bh, bl;
+            split8(cur.v[2 * s], cur.v[2 * s + 1], bh, bl);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[s], acc, 0, 0, 0);
+        }
+        // the lane holds (a row n) x (b rows 16 t + 4 g + i), ascending: the later index wins among equals
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned row = (unsigned)(t * 16 + 4 * g + i);
+            const bool masked = row >= (unsigned)nb || (row >= lo_x && row < hi_x);
+            const float v = masked ? -INFINITY : acc[i];
+            const bool nb_ = v >= best && v > -INFINITY;
+            const bool ns = !nb_ && v > second;
+            second = nb_ ? best : (ns ? v : second);
+            best_i = nb_ ? (int)row : best_i;
+            best = nb_ ? v : best;
+        }
+        cur = nxt;
+    }
+    // fold: the four row groups of a column (lanes n, n + 16, n + 32, n + 48), then the waves
+    auto fold = [](float &b0, int &i0, float &s0, float ob, int oi, float os) {
+        const bool other = ob > b0 || (ob == b0 && oi > i0);
+        const float ns = other ? fmaxf(b0, os) : fmaxf(s0, ob);
+        i0 = other ? oi : i0;
+        b0 = other ? ob : b0;
+        s0 = ns;
+    };
+#pragma unroll
+    for (int m = 16; m <= 32; m <<= 1) {
+        const float ob = __shfl_xor(best, m), os = __shfl_xor(second, m);
+        const int oi = __shfl_xor(best_i, m);
+        fold(best, best_i, second, ob, oi, os);
+    }
+    if (g == 0) { s_best[wave][n] = best; s_second[wave][n] = second; s_idx[wave][n] = best_i; }
+    __syncthreads();
+    float bb = -INFINITY, ss = -INFINITY;
+    int bi = -1;
+    if (threadIdx.x < 16) {
+        bb = s_best[0][n];
+        ss = s_second[0][n];
+        bi = s_idx[0][n];
+#pragma unroll
+        for (int w = 1; w < kSmallWaves; ++w) fold(bb, bi, ss, s_best[w][n], s_idx[w][n], s_second[w][n]);
+    }
+    if (threadIdx.x < 16 && arow < na) {
+        match[arow] = (bi >= 0 && (ratio <= 0.f || bb * ratio > ss)) ? bi : -1;
+        if (best_out) best_out[arow] = bb;
+        if (second_out) second_out[arow] = ss;
+    }
+}
+
 // ---- two-pass form ----------------------------------------------------------------------------------------------
 // Screen: s~ = <hi(a), hi(b)> on the matrix cores.  With a = hi(a) + da, |da_k| <= 2^-11 |a_k| (f16 round to nearest;
 // below 2^-14 the f16 grid is 2^-24 wide, the MFMA does not flush) and the same for b,
@@ -315,7 +446,6 @@ constexpr int kStageTiles = 2;   // b tiles per LDS stage of the screen (one bar
 constexpr int kSub = 4;          // a sub-tiles of 16 rows per wave (the same 64 a rows as the scan's two tiles of 32)
 constexpr int kLanesPerRow = 4;  // lanes that hold values of one a row: streams per (a row, b split)
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // The screen uses v_mfma_f32_16x16x32_f16 (the chip holds a higher clock under this shape than under 32x32x16 on
 // non-trivial operands, MI355X_MICROARCH.md "DVFS give-back" (7)): b rows on the M side again, so lane (n = lane & 15,
@@ -625,6 +755,18 @@ void launch_match(const unsigned char *a_tiles, long na, const unsigned char *b_
     if (na <= 0) return;
     launch_scan_merge(a_tiles, na, b_tiles, nb, excl_lo, excl_hi, ratio, splits, p_best, p_index, p_second, match, best,
                       second, MatchGate{n_over, nullptr, kOverRows, 0}, stream);
+}
+
+// every workgroup walks all of b: beyond a few thousand candidates the scan's shared operand tiles win (measured: 8192 x 2048
+// and 1000 x 16000 are faster through the scan, 4000 x 4000 is level: the limit is half of that)
+bool match_small_fits(long na, long nb) { return na > 0 && nb >= 2 && nb <= 4096 && (double)na * (double)nb <= 8388608.0; }
+
+void launch_match_small(const float *a, long na, const float *b, long nb, const unsigned *excl_lo, const unsigned *excl_hi,
+                        float ratio, int *match, float *best, float *second, unsigned *overflowed_word,
+                        hipStream_t stream) {
+    if (na <= 0) return;
+    hipLaunchKernelGGL(match_small, dim3((unsigned)((na + 15) / 16)), dim3(64 * kSmallWaves), 0, stream, a, na, b, nb,
+                       excl_lo, excl_hi, ratio, match, best, second, overflowed_word);
 }
 
 size_t match_few_tiles_bytes() { return match_tiles_bytes(kOverRows); }

@@ -88,8 +88,13 @@ def test_extrema_edge_cases(lfp, oracle):
             assert len(got) == 0
 
 
-@pytest.mark.parametrize("n", [5000, 40000])      # one workgroup / the multi-workgroup form for long lists
-def test_topk_filter_vs_oracle(lfp, torch, oracle, n):
+# n <= 8192: one workgroup of topk_filter; up to 32 768: one workgroup with the list in its registers (topk_one);
+# beyond that, or with LF_MKD_TOPK=multi: the five-launch form spread over the chip
+@pytest.mark.parametrize("n,form", [(5000, ""), (9000, ""), (20001, ""), (20001, "multi"), (32768, ""), (40000, ""),
+                                    (70000, "")])
+def test_topk_filter_vs_oracle(lfp, torch, oracle, n, form, monkeypatch):
+    if form:
+        monkeypatch.setenv("LF_MKD_TOPK", form)
     rng = np.random.default_rng(3)
     ex = np.stack([rng.uniform(5, 600, n), rng.uniform(5, 400, n), 0.82 * np.sqrt(2) * 2 ** rng.uniform(1, 4.4, n),
                    rng.uniform(0.035, 0.5, n)], axis=1).astype(np.float32)

@@ -8,9 +8,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["scan", "screen"])
+@pytest.fixture(autouse=True, params=["small", "scan", "screen"])
 def form(request, monkeypatch):
-    """Every test runs on both forms of the matcher (lf_mkd.h): the library picks by problem size, LF_MKD_MATCH forces."""
+    """Every test runs on every form of the matcher (lf_mkd.h): the library picks by problem size, LF_MKD_MATCH forces
+    (small: where the problem fits one launch, the scan otherwise)."""
     monkeypatch.setenv("LF_MKD_MATCH", request.param)
     return request.param
 
@@ -208,8 +209,8 @@ def _crowded(lfp, torch, oracle):
 def test_match_of_unnormalised_rows(lfp, torch, oracle, scale_a, scale_b, form):
     """The screening margin is derived from the rows' norms, not assumed: scaled inputs (f16 subnormals included) decide
     as the oracle does.  (The scan form is specified for rows of unit norm or larger, lf_mkd.h.)"""
-    if form == "scan" and min(scale_a, scale_b) < 1:
-        pytest.skip("scan form: rows of unit norm or larger")
+    if form in ("scan", "small") and min(scale_a, scale_b) < 1:
+        pytest.skip("scan and small forms: rows of unit norm or larger")
     a, b = descriptor_sets(1500, 3000, 11)
     rng = np.random.default_rng(12)
     a = (a * scale_a * rng.uniform(0.5, 2.0, (len(a), 1))).astype(np.float32)
@@ -244,11 +245,12 @@ def test_more_rows_than_one_pass_takes(lfp, torch, oracle):
 
 
 def test_the_library_picks_a_form_by_size(lfp, torch, oracle, form, monkeypatch):
-    """Without LF_MKD_MATCH: a problem below the threshold (scan) and one above it (screen) both decide as the oracle."""
+    """Without LF_MKD_MATCH: a problem that fits one launch (small), one between the thresholds (scan) and one above them
+    (screen) all decide as the oracle."""
     if form != "screen":
         pytest.skip("one run is enough")
     monkeypatch.delenv("LF_MKD_MATCH")
-    for na, nb in ((3000, 5000), (16384, 32768)):
+    for na, nb in ((2000, 2000), (6000, 9000), (16384, 32768)):
         a, b = descriptor_sets(na, nb, na ^ nb)
         want, s1, s2 = oracle.match(a, b)
         got, g1, g2 = run_device(lfp, torch, a, b)

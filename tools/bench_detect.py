@@ -25,7 +25,7 @@ def frame(h, w, seed, sigma=2.5):
 def run(w, h, top_n, frames, tag, sigma=2.5):
     cap = 2 * top_n
     hnd = lfp.MkdHandle(max_features=cap, max_image_width=w, max_image_height=h, pool_mode=lfp.POOL_F16X3,
-                        max_blobs=1 << 17)
+                        max_blobs=1 << 16)
     s = torch.cuda.current_stream().cuda_stream
     imgs = [frame(h, w, 100 + f, sigma) for f in range(4)]
     ex = torch.empty((1 << 17, 4), device="cuda")
@@ -57,7 +57,7 @@ def run_graph(w, h, top_n, frames, tag, sigma=2.5):
     """the same frames through lf_mkd_stream_*: one hipGraph launch per frame, no host round trip"""
     cap = 2 * top_n
     hnd = lfp.MkdHandle(max_features=cap, max_image_width=w, max_image_height=h, pool_mode=lfp.POOL_F16X3,
-                        max_blobs=1 << 17)
+                        max_blobs=1 << 16)
     s = torch.cuda.current_stream().cuda_stream
     imgs = [frame(h, w, 100 + f, sigma) for f in range(4)]
     d_img = torch.empty((h, w), device="cuda")
