@@ -763,12 +763,22 @@ def main():
                 ndesc = sum(g["descriptors"] for g in good)
                 alg = good[0]["algorithmic_bytes_per_call"]
                 ach = alg / (slow * 1e-3) / 1e9
+                kp_traffic = None        # PMC counters of the same call, quoted if they were taken on this very source
+                try:
+                    kj = json.load(open(os.path.join(ROOT, "profiles", "traffic_keypoint_mode.json")))
+                    if (kj.get("source_sha256") == keypoint_source_stamp() and args.frames_per_gpu == 128
+                            and args.kpts_per_image == 8192):
+                        kp_traffic = kj.get("hbm_bytes_per_call", {}).get("configs3_128x1080p_8192_keypoints")
+                except Exception:
+                    kp_traffic = None
                 kp.update({"descriptors_per_s": ndesc / (slow * 1e-3), "descriptors_per_s_per_gpu": ndesc / world / (slow * 1e-3),
                            "describe_only_descriptors_per_s_per_gpu":
                                good[0]["descriptors"] / (max(g["describe_kernel_ms"] for g in good) * 1e-3),
                            "frames_of_rank0": good[0]["first_global_frames"],
                            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                        "frac": ach / HBM_PEAK_GBS, "traffic": kp_traffic,
+                                        "counters_from": "profiles/traffic_keypoint_mode.json (rocprofv3 --pmc, builder's box)"
+                                                         if kp_traffic else None,
                                         "algorithmic_bytes_per_call": alg,
                                         "algorithmic_bytes_per_descriptor": alg / good[0]["descriptors"],
                                         "what": "per GPU: 528 B per keypoint (16 in, 512 out) + the frames' bytes, over the "

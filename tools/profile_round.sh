@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --cpu-sample 0 --no-extras --no-match"
+ARGS="--steps 5 --warmup 2 --cpu-sample 0 --no-extras --no-match --frames-per-gpu 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1
@@ -23,4 +23,8 @@ rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ --ou
 # configs[1] (one 1080p frame, 10 000 keypoints): HBM traffic of the same call
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/kp1_fetch -- python3 $R/tools/prof_keypoints.py configs1 > $OUT/kp1_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/kp1_write -- python3 $R/tools/prof_keypoints.py configs1 > $OUT/kp1_write.log 2>&1
+# configs[3] in its own form, one GPU's share (128 frames 1080p x 8192 keypoints): kernel times and HBM traffic
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kp3_stats -- python3 $R/tools/prof_keypoints.py configs3 > $OUT/kp3_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/kp3_fetch -- python3 $R/tools/prof_keypoints.py configs3 > $OUT/kp3_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/kp3_write -- python3 $R/tools/prof_keypoints.py configs3 > $OUT/kp3_write.log 2>&1
 tail -1 $OUT/stats.log | cut -c1-400

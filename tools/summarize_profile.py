@@ -204,6 +204,24 @@ if kp_stats:
                 f"{tot1 / 10000:.0f} B per descriptor (same correction); algorithmic {alg1 / 1e6:.1f} MB = {alg1 / 10000:.0f} B per descriptor "
                 f"-> ratio {tot1 / alg1:.1f}.", ""]
         per_call["configs1_1080p_10k_keypoints"] = tot1
+    # configs[3] in its own form, one GPU's share: 128 frames 1920 x 1080, 8192 keypoints each
+    f3, w3 = per_kernel("kp3_fetch", "FETCH_SIZE"), per_kernel("kp3_write", "WRITE_SIZE")
+    kp3_stats = newest("kp3_stats", "*kernel_stats.csv")
+    if f3 and w3:
+        rd3 = lambda k, v: v * (1.0 if k.startswith("mkd_pool") else 2.0)      # the same correction
+        n3 = 128 * 8192
+        tot3 = sum(rd3(k, v) for k, v in f3.items() if ours(k)) / calls * 1024 + sum(v for k, v in w3.items() if ours(k)) / calls * 1024
+        alg3 = n3 * (16 + 512) + 128 * 1920 * 1080 * 4
+        out += [f"configs[3] in its own form, one GPU's share (128 frames 1920 x 1080, 8192 keypoints each = 2^20 descriptors; "
+                f"`prof_keypoints.py configs3`): {tot3 / 1e9:.2f} GB per call = {tot3 / n3:.0f} B per descriptor (same correction); "
+                f"algorithmic {alg3 / 1e9:.3f} GB = {alg3 / n3:.0f} B per descriptor -> ratio {tot3 / alg3:.1f}.", ""]
+        per_call["configs3_128x1080p_8192_keypoints"] = tot3
+        if kp3_stats:
+            out += ["| kernel (configs[3] own form) | calls | avg us | total ms |", "|---|---|---|---|"]
+            for r in sorted((r for r in csv.DictReader(open(kp3_stats)) if "lfmkd" in r["Name"]), key=lambda r: -float(r["TotalDurationNs"])):
+                name = r["Name"].split("(")[0].replace("void ", "").replace("lfmkd::", "")
+                out.append(f"| `{name}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.2f} |")
+            out.append("")
     if per_call:
         json.dump({"tag": tag, "source_sha256": stamp(("mkd_describe.hip", "mkd_pyramid.hip", "mkd_sample.h", "mkd_device.h", "lf_mkd.cpp")),
                    "git_head_at_summary": head, "hbm_bytes_per_call": per_call,
