@@ -344,23 +344,22 @@ __global__ __launch_bounds__(64 * kSmallWaves) void match_small(const float *__r
         hi = __builtin_bit_cast(h8, h);
         lo = __builtin_bit_cast(h8, l);
     };
-    // a fragments: lane (n, g) holds a[row n][32 s + 8 g + j] of k-step s
-    h8 ah[4], al[4];
-    {
-        const Raw ra = load_row(a + arow_c * 128);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) split8(ra.v[2 * s], ra.v[2 * s + 1], ah[s], al[s]);
-    }
-    const unsigned lo_x = excl_lo && arow < na ? excl_lo[arow] : 0u, hi_x = excl_lo && arow < na ? excl_hi[arow] : 0u;
-    float best = -INFINITY, second = -INFINITY;
-    int best_i = -1;
-    const long b_tiles = (nb + 15) / 16, t_first = 0;
+    const long b_tiles = (nb + 15) / 16;
     auto b_row = [&](long t) {   // as A operand: lane (n, g) brings b row n of tile t (clamped: masked below)
         const long r = t * 16 + n;
         return b + (r < nb ? r : nb - 1) * 128;
     };
-    Raw cur = load_row(b_row(t_first + wave < b_tiles ? t_first + wave : 0));
-    for (long t = t_first + wave; t < b_tiles; t += kSmallWaves) {
+    // the wave's first b tile is requested together with its a rows: one round trip to memory in front of the loop, not two
+    const Raw ra = load_row(a + arow_c * 128);
+    Raw cur = load_row(b_row(wave < b_tiles ? wave : 0));
+    // a fragments: lane (n, g) holds a[row n][32 s + 8 g + j] of k-step s
+    h8 ah[4], al[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) split8(ra.v[2 * s], ra.v[2 * s + 1], ah[s], al[s]);
+    const unsigned lo_x = excl_lo && arow < na ? excl_lo[arow] : 0u, hi_x = excl_lo && arow < na ? excl_hi[arow] : 0u;
+    float best = -INFINITY, second = -INFINITY;
+    int best_i = -1;
+    for (long t = wave; t < b_tiles; t += kSmallWaves) {
         const long tn = t + kSmallWaves < b_tiles ? t + kSmallWaves : t;
         const Raw nxt = load_row(b_row(tn));                // in flight while this tile is split and multiplied
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -372,7 +371,9 @@ __global__ __launch_bounds__(64 * kSmallWaves) void match_small(const float *__r
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[s], acc, 0, 0, 0);
         }
-        // the lane holds (a row n) x (b rows 16 t + 4 g + i), ascending: the later index wins among equals
+        // the lane holds (a row n) x (b rows 16 t + 4 g + i), ascending: the later index wins among equals.  (The scan's
+        // "does this tile hold a new best at all" short cut was measured here and lost 3 us at 2000 x 2000: with eight tiles
+        // per wave the running best is still settling in most of them.)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned row = (unsigned)(t * 16 + 4 * g + i);
