@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised soak of the matcher against the CPU oracle: random shapes, ratios, exclusion ranges, planted duplicates and
-clusters, both forms (LF_MKD_MATCH=scan / screen).  A differing decision is tolerated only at a near-tie (2e-6), as in
+clusters, every form (LF_MKD_MATCH=small / scan / screen; small: where the problem fits one launch, the scan otherwise).  A differing decision is tolerated only at a near-tie (2e-6), as in
 tests/test_gpu_match.py.  Usage: soak_match.py [seconds] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,7 +44,7 @@ while time.time() < t_end:
     d_a, d_b = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
     d_lo = torch.from_numpy(excl[0].view(np.int32)).cuda() if excl else None
     d_hi = torch.from_numpy(excl[1].view(np.int32)).cuda() if excl else None
-    for form in ("scan", "screen"):
+    for form in ("small", "scan", "screen"):
         os.environ["LF_MKD_MATCH"] = form
         d_m = torch.empty(na, dtype=torch.int32, device="cuda")
         d_1, d_2 = torch.empty(na, device="cuda"), torch.empty(na, device="cuda")
@@ -63,5 +63,5 @@ while time.time() < t_end:
             assert tie, (form, na, nb, ratio, int(i), int(got[i]), int(want[i]), float(s1[i]), float(s2[i]))
             near_ties += 1
     cases += 1
-print(f"soak_match: {cases} cases x 2 forms, worst similarity error {worst:.2e}, decisions differing at near-ties "
+print(f"soak_match: {cases} cases x 3 forms, worst similarity error {worst:.2e}, decisions differing at near-ties "
       f"{near_ties}, rows redone by the full scan {redone}: all decisions equal the oracle's")
