@@ -299,9 +299,11 @@ __global__ __launch_bounds__(256) void match_merge(const float *__restrict__ p_b
 // Ties as everywhere: the higher b index wins.
 // Cost: every workgroup converts all of b (64 vector instructions per tile and lane beside 12 matrix instructions), which
 // is why this form is for small problems only (match_small_fits).  (Cutting b into ranges per a block, the ranges' results
-// folded by whichever workgroup of the block finishes last, was built and measured in round 4: the release / acquire
-// fences between workgroups on different XCDs write back and invalidate their L2s -- 4000 x 4000 took 300 us instead of
-// 62.  One range it stays.)
+// folded by whichever workgroup of the block finishes last, was built twice in round 4 and measured: with the partial
+// results in memory behind release / acquire fences 4000 x 4000 took 300 us instead of 62 -- the fences write back and
+// invalidate the XCDs' L2s; with the results meeting in two atomically maintained 64-bit words per a row (largest key,
+// largest key that ever lost; device-scope atomics only, no fence) 2000 x 2000 took 50 us instead of 35 -- 30 k
+// device-scope atomics, five workgroups per word.  One range it stays.)
 constexpr int kSmallWaves = 16;
 
 __global__ __launch_bounds__(64 * kSmallWaves) void match_small(const float *__restrict__ a, long na,

@@ -11,7 +11,7 @@ import local_features_python as lfp
 torch.cuda.set_stream(torch.cuda.Stream())
 h = lfp.MkdHandle(max_features=64)
 s = torch.cuda.current_stream().cuda_stream
-for na, nb in ((2000, 2000), (500, 500), (4000, 4000), (1000, 16000), (8192, 2048), (64, 8000), (10000, 10000)):
+for na, nb in ((2000, 2000), (500, 500), (256, 256), (1000, 4000), (3000, 2500), (4000, 4000), (8192, 2048), (64, 8000), (10000, 10000)):
     g = torch.Generator(device="cuda").manual_seed(na + nb)
     b = torch.nn.functional.normalize(torch.randn((nb, 128), device="cuda", generator=g), dim=1)
     a = torch.nn.functional.normalize(b[torch.randint(0, nb, (na,), device="cuda", generator=g)]
