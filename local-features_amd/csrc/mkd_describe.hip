@@ -737,6 +737,14 @@ __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_fl
 // producer can afford, so a describe wave issues no memory instruction between its barriers.
 struct KpTaps { f32x2 top[8], bot[8]; float ax[8], ay[8]; };
 
+// min(max(x, 0), hi) for hi >= 0 as ONE instruction (the median of x, 0, hi); hipcc cannot fuse the pair itself because it
+// does not know hi >= 0
+__device__ __forceinline__ int clamp_med3(int x, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+    return r;
+}
+
 // (uniform base) + (unsigned 32-bit lane offset) -> global_load_dwordx2 v, v_off, s[base:base+1]: no 64-bit address arithmetic
 // (the two empty asm statements: see lds_dma16_sv).  Texel addresses are 4-byte aligned only.
 __device__ __forceinline__ f32x2 load2_sv(const unsigned char *uniform_base, unsigned lane_off) {
@@ -800,13 +808,16 @@ struct KpSampler {
             const float cx = readlane_f(g_cx, src), cy = readlane_f(g_cy, src);
             const int xmax = readlane_i(g_xmax, src), ymax = readlane_i(g_ymax, src), pitch4 = 4 * (xmax + 2);
             constexpr int apron = kPyrApron;
-            const unsigned char *a0 = base_of(src);
+            const unsigned char *a0 = base_of(src), *a1 = a0 + pitch4;   // the two tap rows: two uniform bases, one lane offset
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const SamplePos p = sample_position(ca, sa, rem, cx, cy, 16 * hh + c, ly);
                 t.ax[2 * i + hh] = p.ax;
                 t.ay[2 * i + hh] = p.ay;
-                const int ix = min(max(p.ix + apron, 0), xmax), iy = min(max(p.iy + apron, 0), ymax);
+                // the apron goes onto both coordinates as ONE two-wide float addition (exact: integers far below 2^23)
+                typedef float v2 __attribute__((ext_vector_type(2)));
+                const v2 fa = v2{p.fx0, p.fy0} + v2{(float)apron, (float)apron};
+                const int ix = clamp_med3((int)fa.x, xmax), iy = clamp_med3((int)fa.y, ymax);
                 const unsigned off = __umul24((unsigned)iy, (unsigned)pitch4) + 4u * (unsigned)ix;   // both < 2^24: full-rate multiply
                 if constexpr (ablate::kNoTaps) {
                     t.top[2 * i + hh] = f32x2{__uint_as_float(off), p.ax};
@@ -814,7 +825,7 @@ struct KpSampler {
                     continue;
                 }
                 t.top[2 * i + hh] = load2_sv(a0, off);
-                t.bot[2 * i + hh] = load2_sv(a0, off + (unsigned)pitch4);
+                t.bot[2 * i + hh] = load2_sv(a1, off);
             }
         }
     }

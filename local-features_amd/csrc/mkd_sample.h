@@ -67,7 +67,7 @@ __device__ __forceinline__ KpGeom keypoint_geometry(float x, float y, float size
 
 // position of patch pixel (lx, ly) in texels of the keypoint's level: floor parts and fractions of the bilinear fetch at
 // normalised coordinate (s + 0.5) / size
-struct SamplePos { float ax, ay; int ix, iy; };
+struct SamplePos { float ax, ay; int ix, iy; float fx0, fy0; };   // (fx0, fy0) = (ix, iy) as floats: integers below 2^23
 
 __device__ __forceinline__ SamplePos sample_position(float ca, float sa, float rem, float cx, float cy, int lx, int ly) {
 #pragma clang fp contract(off)
@@ -88,6 +88,8 @@ __device__ __forceinline__ SamplePos sample_position(float ca, float sa, float r
     p.ay = a.y;
     p.ix = (int)f0.x;
     p.iy = (int)f0.y;
+    p.fx0 = f0.x;
+    p.fy0 = f0.y;
     return p;
 }
 
