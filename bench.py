@@ -524,7 +524,7 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
     return res
 
 
-def headline_line(args, world, n, total, dt, kern_s, achieved, alt, alt_f32, clock_mhz, wg0_ms):
+def headline_line(args, world, n, total, dt, kern_s, achieved, alt, alt_f32, alt_fp6, clock_mhz, wg0_ms):
     """The bench line without its match_stage / pipelines / cpu_baseline objects."""
     # HBM traffic of the kernel comes from rocprofv3 PMC passes (tools/profile_round.sh), which cannot run inside
     # this process: the committed figure is quoted only if it was measured on this very kernel source and workload
@@ -553,6 +553,7 @@ def headline_line(args, world, n, total, dt, kern_s, achieved, alt, alt_f32, clo
                    "parallelism": f"shard-by-rank x{world}, no collective in the describe path"},
         "exact_zero_angle_mode_value": alt,
         "f32_pool_mode_value": alt_f32,
+        "fp6_cross_pool_mode_value": alt_fp6,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "mkd_pool", "kernel_ms": kern_s * 1e3,
@@ -691,11 +692,14 @@ def main():
         torch.cuda.synchronize()
         return n * args.steps / (time.perf_counter() - t1)
 
-    alt = alt_f32 = None
+    alt = alt_f32 = alt_fp6 = None
     if world == 1 and args.angle == "shader" and args.pool == "f16x3":
         alt = side_figure(lfp.ANGLE_EXACT_ZERO, lfp.POOL_F16X3)
         # the same workload with the pooling contraction in exact f32 arithmetic (LF_MKD_POOL_F32, the verification mode)
         alt_f32 = side_figure(lfp.ANGLE_SHADER, lfp.POOL_F32)
+        # ... and with the harmonics' cross terms in e2m3 (LF_MKD_POOL_F16_FP6: round 4's formulation experiment, kept as a
+        # mode; 51 instead of 81 matrix instructions per wave-row at ~6 x the default mode's error)
+        alt_fp6 = side_figure(lfp.ANGLE_SHADER, lfp.POOL_F16_FP6)
 
     # sanity on the timed output: finite, unit norm (a wrong-but-fast kernel must not pass silently)
     nrm = out.norm(dim=1)
@@ -730,7 +734,7 @@ def main():
     failed = None          # why this run must end with a non-zero status although its line was printed
     desync = False         # an exception on this rank alone: its peers may be waiting in a collective
     if rank == 0:
-        line.update(headline_line(args, world, n, total, dt, kern_s, achieved, alt, alt_f32, clock_mhz, wg0_ms))
+        line.update(headline_line(args, world, n, total, dt, kern_s, achieved, alt, alt_f32, alt_fp6, clock_mhz, wg0_ms))
 
     # configs[3] in its own form (keypoint mode, frames sharded by image): every rank runs its share, with no collective
     # inside; one object gather afterwards, reached by every rank whatever happened locally

@@ -21,6 +21,7 @@ pub const LF_MKD_ANGLE_EXACT_ZERO: i32 = 2;
 pub const LF_MKD_POOL_DEFAULT: i32 = 0;
 pub const LF_MKD_POOL_F16X3: i32 = 1;
 pub const LF_MKD_POOL_F32: i32 = 2;
+pub const LF_MKD_POOL_F16_FP6: i32 = 3;
 pub const LF_MKD_FLAG_KERNEL_TIMING: u32 = 1;
 pub const LF_MKD_FLAG_UNFUSED_KEYPOINTS: u32 = 2;
 pub const LF_MKD_MAX_ANGLES_PER_EXTREMUM: usize = 18;

@@ -56,8 +56,14 @@ typedef enum { LF_MKD_ANGLE_SHADER = 0, LF_MKD_ANGLE_EXACT = 1, LF_MKD_ANGLE_EXA
  *           formulation (gate 1e-4).  THE DEFAULT (a zero-initialised lf_mkd_params selects it): ~250 M
  *           descriptors/s per MI355X in patch mode.
  * F32     : v_mfma_f32_16x16x4_f32, bit-for-bit an f32 fma chain; the verification mode, bound by the f32 MFMA
- *           rate at ~117 M descriptors/s (2.1x slower). */
-typedef enum { LF_MKD_POOL_DEFAULT = 0, LF_MKD_POOL_F16X3 = 1, LF_MKD_POOL_F32 = 2 } lf_mkd_pool_mode;
+ *           rate at ~117 M descriptors/s (2.1x slower).
+ * F16_FP6 : an experiment kept as a mode (round 4): hi*hi in f16 as above, the two cross terms of the
+ *           harmonics' streams in ONE block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 per accumulator tile with e2m3
+ *           operands (51 instead of 81 matrix instructions per wave-row).  e2m3 carries three bits below its block's
+ *           maximum: descriptors within ~5e-5 of the f32 formulation (inside the gate, ten times F16X3's error) for a
+ *           few per cent of speed -- NOT the default, not used for any reported parity figure.  Patch mode only: keypoint
+ *           entry points take the two-launch form in this mode. */
+typedef enum { LF_MKD_POOL_DEFAULT = 0, LF_MKD_POOL_F16X3 = 1, LF_MKD_POOL_F32 = 2, LF_MKD_POOL_F16_FP6 = 3 } lf_mkd_pool_mode;
 
 /* lf_mkd_params.flags */
 #define LF_MKD_FLAG_KERNEL_TIMING 1u /* bracket every kernel launch with HIP events on its stream;

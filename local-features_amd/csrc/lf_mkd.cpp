@@ -143,8 +143,9 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     h->params = *params;
     if (h->params.patch_scale_factor == 0.f) h->params.patch_scale_factor = 24.f;  // lib.rs:46
     if (h->params.pool_mode == LF_MKD_POOL_DEFAULT) h->params.pool_mode = LF_MKD_POOL_F16X3;
-    if (h->params.pool_mode != LF_MKD_POOL_F16X3 && h->params.pool_mode != LF_MKD_POOL_F32) {
-        g_create_error = "pool_mode must be LF_MKD_POOL_DEFAULT, LF_MKD_POOL_F16X3 or LF_MKD_POOL_F32";
+    if (h->params.pool_mode != LF_MKD_POOL_F16X3 && h->params.pool_mode != LF_MKD_POOL_F32 &&
+        h->params.pool_mode != LF_MKD_POOL_F16_FP6) {
+        g_create_error = "pool_mode must be LF_MKD_POOL_DEFAULT, LF_MKD_POOL_F16X3, LF_MKD_POOL_F32 or LF_MKD_POOL_F16_FP6";
         delete h;
         return LF_MKD_ERR_BAD_ARG;
     }
@@ -187,6 +188,8 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
     LF_CREATE_HIP(upload(&h->dc.colmap, hc.colmap.data(), hc.colmap.size() * 2));
     LF_CREATE_HIP(upload(&h->dc.pool_b_f32, hc.pool_b_f32.data(), hc.pool_b_f32.size() * 4));
     LF_CREATE_HIP(upload(&h->dc.pool_b_f16, hc.pool_b_f16.data(), hc.pool_b_f16.size() * 2));
+    if (h->params.pool_mode == LF_MKD_POOL_F16_FP6)
+        LF_CREATE_HIP(upload(&h->dc.pool_b_fp6, hc.pool_b_fp6.data(), hc.pool_b_fp6.size() * 2));
     LF_CREATE_HIP(upload(&h->dc.white_a_f16, hc.white_a_f16.data(), hc.white_a_f16.size() * 2));
     LF_CREATE_HIP(upload(&h->dc.white_a_f32, hc.white_a_f32.data(), hc.white_a_f32.size() * 4));
     LF_CREATE_HIP(upload(&h->dc.white_bias, hc.white_bias.data(), hc.white_bias.size() * 4));
@@ -478,7 +481,7 @@ void lf_mkd_destroy(lf_mkd *h) {
     if (!h) return;
     (void)hipSetDevice(h->params.device);
     (void)hipDeviceSynchronize();   // work of this handle may be in flight on the caller's streams too
-    void *ptrs[] = {h->dc.colmap,     h->dc.pool_b_f32, h->dc.pool_b_f16, h->dc.white_a_f16,
+    void *ptrs[] = {h->dc.colmap,     h->dc.pool_b_f32, h->dc.pool_b_f16, h->dc.pool_b_fp6, h->dc.white_a_f16,
                     h->dc.white_a_f32, h->dc.white_bias, h->d_patches,     h->d_out,         h->d_kps,
                     h->d_image,        h->d_pyr,         h->d_tmp_a,       h->d_tmp_b,       h->d_coarse,
                     h->d_extrema,      h->d_angles,      h->d_counts,      h->d_kps_out,     h->d_totals,      h->d_clk,

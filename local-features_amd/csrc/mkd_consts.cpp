@@ -47,6 +47,23 @@ float f16_value(uint16_t b) {
     return static_cast<float>(h);
 }
 
+// nearest e2m3 code of |v| <= 7.5 (6 bits: sign, 2 exponent, 3 mantissa; no infinities, no NaNs), ties to the even code
+uint32_t e2m3_bits(float v) {
+    const float a = std::fabs(v);
+    int best = 0;
+    float best_d = 1e30f;
+    for (int c = 0; c < 32; ++c) {
+        const int e = c >> 3, m = c & 7;
+        const float val = e == 0 ? float(m) / 8.f : (1.f + float(m) / 8.f) * float(1 << (e - 1));
+        const float d = std::fabs(val - a);
+        if (d < best_d || (d == best_d && (c & 1) == 0)) {
+            best_d = d;
+            best = c;
+        }
+    }
+    return uint32_t(best) | (v < 0.f ? 32u : 0u);
+}
+
 // One column of a LUT tile: which spatial kernel, rotated by which harmonic of phi.
 struct LutColumn {
     bool used;
@@ -206,6 +223,45 @@ void build_host_consts(const PcaModel &pca, HostConsts &hc) {
                     hc.pool_b_f16[(((size_t(y) * kUniqueTiles + ut) * 2 + 1) * 64 + lane) * 8 + e] = lo;
                 }
             }
+    // LF_MKD_POOL_F16_FP6: the cross-term operands of the harmonics' tiles (see mkd_consts.hpp)
+    hc.pool_b_fp6 = hc.pool_b_f16;
+    {
+        const float kX = 2048.f;      // the residuals' common factor (the kernel scales its stream residuals by the same)
+        auto slot_values = [&](int y, int ut, int lane, float (&sv)[16]) {
+            const LutColumn col = lut_column(ut, lane & 15);
+            const int q = lane >> 4;
+            for (int e = 0; e < 8; ++e) {
+                const float v = lut_value(col, y * kPatch + 8 * q + e);
+                const float hi = f16_value(f16_bits(v));
+                sv[2 * e] = kX * (v - hi);
+                sv[2 * e + 1] = hi;
+            }
+        };
+        for (int y = 0; y < kPatch; ++y)
+            for (int ut = 3; ut < kUniqueTiles; ++ut)
+                for (int lane = 0; lane < 64; ++lane) {
+                    float sv[16], other[16];
+                    slot_values(y, ut, lane, sv);
+                    float mx = 0.f;
+                    for (float v : sv) mx = std::fmax(mx, std::fabs(v));
+                    const int part = (ut - 3) % 4;
+                    if (part < 2) {   // P0 and Q0 of a harmonic share the scale
+                        slot_values(y, part == 0 ? ut + 1 : ut - 1, lane, other);
+                        for (float v : other) mx = std::fmax(mx, std::fabs(v));
+                    }
+                    int ex = 0;                                   // T = 2^ex with mx / T in [2, 4)
+                    if (mx > 0.f) ex = int(std::floor(std::log2(mx))) - 1;
+                    const float inv_t = std::ldexp(1.f, -ex);
+                    uint32_t w[4] = {0u, 0u, 0u, uint32_t(127 + ex) & 255u};
+                    for (int f = 0; f < 16; ++f) {
+                        const uint64_t bits = uint64_t(e2m3_bits(sv[f] * inv_t)) << ((6 * f) & 31);
+                        w[(6 * f) / 32] |= uint32_t(bits);
+                        if ((6 * f) / 32 + 1 < 3) w[(6 * f) / 32 + 1] |= uint32_t(bits >> 32);
+                    }
+                    uint16_t *dst = &hc.pool_b_fp6[(((size_t(y) * kUniqueTiles + ut) * 2 + 1) * 64 + lane) * 8];
+                    std::memcpy(dst, w, 16);
+                }
+    }
     auto w_packed = [&](int n, int packed_col) -> float {
         const int d = packed_col < kPackedCols ? hc.colmap[packed_col] : -1;
         return d < 0 ? 0.f : hc.w_t[size_t(n) * kRaw + d];

@@ -64,6 +64,12 @@ struct HostConsts {
     // f16 hi/lo pooling fragments for v_mfma_f32_16x16x32_f16 (B[k][col], k = 8*(lane>>4)+e):
     //   [row y 32][unique tile 15][hi|lo 2][lane 64][e 8] (uint16 bit patterns); v = hi + lo, both f16
     std::vector<uint16_t> pool_b_f16;
+    // The same row images for LF_MKD_POOL_F16_FP6: the hi pieces (and the m stream's three tiles) as above; for the tiles of
+    // the harmonics the lo piece is replaced by the lane's operand of v_mfma_scale_f32_16x16x128_f8f6f4 that carries BOTH
+    // cross terms of the split: 16 e2m3 fields (12 bytes) -- field 2e = 2048 (v - hi) / T, field 2e + 1 = hi / T for the
+    // lane's pixel e -- and a word with the lane's block scale T as an E8M0 byte (tiles P0 and Q0 of a harmonic share T:
+    // they meet in one instruction).
+    std::vector<uint16_t> pool_b_fp6;
     // Whitening as out^T = W_T x raw with the pooling accumulators as B operand: a lane (patch p, q) holds
     // packed columns 16t + 4q + i in accumulator (t, i).  A fragments = rows of W_T, K ordered to match:
     //   f16 (16x16x32): [step 11][row tile 8][hi|lo 2][lane 64][j 8], lane = (row n = lane&15, q = lane>>4),

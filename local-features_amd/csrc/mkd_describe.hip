@@ -34,6 +34,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 pk_set(float v) { return f32x2{v, v}; }
 
+// LF_POOL_F16X3 and LF_POOL_F16_FP6 share everything but the arithmetic of the harmonics' cross terms (row images by
+// LDS-DMA, counted vmcnt waits, the f16x3 whitening epilogue, the m stream's three tiles)
+__device__ __host__ constexpr bool f16_family(int pool) { return pool == LF_POOL_F16X3 || pool == LF_POOL_F16_FP6; }
+
 // Seven per-pixel streams -- m, and m cos / sin (k theta) for k = 1..3 -- are pooled; the rotation by gradient_angle(px)
 // that the polar kernels' streams carry (embedding.glsl:70-72) is folded into the LUT (mkd_consts.hpp):
 //   LUT tiles of a patch row: 0-2 m | per harmonic h = k-1, 3 + 4h + {0: P0 = EPc[0:16], 1: Q0 = EPs[0:16],
@@ -357,6 +361,7 @@ template <> struct AFrag<LF_POOL_F16X3> {
 // dependent MFMAs of one tile.
 template <int POOL, int PART>
 __device__ __forceinline__ void mma_part(const AFrag<POOL> &a, const BFrag &b, f32x4 &acc) {
+    static_assert(POOL == LF_POOL_F32 || POOL == LF_POOL_F16X3, "the three-term / f32 forms");
     if constexpr (ablate::kNoMma && POOL == LF_POOL_F16X3) {   // (operands kept alive)
         asm volatile("" ::"v"(a.hi), "v"(a.lo), "v"(b.p0), "v"(b.p1));
         return;
@@ -494,6 +499,111 @@ __device__ __forceinline__ void pool_harmonics(const f32x2 (&m)[4], const f32x2 
     }
 }
 
+// LF_POOL_F16_FP6 (an experiment kept as a mode): the harmonics with hi x hi in f16 (8 instructions per
+// harmonic) and BOTH cross terms of every accumulator tile in one v_mfma_scale_f32_16x16x128_f8f6f4 with e2m3 operands (7):
+// a lane's 32 K slots hold (a_e, 2048 r_e) of its 8 pixels for the cos stream (fields 0-15 = registers 0-2) and for the
+// sin stream (16-31 = registers 3-5), a = the stream value, r = a - f16(a), all divided by the lane's block scale S (from
+// the largest m of its 8 pixels: |a| <= m); the LUT operand holds (2048 lo, hi) / T the same way (mkd_consts.hpp).  The
+// two streams' values go through ONE v_cvt_scalef32_2xpk16_fp6_f32, which interleaves its two 16-value sources field by
+// field (tools/micro/fp6_cross.hip).  A single-stream product reads the stream's three registers beside three zeros (the
+// LUT registers opposite them may hold anything: e2m3 has no NaN or infinity); the merged tile reads all six.
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef unsigned v6u __attribute__((ext_vector_type(6)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void pool_harmonics_fp6(const f32x2 (&m)[4], const f32x2 (&c1)[4], const f32x2 (&s1)[4],
+                                                   const unsigned char *brow, BFrag &g, f32x4 (&acc)[kAccTiles]) {
+    // the harmonic's two streams live in the conversion's first source, aq = (pk[0..3], qk[0..3]): the recurrence writes the
+    // next harmonic into a fresh one (the k loop is unrolled: renaming, no copies)
+    v16f aq, ap;
+    f32x2 tc[4];
+    auto pair = [](const v16f &v, int i) { return f32x2{v[2 * i], v[2 * i + 1]}; };
+    auto put = [](v16f &v, int i, f32x2 x) { v[2 * i] = x.x; v[2 * i + 1] = x.y; };
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        put(aq, e, m[e] * c1[e]);
+        put(aq, 4 + e, m[e] * s1[e]);
+        tc[e] = c1[e] + c1[e];
+    }
+    // block scale S = 2^(exponent of the largest m) / 2: every |a| / S < 4 and every 2048 r / S < 4 (r < one f16 ulp of a)
+    float mx = fmaxf(fmaxf(m[0].x, m[0].y), fmaxf(m[1].x, m[1].y));
+    mx = fmaxf(mx, fmaxf(fmaxf(m[2].x, m[2].y), fmaxf(m[3].x, m[3].y)));
+    const unsigned s_bits = (__float_as_uint(mx) & 0x7F800000u) - 0x00800000u;
+    const float s_scale = __uint_as_float(s_bits);
+    const int scale_b = (int)(s_bits >> 23) - 11;        // E8M0 of S / 2048
+    float one = 1.f;
+    asm("" : "+v"(one));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        u32x4 hc, hs;
+        v16f r16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x2 p = pair(aq, e), q = pair(aq, 4 + e);
+            hc[e] = pack_rtz(p.x, p.y);
+            hs[e] = pack_rtz(q.x, q.y);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x2 p = pair(aq, e), q = pair(aq, 4 + e);
+            const f32x2 rc = {__builtin_fmaf(p.x, one, -(float)__builtin_bit_cast(_Float16, (unsigned short)(hc[e] & 0xffffu))),
+                              __builtin_fmaf(p.y, one, -(float)__builtin_bit_cast(_Float16, (unsigned short)(hc[e] >> 16)))};
+            const f32x2 rs = {__builtin_fmaf(q.x, one, -(float)__builtin_bit_cast(_Float16, (unsigned short)(hs[e] & 0xffffu))),
+                              __builtin_fmaf(q.y, one, -(float)__builtin_bit_cast(_Float16, (unsigned short)(hs[e] >> 16)))};
+            put(r16, e, rc * pk_set(2048.f));
+            put(r16, 4 + e, rs * pk_set(2048.f));
+        }
+        // (written as inline assembly for its early-clobber destination: through the builtin, hipcc of ROCm 7.2 lets the six
+        //  destination registers overlap a source that dies here -- v[36:41] <- v[16:31], v[32:47] -- and the instruction
+        //  writes them while it still reads its thirty-two inputs: harmonics 2 and 3 came out with garbage cross terms)
+        v6u d;
+        asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(aq), "v"(r16), "v"(s_scale));
+        if (k < 2) {   // x_{k+1} = 2 c1 x_k - x_{k-1}, written over x_{k-1}; then the two change roles
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 p = pair(aq, e), q = pair(aq, 4 + e);
+                put(ap, e, pk_fma(tc[e], p, k == 0 ? -m[e] : -pair(ap, e)));
+                put(ap, 4 + e, k == 0 ? tc[e] * q : pk_fma(tc[e], q, -pair(ap, 4 + e)));
+            }
+            const v16f t = aq;
+            aq = ap;
+            ap = t;
+        }
+        const int a0 = 3 + 7 * k, u0 = 3 + 4 * k;
+        const BFrag p0 = g, q0 = load_b(brow, u0 + 1), r = load_b(brow, u0 + 2), sf = load_b(brow, u0 + 3);
+        if (k < 2) g = load_b(brow, u0 + 4);
+        const f16x8 ch = __builtin_bit_cast(f16x8, hc), sh = __builtin_bit_cast(f16x8, hs);
+        auto hh = [&](const BFrag &b, const f16x8 &st, f32x4 &c) {
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b.p0), st, c, 0, 0, 0);
+        };
+        // hi x hi: cos x P0 -> a0 | sin x P0, cos x Q0 -> a0+2 | sin x Q0 -> a0+1 | cos, sin x R -> a0+3, a0+4 | x S -> a0+5, a0+6
+        hh(p0, ch, acc[a0 + 0]); hh(p0, sh, acc[a0 + 2]); hh(q0, sh, acc[a0 + 1]); hh(r, ch, acc[a0 + 3]);
+        hh(r, sh, acc[a0 + 4]); hh(sf, ch, acc[a0 + 5]); hh(sf, sh, acc[a0 + 6]); hh(q0, ch, acc[a0 + 2]);
+        // the cross terms: one instruction per accumulator; the LUT fragment's fourth word is its block scale
+        v8i bc, bs, bm;      // (registers 6 and 7 of an fp6 operand are not read)
+        bc[0] = (int)d[0]; bc[1] = (int)d[1]; bc[2] = (int)d[2]; bc[3] = 0; bc[4] = 0; bc[5] = 0;
+        bs[0] = (int)d[3]; bs[1] = (int)d[4]; bs[2] = (int)d[5]; bs[3] = 0; bs[4] = 0; bs[5] = 0;
+        bm[0] = (int)d[0]; bm[1] = (int)d[1]; bm[2] = (int)d[2]; bm[3] = (int)d[3]; bm[4] = (int)d[4]; bm[5] = (int)d[5];
+        auto single = [&](const u32x4 &f, const v8i &b, f32x4 &c) {
+            v8i a;   // the fragment's own four registers; what follows them meets the zeros of b
+            a[0] = (int)f[0]; a[1] = (int)f[1]; a[2] = (int)f[2]; a[3] = (int)f[3];
+            c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 2, 2, 0, (int)f[3], 0, scale_b);
+        };
+        single(p0.p1, bc, acc[a0 + 0]);
+        single(q0.p1, bs, acc[a0 + 1]);
+        {   // cos x Q0 + sin x P0 (P0 and Q0 carry the same scale)
+            v8i a;
+            a[0] = (int)q0.p1[0]; a[1] = (int)q0.p1[1]; a[2] = (int)q0.p1[2];
+            a[3] = (int)p0.p1[0]; a[4] = (int)p0.p1[1]; a[5] = (int)p0.p1[2];
+            acc[a0 + 2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, bm, acc[a0 + 2], 2, 2, 0, (int)p0.p1[3], 0, scale_b);
+        }
+        single(r.p1, bc, acc[a0 + 3]);
+        single(r.p1, bs, acc[a0 + 4]);
+        single(sf.p1, bc, acc[a0 + 5]);
+        single(sf.p1, bs, acc[a0 + 6]);
+    }
+}
+
 // The 24 accumulator tiles of the row loop -> the 21 tiles of packed output columns (mkd_consts.hpp, packed_desc):
 //   relcos_k = cos x EPc - sin x EPs, relsin_k = sin x EPc + cos x EPs (columns 0-15 in P0 / Q0, 16-24 in slots 0-8 of R / S),
 //   abscos_k / abssin_k = the EC columns: 0-6 in slots 9-15 of R, 7-8 in slots 9-10 of S.
@@ -542,7 +652,7 @@ __device__ __forceinline__ void finish_descriptors(const f32x4 (&acc_row)[kAccTi
     const int q = lane >> 4;
     f32x4 acc[kTiles];
     combine_tiles(acc_row, q, acc);
-    if constexpr (POOL == LF_POOL_F16X3) {
+    if constexpr (f16_family(POOL)) {
         __syncthreads();   // every wave has left patch row 31: row buffer 1 is free too
         issue_w_step<W>(wfrag, 1, s_mem, wave, lane);
         issue_w_step<W>(wfrag, 2, s_mem, wave, lane);
@@ -594,7 +704,7 @@ __device__ __forceinline__ void finish_descriptors(const f32x4 (&acc_row)[kAccTi
     f32x4 o[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) o[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (POOL == LF_POOL_F16X3) {
+    if constexpr (f16_family(POOL)) {
         // The whitening is bound by operand delivery (each wave needs all 176 KiB of fragments per batch): from LDS, where
         // the 8 waves share one copy, they arrive at twice the rate the vector L1 gives each wave its own.
         constexpr int kDma = 16 / W;   // DMA instructions per lane and step
@@ -956,6 +1066,7 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
     }
     constexpr int kSlots = kKp ? kRingSlotsKp : kRingSlots;
     static_assert(!kKp || POOL == LF_POOL_F16X3, "keypoint mode pools in f16x3");
+    constexpr int kMPool = POOL == LF_POOL_F16_FP6 ? LF_POOL_F16X3 : POOL;   // the m stream keeps the three-term form
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kRingOff + W * kSlots * 2048 +
                                                                 (kKp ? kLevelTableBytes + kMaxPyrLevels * 8 : 0)];
     // number of patches: given by the host, or (graph-captured pipelines) left on the device by the previous stage
@@ -1061,9 +1172,9 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
             // row buffer par ^ 1 is free: next LUT row; during row 31 the f16 epilogue's first whitening step instead
             // (keypoint mode: the producer waves request LUT rows 1..31 -- an LDS-DMA request stalls its issuer for 60-180
             // cycles, which a producer can afford -- so a describe wave issues no memory instruction in the row loop)
-            if (POOL == LF_POOL_F16X3 ? !kLast : (!kLast || more)) {
+            if (f16_family(POOL) ? !kLast : (!kLast || more)) {
                 if constexpr (!kKp) issue_lut_row<W>(lr, (g + 1) & 31, s_mem + (par ^ 1) * kRowBytes, wave, lane);
-            } else if (POOL == LF_POOL_F16X3) {
+            } else if (f16_family(POOL)) {
                 issue_w_step<W>(wf, 0, s_mem, wave, lane);
             }
             par ^= 1;
@@ -1148,18 +1259,19 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
             // m stream x (polar | cartesian) kernels: accumulator tiles 0-2
             BFrag gfrag = load_b(brow, 3);   // first harmonic: P0
             {
-                AFrag<POOL> am;
+                AFrag<kMPool> am;
                 am.set(m);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) mma_part<POOL, 0>(am, bm[t], acc[t]);
+                for (int t = 0; t < 3; ++t) mma_part<kMPool, 0>(am, bm[t], acc[t]);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) mma_part<POOL, 1>(am, bm[t], acc[t]);
+                for (int t = 0; t < 3; ++t) mma_part<kMPool, 1>(am, bm[t], acc[t]);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) mma_part<POOL, 2>(am, bm[t], acc[t]);
+                for (int t = 0; t < 3; ++t) mma_part<kMPool, 2>(am, bm[t], acc[t]);
             }
             phase.mark(3);
             // cos / sin streams of the three harmonics x their four LUT tiles: accumulator tiles 3-23
-            pool_harmonics<POOL>(m, c1, s1, brow, gfrag, acc);
+            if constexpr (POOL == LF_POOL_F16_FP6) pool_harmonics_fp6(m, c1, s1, brow, gfrag, acc);
+            else pool_harmonics<POOL>(m, c1, s1, brow, gfrag, acc);
             phase.mark(4);
             phase.mark(5);
         };
@@ -1171,7 +1283,7 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
             f32x4 sum = acc[0];
             for (int t = 1; t < kAccTiles; ++t) sum += acc[t];
             if (base + p < n) *reinterpret_cast<f32x4 *>(out + (base + p) * 128 + 4 * q) = sum;
-            if (POOL == LF_POOL_F16X3) {
+            if (f16_family(POOL)) {
                 __syncthreads();
                 if (more) issue_lut_row<W>(lr, 0, s_mem, wave, lane);
             }
@@ -1205,9 +1317,10 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
     const bool small = ablate::kForceFourWaves || waves == 4 || (waves != 8 && n <= 64L * num_cus);
     const long nbatch = small ? (n + 63) / 64 : (n + 127) / 128;
     const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);
-    const bool f16 = pool_mode == LF_POOL_F16X3;
-    const unsigned char *lut = f16 ? reinterpret_cast<const unsigned char *>(dc.pool_b_f16)
-                                   : reinterpret_cast<const unsigned char *>(dc.pool_b_f32);
+    const bool f16 = f16_family(pool_mode);
+    const unsigned char *lut = pool_mode == LF_POOL_F16_FP6 ? reinterpret_cast<const unsigned char *>(dc.pool_b_fp6)
+                               : f16                        ? reinterpret_cast<const unsigned char *>(dc.pool_b_f16)
+                                                            : reinterpret_cast<const unsigned char *>(dc.pool_b_f32);
     const unsigned char *wf = f16 ? reinterpret_cast<const unsigned char *>(dc.white_a_f16)
                                   : reinterpret_cast<const unsigned char *>(dc.white_a_f32);
 #define LF_LAUNCH_W(A, P, WV)                                                                                          \
@@ -1218,7 +1331,11 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
         if (small) LF_LAUNCH_W(A, P, 4); \
         else LF_LAUNCH_W(A, P, 8); \
     } while (0)
-    if (f16) {
+    if (pool_mode == LF_POOL_F16_FP6) {
+        if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH(LF_ANGLE_EXACT, LF_POOL_F16_FP6);
+        else if (angle_mode == LF_ANGLE_EXACT_ZERO) LF_LAUNCH(LF_ANGLE_EXACT_ZERO, LF_POOL_F16_FP6);
+        else LF_LAUNCH(LF_ANGLE_SHADER, LF_POOL_F16_FP6);
+    } else if (f16) {
         if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH(LF_ANGLE_EXACT, LF_POOL_F16X3);
         else if (angle_mode == LF_ANGLE_EXACT_ZERO) LF_LAUNCH(LF_ANGLE_EXACT_ZERO, LF_POOL_F16X3);
         else LF_LAUNCH(LF_ANGLE_SHADER, LF_POOL_F16X3);

@@ -11,6 +11,7 @@
 #define LF_ANGLE_EXACT_ZERO 2   // exact direction, but angle 0 where gx == 0 like the shader
 #define LF_POOL_F16X3 1         // = LF_MKD_POOL_F16X3 (lf_mkd.h); the ABI's 0 ("default") is mapped to it at creation
 #define LF_POOL_F32 2           // = LF_MKD_POOL_F32
+#define LF_POOL_F16_FP6 3       // = LF_MKD_POOL_F16_FP6
 
 namespace lfmkd {
 
@@ -37,6 +38,7 @@ struct DeviceConsts {
     short *colmap = nullptr;        // [336]
     float *pool_b_f32 = nullptr;    // [32][15][2][64][4]
     uint16_t *pool_b_f16 = nullptr; // [32][15][2][64][8]
+    uint16_t *pool_b_fp6 = nullptr; // the same row images with fp6 cross-term operands for the harmonics' tiles (mkd_consts.hpp)
     uint16_t *white_a_f16 = nullptr; // [11][8][2][64][8]
     float *white_a_f32 = nullptr;    // [21][4][8][64]
     float *white_bias = nullptr;     // [128]  -W mean

@@ -14,10 +14,10 @@ import threading
 import numpy as np
 
 from ._lib import (ANGLE_EXACT, ANGLE_EXACT_ZERO, ANGLE_SHADER, FLAG_KERNEL_TIMING, FLAG_UNFUSED_KEYPOINTS, KEYPOINT_DTYPE, LIB_PATH, MODEL_DIR, PCA_NAMES,
-                   POOL_DEFAULT, POOL_F16X3, POOL_F32, SYMBOLS, COMM_ID_BYTES, GATHER_DIRECT, GATHER_RING, Comm, MkdHandle,
+                   POOL_DEFAULT, POOL_F16X3, POOL_F32, POOL_F16_FP6, SYMBOLS, COMM_ID_BYTES, GATHER_DIRECT, GATHER_RING, Comm, MkdHandle,
                    comm_unique_id, load_library, model_path)
 
-__all__ = ["Keypoint", "LocalFeatures", "MkdHandle", "ANGLE_SHADER", "ANGLE_EXACT", "ANGLE_EXACT_ZERO", "POOL_DEFAULT", "POOL_F32",
+__all__ = ["Keypoint", "LocalFeatures", "MkdHandle", "ANGLE_SHADER", "ANGLE_EXACT", "ANGLE_EXACT_ZERO", "POOL_DEFAULT", "POOL_F32", "POOL_F16_FP6",
            "POOL_F16X3", "FLAG_KERNEL_TIMING", "FLAG_UNFUSED_KEYPOINTS", "KEYPOINT_DTYPE", "PCA_NAMES", "SYMBOLS", "LIB_PATH", "MODEL_DIR",
            "load_library", "model_path", "Comm", "comm_unique_id", "COMM_ID_BYTES", "GATHER_DIRECT", "GATHER_RING"]
 

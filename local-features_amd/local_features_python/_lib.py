@@ -13,7 +13,7 @@ MODEL_DIR = os.path.join(_ROOT, "models", "mkd")
 FLAG_KERNEL_TIMING = 1
 FLAG_UNFUSED_KEYPOINTS = 2
 ANGLE_SHADER, ANGLE_EXACT, ANGLE_EXACT_ZERO = 0, 1, 2
-POOL_DEFAULT, POOL_F16X3, POOL_F32 = 0, 1, 2   # lf_mkd_pool_mode; the default is the f16x3 split
+POOL_DEFAULT, POOL_F16X3, POOL_F32, POOL_F16_FP6 = 0, 1, 2, 3   # lf_mkd_pool_mode; the default is the f16x3 split
 PCA_NAMES = ("liberty", "notredame", "yosemite")   # enum MKDPCA, lib.rs:26-32
 
 # every symbol include/lf_mkd.h declares

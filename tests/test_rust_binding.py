@@ -151,7 +151,7 @@ STRUCTS = {
 CONSTANTS = ["LF_MKD_OK", "LF_MKD_ERR_BAD_ARG", "LF_MKD_ERR_HIP", "LF_MKD_ERR_IO", "LF_MKD_ERR_NO_IMAGE",
              "LF_MKD_ERR_NO_DEVICE", "LF_MKD_ERR_COMM", "LF_MKD_COMM_ID_BYTES", "LF_MKD_GATHER_DIRECT", "LF_MKD_GATHER_RING",
              "LF_MKD_ANGLE_SHADER", "LF_MKD_ANGLE_EXACT", "LF_MKD_ANGLE_EXACT_ZERO",
-             "LF_MKD_POOL_DEFAULT", "LF_MKD_POOL_F16X3", "LF_MKD_POOL_F32", "LF_MKD_FLAG_KERNEL_TIMING", "LF_MKD_FLAG_UNFUSED_KEYPOINTS",
+             "LF_MKD_POOL_DEFAULT", "LF_MKD_POOL_F16X3", "LF_MKD_POOL_F32", "LF_MKD_POOL_F16_FP6", "LF_MKD_FLAG_KERNEL_TIMING", "LF_MKD_FLAG_UNFUSED_KEYPOINTS",
              "LF_MKD_MAX_ANGLES_PER_EXTREMUM", "LF_MKD_PCA_LIBERTY", "LF_MKD_PCA_NOTREDAME", "LF_MKD_PCA_YOSEMITE",
              "LF_MKD_PATCH_SIZE", "LF_MKD_RAW_LEN", "LF_MKD_DESC_LEN"]
 

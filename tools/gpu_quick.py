@@ -10,7 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 18
 p = torch.rand((n, 32, 32), device="cuda")
 out = torch.empty((n, 128), device="cuda")
 for angle in (lfp.ANGLE_SHADER, lfp.ANGLE_EXACT):
-    for pool in (lfp.POOL_F32, lfp.POOL_F16X3):
+    for pool in (lfp.POOL_F32, lfp.POOL_F16X3, lfp.POOL_F16_FP6):
         h = lfp.MkdHandle(max_features=n, angle_mode=angle, pool_mode=pool)
         s = torch.cuda.current_stream().cuda_stream
         for _ in range(2):
