@@ -121,6 +121,38 @@ def test_topk_filter_vs_oracle(lfp, torch, oracle, n, form, monkeypatch):
     assert np.array_equal(d_idx.cpu().numpy(), np.arange(50))
 
 
+@pytest.mark.parametrize("kind", ["last_bits", "forty_binades", "all_equal", "two_values", "one_above"])
+def test_topk_key_distributions(lfp, torch, oracle, kind):
+    """The one-workgroup selection takes its radix digits from the highest bit in which the keys differ: contrast sets whose
+    keys differ in the last bits only, span forty binades, are all equal, take two values, or hold one key above a crowd --
+    against the oracle, at a list length of each form."""
+    rng = np.random.default_rng(11)
+    for n in (7000, 20000, 45000):
+        if kind == "last_bits":
+            c = (np.float32(0.125) + np.arange(n, dtype=np.float32) % 7 * np.float32(2.0 ** -26)).astype(np.float32)
+            rng.shuffle(c)
+        elif kind == "forty_binades":
+            c = (2.0 ** rng.uniform(-20, 20, n)).astype(np.float32)
+        elif kind == "all_equal":
+            c = np.full(n, 0.3, np.float32)
+        elif kind == "two_values":
+            c = np.where(rng.random(n) < 0.5, np.float32(0.2), np.float32(0.20000002)).astype(np.float32)
+        else:
+            c = np.full(n, 0.1, np.float32)
+            c[n // 3] = 7.0
+        ex = np.stack([rng.uniform(5, 600, n), rng.uniform(5, 400, n), rng.uniform(2, 40, n), c], axis=1).astype(np.float32)
+        h = lfp.MkdHandle(max_features=64)
+        d_ex = torch.from_numpy(ex).cuda()
+        for top_n, min_size in ((1, 0.0), (2, 0.0), (3000, 0.0), (n - 1, 0.0), (500, 10.0)):
+            d_out = torch.zeros((top_n, 4), device="cuda")
+            d_idx = torch.zeros((top_n,), dtype=torch.int32, device="cuda")
+            m = h.filter_extrema_device(d_ex.data_ptr(), n, top_n, min_size, d_out.data_ptr(), d_idx.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream)
+            want = oracle.topk_filter(ex, top_n, min_size)
+            assert m == len(want), (kind, n, top_n, min_size, m, len(want))
+            assert np.array_equal(d_idx[:m].cpu().numpy().view(np.uint32), want), (kind, n, top_n, min_size)
+
+
 def test_multi_frame_extrema(lfp, torch, oracle):
     w, hgt, frames = 160, 120, 3
     imgs = np.stack([blob_image(w, hgt, 50 + f, 80) for f in range(frames)])

@@ -21,7 +21,7 @@ for model in lfp.PCA_NAMES:
     for name, mode in (("shader", ATAN_SHADER | BLUR_CONTRACT), ("libm", ATAN_LIBM | BLUR_CONTRACT)):
         t = time.time(); refs[name] = orc.describe_patches(p, atan_mode=mode, nthreads=16)
         print(f"  oracle {model} {name}: {time.time()-t:.1f} s", flush=True)
-    for pool in (lfp.POOL_F16X3, lfp.POOL_F32):
+    for pool in (lfp.POOL_F16X3, lfp.POOL_F32, lfp.POOL_F16_FP6):      # (3 = the fp6 cross-term experiment: inside the gate, not the default)
         for amode, ref in ((lfp.ANGLE_SHADER, "shader"), (lfp.ANGLE_EXACT, "libm"), (lfp.ANGLE_EXACT_ZERO, "shader")):
             d = lfp.MkdHandle(pca=model, max_features=1 << 16, angle_mode=amode, pool_mode=pool).describe_patches(p)
             e = np.linalg.norm(d.astype(np.float64) - refs[ref], axis=1) / np.linalg.norm(refs[ref], axis=1)
