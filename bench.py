@@ -236,8 +236,11 @@ def pipeline_extras(lfp, torch, device):
                 kp_traffic = kj.get("hbm_bytes_per_call", {})
         except Exception:
             kp_traffic = {}
+        # (third row: the reference's own settings -- examples/match_images/src/main.rs:62-76: top_n 2000, max_features 3000 --
+        #  on one 1080p frame: a launch of at most 8192 keypoints takes the 2 + 2-wave form of the describe kernel)
         for tag, w, h, nk, nf, iters in (("configs1_1080p_10k_keypoints", 1920, 1080, 10000, 1, 30),
-                                         ("configs2_256x640x480_2k_keypoints", 640, 480, 2000, 256, 5)):
+                                         ("configs2_256x640x480_2k_keypoints", 640, 480, 2000, 256, 5),
+                                         ("reference_defaults_1080p_3000_keypoints", 1920, 1080, 3000, 1, 30)):
             n = nk * nf
             hnd = lfp.MkdHandle(max_features=n, max_image_width=w, max_image_height=h, max_frames=nf, device=device)
             imgs = frames(nf, h, w, 2.0, 11)

@@ -1350,25 +1350,37 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
 
 #else   // LF_DESCRIBE_KP
 // Keypoint mode in one launch: 4 describe waves + 4 producer waves per workgroup, 64 keypoints per batch, one workgroup
-// per CU (160 KB of LDS), persistent.
+// per CU (160 KB of LDS), persistent; requests of at most 8192 keypoints: 2 + 2 waves, 32 keypoints per workgroup (below).
 void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                                const unsigned *frame_of_kp, unsigned n_frames, long n, const unsigned long long *n_dev,
                                float psf, const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream,
                                unsigned long long *clk) {
     if (n <= 0) return;
-    const long nbatch = (n + 63) / 64;
+    // A request of at most one round of 32-keypoint workgroups (<= 32 x CUs = 8192 keypoints: a frame at the reference's own
+    // settings, top_n 2000 / max_features 3000) takes the 2 + 2-wave form: every wave has a SIMD to itself -- the describe
+    // waves do not share theirs with a producer -- and the launch spreads over twice as many CUs.  It is a launch's latency
+    // that this shortens; on full batches the 4 + 4 form's eight waves per CU are the faster arrangement.
+    const bool narrow = n <= 32L * num_cus;      // (with n_dev, n is the capacity: the count on the device is no larger)
+    const long per_wg = narrow ? 32 : 64;
+    const long nbatch = (n + per_wg - 1) / per_wg;
     const unsigned grid = (unsigned)(nbatch < num_cus ? nbatch : num_cus);
     const unsigned char *lut = reinterpret_cast<const unsigned char *>(dc.pool_b_f16);
     const unsigned char *wf = reinterpret_cast<const unsigned char *>(dc.white_a_f16);
     KpSource ks;
     ks.pyr = pyr; ks.pyr_stride = pyr_stride; ks.kps = kps; ks.frame_of = frame_of_kp; ks.n_frames = n_frames ? n_frames : 1u;
     ks.psf = psf; ks.pd = pd;
-#define LF_LAUNCH_KP(A)                                                                                                \
-    hipLaunchKernelGGL((mkd_pool<A, LF_POOL_F16X3, 4, kSrcKeypoints>), dim3(grid), dim3(512), 0, stream,                \
+#define LF_LAUNCH_KP_W(A, WV)                                                                                          \
+    hipLaunchKernelGGL((mkd_pool<A, LF_POOL_F16X3, WV, kSrcKeypoints>), dim3(grid), dim3(128 * WV), 0, stream,          \
                        (const float *)nullptr, n, n_dev, lut, dc.colmap, wf, dc.white_bias, out, (float *)nullptr, ks, clk)
+#define LF_LAUNCH_KP(A)                 \
+    do {                                \
+        if (narrow) LF_LAUNCH_KP_W(A, 2); \
+        else LF_LAUNCH_KP_W(A, 4);      \
+    } while (0)
     if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH_KP(LF_ANGLE_EXACT);
     else if (angle_mode == LF_ANGLE_EXACT_ZERO) LF_LAUNCH_KP(LF_ANGLE_EXACT_ZERO);
     else LF_LAUNCH_KP(LF_ANGLE_SHADER);
+#undef LF_LAUNCH_KP_W
 #undef LF_LAUNCH_KP
 }
 #endif  // LF_DESCRIBE_KP
