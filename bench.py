@@ -719,12 +719,12 @@ def main():
     achieved = BYTES_PER_DESC * n / kern_s / 1e9 if kern_s > 0 else 0.0
     line = {}
 
-    def emit_and_leave(reason):
+    def emit_and_leave(reason, key="match_stage"):
         """Watchdog: a rank stuck in a collective its peers never entered.  Rank 0 prints the headline line with the stage
         marked, then every rank leaves at once with a NON-ZERO status (no destroy_process_group: it would wait for the stuck
         collective; os._exit from this timer thread ends the process without re-executing anything)."""
         if rank == 0:
-            line["match_stage"] = {"error": reason}
+            line[key] = {"error": reason}      # the stage that hung, under its own key
             print(json.dumps(line), flush=True)
         sys.stderr.write(f"bench.py rank {rank}: {reason}\n")
         sys.stderr.flush()
@@ -742,7 +742,7 @@ def main():
     # configs[3] in its own form (keypoint mode, frames sharded by image): every rank runs its share, with no collective
     # inside; one object gather afterwards, reached by every rank whatever happened locally
     if args.frames_per_gpu > 0:
-        dog = threading.Timer(limit, emit_and_leave, args=(f"configs[3] keypoint-mode leg did not finish within {limit:.0f} s",))
+        dog = threading.Timer(limit, emit_and_leave, args=(f"configs[3] keypoint-mode leg did not finish within {limit:.0f} s", "configs3_keypoint_mode"))
         dog.daemon = True
         dog.start()
         try:

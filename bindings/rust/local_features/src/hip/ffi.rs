@@ -24,6 +24,7 @@ pub const LF_MKD_POOL_F32: i32 = 2;
 pub const LF_MKD_POOL_F16_FP6: i32 = 3;
 pub const LF_MKD_FLAG_KERNEL_TIMING: u32 = 1;
 pub const LF_MKD_FLAG_UNFUSED_KEYPOINTS: u32 = 2;
+pub const LF_MKD_FLAG_DETECT_STEPWISE: u32 = 4;
 pub const LF_MKD_MAX_ANGLES_PER_EXTREMUM: usize = 18;
 pub const LF_MKD_COMM_ID_BYTES: usize = 128;
 pub const LF_MKD_GATHER_DIRECT: i32 = 0;
@@ -99,6 +100,9 @@ extern "C" {
                                    stream: *mut c_void) -> c_int;
     pub fn lf_mkd_set_images_device(h: *mut lf_mkd, d_images: *const f32, n_frames: u32, width: u32, height: u32,
                                     stream: *mut c_void) -> c_int;
+    pub fn lf_mkd_set_image_u8(h: *mut lf_mkd, image: *const u8, width: u32, height: u32) -> c_int;
+    pub fn lf_mkd_set_images_u8_device(h: *mut lf_mkd, d_images: *const u8, n_frames: u32, width: u32, height: u32,
+                                       stream: *mut c_void) -> c_int;
 
     pub fn lf_mkd_describe_keypoints(h: *mut lf_mkd, kps: *const lf_mkd_keypoint, n: u64, out: *mut f32) -> c_int;
     pub fn lf_mkd_describe_keypoints_device(h: *mut lf_mkd, d_kps: *const lf_mkd_keypoint, n: u64, d_out: *mut f32,
@@ -131,6 +135,10 @@ extern "C" {
     pub fn lf_mkd_detect(h: *mut lf_mkd, image: *const f32, width: u32, height: u32, top_n: u32, min_size: f32,
                          keypoints: *mut lf_mkd_keypoint, descriptors: *mut f32, max_out: u64, n_out: *mut u64,
                          dropped_blobs: *mut u64, dropped_features: *mut u64) -> c_int;
+    pub fn lf_mkd_detect_u8(h: *mut lf_mkd, image: *const u8, width: u32, height: u32, top_n: u32, min_size: f32,
+                            keypoints: *mut lf_mkd_keypoint, descriptors: *mut f32, max_out: u64, n_out: *mut u64,
+                            dropped_blobs: *mut u64, dropped_features: *mut u64) -> c_int;
+    pub fn lf_mkd_detect_times(h: *mut lf_mkd, upload_ms: *mut f64, pipeline_ms: *mut f64, readback_ms: *mut f64) -> c_int;
     pub fn lf_mkd_detect_frames_device(h: *mut lf_mkd, d_images: *const f32, n_frames: u32, width: u32, height: u32,
                                        top_n: u32, min_size: f32, d_keypoints: *mut lf_mkd_keypoint,
                                        d_frame_of_kp: *mut u32, d_descriptors: *mut f32, max_out: u64,

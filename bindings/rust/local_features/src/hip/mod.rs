@@ -146,6 +146,32 @@ impl LocalFeaturesHip {
         self.detect_on_device(img, n, min_size)
     }
 
+    /// `detect_top_n` on the 8-bit luma the reference's callers convert from (`image::open(..).grayscale()` then `convert()`,
+    /// examples/match_images/src/main.rs:44-60; `u8 as f32 / 255.`, examples/webcam/src/main.rs:136): a quarter of the
+    /// upload, the same keypoints and descriptors bit for bit (the device divides by 255 with a correctly rounded division).
+    pub fn detect_top_n_u8(&mut self, img: &ArrayView2<u8>, n: u32, min_size: f32) -> Result<FeaturesResult, Error> {
+        let width: u32 = img.ncols().try_into().map_err(|_| Error::BadArgument("image too wide".into()))?;
+        let height: u32 = img.nrows().try_into().map_err(|_| Error::BadArgument("image too tall".into()))?;
+        let data = img.as_slice().expect("image must be contiguous row-major"); // vulkan/mod.rs:368
+        let cap = self.fixed_params.max_features as usize;
+        let mut keypoints = vec![ffi::lf_mkd_keypoint::default(); cap];
+        let mut descriptors = Array2::<f32>::zeros((cap, DESCRIPTOR_LEN));
+        let (mut m, mut dropped_blobs, mut dropped_features) = (0u64, 0u64, 0u64);
+        // SAFETY: `data` holds width*height bytes; the two outputs have room for `cap` rows
+        unsafe {
+            check(self.h, ffi::lf_mkd_detect_u8(self.h, data.as_ptr(), width, height, n, min_size, keypoints.as_mut_ptr(),
+                                                descriptors.as_mut_ptr(), cap as u64, &mut m, &mut dropped_blobs,
+                                                &mut dropped_features))?;
+        }
+        keypoints.truncate(m as usize);
+        Ok(FeaturesResult {
+            keypoints: keypoints.into_iter().map(to_keypoint).collect(),
+            descriptors: descriptors.slice_move(s![..m as usize, ..]),
+            dropped_blobs: dropped_blobs as u32,
+            dropped_features: dropped_features as u32,
+        })
+    }
+
     /// vulkan/mod.rs:363-593 with a caller-supplied blob filter: detect graph, the filter on the host (where the
     /// reference calls it, vulkan/mod.rs:596-691), extract graph on the blobs it kept.  `None` keeps every blob.
     pub fn detect(&mut self, img: &ArrayView2<f32>, filter_keypoints: Option<&mut dyn FilterBlobs>)

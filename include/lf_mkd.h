@@ -60,8 +60,9 @@ typedef enum { LF_MKD_ANGLE_SHADER = 0, LF_MKD_ANGLE_EXACT = 1, LF_MKD_ANGLE_EXA
  * F16_FP6 : an experiment kept as a mode (round 4): hi*hi in f16 as above, the two cross terms of the
  *           harmonics' streams in ONE block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 per accumulator tile with e2m3
  *           operands (51 instead of 81 matrix instructions per wave-row).  e2m3 carries three bits below its block's
- *           maximum: descriptors within ~5e-5 of the f32 formulation (inside the gate, ten times F16X3's error) for a
- *           few per cent of speed -- NOT the default, not used for any reported parity figure.  Patch mode only: keypoint
+ *           maximum: descriptors within 3e-5 of the oracle (measured worst 2.95e-5, mean 2.0e-5, over the goldens and 4099
+ *           patches x 3 angle modes x both kernel forms; F16X3: 4.2e-6 / 3.1e-6 -- seven times the error, inside the gate; the
+ *           -m gpu test holds it below 4e-5) for +2 % of speed -- NOT the default, not used for any reported parity figure.  Patch mode only: keypoint
  *           entry points take the two-launch form in this mode. */
 typedef enum { LF_MKD_POOL_DEFAULT = 0, LF_MKD_POOL_F16X3 = 1, LF_MKD_POOL_F32 = 2, LF_MKD_POOL_F16_FP6 = 3 } lf_mkd_pool_mode;
 
@@ -73,6 +74,11 @@ typedef enum { LF_MKD_POOL_DEFAULT = 0, LF_MKD_POOL_F16X3 = 1, LF_MKD_POOL_F32 =
                                         By default patches are sampled inside the describe kernel -- producer waves of each
                                         workgroup fill its LDS row ring, patch_gradients.glsl:42-70 -- and never touch HBM.
                                         (LF_MKD_POOL_F32 always takes the two-launch form.) */
+
+#define LF_MKD_FLAG_DETECT_STEPWISE 4u /* lf_mkd_detect / lf_mkd_detect_u8 stage by stage, every count fetched by the host before the
+                                        next stage is sized (three waits): the verification form.  By default the call launches
+                                        the whole pipeline as ONE hipGraph, recorded on the first call for a (frame size, top_n,
+                                        min_size, max_out, pixel type) and kept; same bits. */
 
 /* Mirrors BuildTimeParams (lib.rs:54-75) + FeatureDetectParams (lib.rs:34-52) for this path.
  * Zero-initialise, then set what you need; 0 means "default". */
@@ -149,6 +155,16 @@ int lf_mkd_set_image(lf_mkd *h, const float *image, uint32_t width, uint32_t hei
 int lf_mkd_set_image_device(lf_mkd *h, const float *d_image, uint32_t width, uint32_t height,
                             void *stream);
 
+/* The same from the 8-bit luma the reference's callers start from (`image::open(..).grayscale()`, then `convert()` to f32 / 255:
+ * examples/match_images/src/main.rs:44-60; `u8 as f32 / 255.`: examples/webcam/src/main.rs:136): 1 byte per pixel over PCIe
+ * instead of 4.  A pixel v becomes (float)v / 255.0f with a correctly rounded division on the device, i.e. the f32 frame the
+ * host conversion gives, bit for bit: every result equals that of lf_mkd_set_image on the converted frame.  Row-major,
+ * contiguous, width bytes per row. */
+int lf_mkd_set_image_u8(lf_mkd *h, const uint8_t *image, uint32_t width, uint32_t height);
+/* Device-pointer form, n_frames frames of one size, width * height bytes apart (n_frames <= max_frames). */
+int lf_mkd_set_images_u8_device(lf_mkd *h, const uint8_t *d_images, uint32_t n_frames, uint32_t width, uint32_t height,
+                                void *stream);
+
 /* Multi-frame form of step 1 (BASELINE configs[2], [3]: hundreds of small frames): n_frames frames of one
  * size, contiguous [n_frames][height][width] in device memory, all pyramids built by one set of launches.
  * n_frames <= max_frames. */
@@ -216,10 +232,17 @@ int lf_mkd_filter_extrema_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, ui
  * image -> pyramid + a-trous stack -> extrema (at most max_blobs) -> [top_n filter if top_n > 0] ->
  * orientation -> sampling -> descriptors.  keypoints [max_out] and descriptors [max_out][128] receive
  * *n_out <= max_out results; *dropped_blobs and *dropped_features (may be NULL) as FeaturesResult
- * (lib.rs:77-83). */
+ * (lib.rs:77-83).  The whole pipeline is one hipGraph launch (recorded on the first call for these arguments' frame size, top_n,
+ * min_size and max_out; up to 8 such recordings are kept per handle): the call costs the upload of the frame, the pipeline
+ * and the copy of *n_out results, with one wait in between.  Afterwards the handle holds the frame like lf_mkd_set_image. */
 int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height, uint32_t top_n,
                   float min_size, lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out,
                   uint64_t *n_out, uint64_t *dropped_blobs, uint64_t *dropped_features);
+
+/* lf_mkd_detect on an 8-bit frame (see lf_mkd_set_image_u8): same results, a quarter of the upload. */
+int lf_mkd_detect_u8(lf_mkd *h, const uint8_t *image, uint32_t width, uint32_t height, uint32_t top_n, float min_size,
+                     lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out, uint64_t *n_out,
+                     uint64_t *dropped_blobs, uint64_t *dropped_features);
 
 /* detect_top_n over a BATCH of frames (BASELINE configs[2]: hundreds of small frames): n_frames frames of one size,
  * contiguous in device memory, through the whole pipeline with every stage launched once for all frames --
@@ -273,9 +296,10 @@ int lf_mkd_stream_frame(lf_mkd *h, void *stream);
  *              result of an exhaustive f32 scan; ~5.9e12 pairs/s.  A row with more than 64 such candidates in one lane's
  *              share of b (hundreds of near-duplicates of its best match) is redone by the scan form inside the same call,
  *              decided on the device.
- * LF_MKD_MATCH=small, =scan or =screen in the environment forces a form (small: where it fits, else scan).  Elements must be finite and below 65504 in magnitude
- * (f16 range).
- * Device pointers, asynchronous on `stream`. */
+ * LF_MKD_MATCH=small, =scan or =screen in the environment forces a form (small: where it fits -- also nb >= 128 or na <= 4096 --
+ * else scan).  Elements must be finite and below 65504 in magnitude (f16 range).
+ * Device pointers, asynchronous on `stream`.  d_a and d_b must be 16-byte aligned (rows are read as 16-byte vectors; any
+ * hipMalloc'd array or row offset into one is: a row is 512 bytes). */
 int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d_b, uint64_t nb,
                         const uint32_t *d_exclude_lo, const uint32_t *d_exclude_hi, float ratio,
                         int32_t *d_match, float *d_best, float *d_second, void *stream);
@@ -360,6 +384,11 @@ int lf_mkd_build_constants(const float *mean, const float *eigvals, const float 
  * and the number of batches since the previous call, then resets the sums.  Any output pointer may
  * be NULL. */
 int lf_mkd_kernel_times(lf_mkd *h, double *pool_ms, double *whiten_ms, uint64_t *launches);
+
+/* With LF_MKD_FLAG_KERNEL_TIMING: where the handle's latest lf_mkd_detect / lf_mkd_detect_u8 call spent its time -- the upload of
+ * the frame and the recorded pipeline (HIP events on the handle's stream around each), and the wall time from the pipeline's
+ * end to the return (the copy of the results to the caller's arrays).  Any output pointer may be NULL. */
+int lf_mkd_detect_times(lf_mkd *h, double *upload_ms, double *pipeline_ms, double *readback_ms);
 
 /* With LF_MKD_FLAG_KERNEL_TIMING: the shader clock the chip sustained during the handle's latest describe launch, from
  * stamps workgroup 0 of the kernel leaves on entry and exit (shader-clock counter / constant 100 MHz counter), and that

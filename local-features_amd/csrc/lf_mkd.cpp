@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -61,6 +62,23 @@ struct lf_mkd {
     PyramidDesc graph_pd{};     // frame geometry the recorded pipeline was captured for
     float *d_stream_patches = nullptr;
     uint64_t stream_patch_cap = 0;
+    // lf_mkd_detect / lf_mkd_detect_u8: the same launch sequence recorded once per (frame size, top_n, min_size, max_out,
+    // pixel type) and kept -- a call is one upload, one graph launch, one wait, the result copies
+    struct DetectPlan {
+        uint32_t w = 0, h = 0, top_n = 0, min_size_bits = 0;
+        uint64_t max_out = 0, stamp = 0;
+        bool u8 = false;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        PyramidDesc pd{};
+    };
+    std::vector<DetectPlan> plans;
+    uint64_t plan_clock = 0;
+    unsigned char *d_image_u8 = nullptr;              // 8-bit frame(s) on their way to level 0, allocated on first use
+    unsigned long long *d_det_counts = nullptr;       // [8] the recorded detect pipeline's counts (as lf_mkd_stream_create's d_counts)
+    unsigned long long *h_det_counts = nullptr;       // the same in pinned host memory: the last node of a plan copies them here
+    hipEvent_t det_ev[3] = {nullptr, nullptr, nullptr};   // LF_MKD_FLAG_KERNEL_TIMING: before the upload, after it, after the pipeline
+    double det_upload_ms = 0, det_pipeline_ms = 0, det_readback_ms = 0;
     // matcher scratch
     unsigned char *d_match_a = nullptr, *d_match_b = nullptr;
     float *d_match_part = nullptr, *d_match_in = nullptr;
@@ -132,6 +150,12 @@ long pyramid_floats(uint32_t w, uint32_t h) {
 int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) {
     if (!params || !out) return LF_MKD_ERR_BAD_ARG;
     *out = nullptr;
+    // the model first: a bad model is the caller's error whatever the machine (and is reported without a device)
+    HostConsts hc;
+    if (const std::string e = build_host_consts(pca, hc); !e.empty()) {
+        g_create_error = e;
+        return LF_MKD_ERR_BAD_ARG;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || params->device < 0 || params->device >= ndev) {
         g_create_error = "no HIP device " + std::to_string(params->device) + " (devices visible: " +
@@ -183,8 +207,6 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
         LF_CREATE_HIP(hipGetDeviceProperties(&prop, params->device));
         h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    HostConsts hc;
-    build_host_consts(pca, hc);
     LF_CREATE_HIP(upload(&h->dc.colmap, hc.colmap.data(), hc.colmap.size() * 2));
     LF_CREATE_HIP(upload(&h->dc.pool_b_f32, hc.pool_b_f32.data(), hc.pool_b_f32.size() * 4));
     LF_CREATE_HIP(upload(&h->dc.pool_b_f16, hc.pool_b_f16.data(), hc.pool_b_f16.size() * 2));
@@ -303,11 +325,16 @@ int describe_keypoints_on_device(lf_mkd *h, const float *d_kps, const uint32_t *
 // A recorded stream pipeline holds raw pointers into the scratch buffers: re-allocating one of them retires the graph
 // (lf_mkd_stream_frame then asks for a new lf_mkd_stream_create instead of touching freed memory).
 void retire_graph(lf_mkd *h) {
-    if (h->graph_exec) (void)hipDeviceSynchronize();   // a launch of it may still be running (on any stream)
+    if (h->graph_exec || !h->plans.empty()) (void)hipDeviceSynchronize();   // a launch may still be running (on any stream)
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     h->graph_exec = nullptr;
     h->graph = nullptr;
+    for (auto &p : h->plans) {       // lf_mkd_detect's recordings hold the same raw pointers: the next call records anew
+        if (p.exec) (void)hipGraphExecDestroy(p.exec);
+        if (p.graph) (void)hipGraphDestroy(p.graph);
+    }
+    h->plans.clear();
 }
 
 // Extends the loaded frames' level 0 into the a-trous stack (once per set_image*), allocating it on first use.
@@ -457,7 +484,10 @@ int lf_mkd_build_constants(const float *mean, const float *eigvals, const float 
     pca.eigvals.assign(eigvals, eigvals + kRaw);
     pca.eigvecs.assign(eigvecs, eigvecs + size_t(kRaw) * kRaw);
     HostConsts hc;
-    build_host_consts(pca, hc);
+    if (const std::string e = build_host_consts(pca, hc); !e.empty()) {
+        g_create_error = e;
+        return LF_MKD_ERR_BAD_ARG;
+    }
     if (gradient_angle) std::memcpy(gradient_angle, hc.gradient_angle.data(), hc.gradient_angle.size() * 4);
     if (embedding_polar) std::memcpy(embedding_polar, hc.embedding_polar.data(), hc.embedding_polar.size() * 4);
     if (embedding_cartesian)
@@ -496,6 +526,15 @@ void lf_mkd_destroy(lf_mkd *h) {
         if (p) (void)hipFree(p);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
+    for (auto &p : h->plans) {
+        if (p.exec) (void)hipGraphExecDestroy(p.exec);
+        if (p.graph) (void)hipGraphDestroy(p.graph);
+    }
+    if (h->d_image_u8) (void)hipFree(h->d_image_u8);
+    for (hipEvent_t e : h->det_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->d_det_counts) (void)hipFree(h->d_det_counts);
+    if (h->h_det_counts) (void)hipHostFree(h->h_det_counts);
     if (h->d_stream_patches) (void)hipFree(h->d_stream_patches);
     for (hipEvent_t e : h->ev_pending) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
@@ -597,10 +636,12 @@ int lf_mkd_describe_patches(lf_mkd *h, const float *patches, uint64_t n, float *
     return LF_MKD_OK;
 }
 
-int lf_mkd_set_images_device(lf_mkd *h, const float *d_images, uint32_t n_frames, uint32_t width, uint32_t height,
-                             void *stream) {
+// lf_mkd_set_images_device and its 8-bit twin: exactly one of d_images / d_images_u8 is given
+static int set_images_impl(lf_mkd *h, const float *d_images, const unsigned char *d_images_u8, uint32_t n_frames,
+                           uint32_t width, uint32_t height, void *stream) {
     if (!h) return LF_MKD_ERR_BAD_ARG;
-    if (!d_images || width < 2 || height < 2 || n_frames == 0) return fail(h, LF_MKD_ERR_BAD_ARG, "set_image: bad image");
+    if ((!d_images && !d_images_u8) || width < 2 || height < 2 || n_frames == 0)
+        return fail(h, LF_MKD_ERR_BAD_ARG, "set_image: bad image");
     if (!h->d_pyr || width > h->params.max_image_width || height > h->params.max_image_height)
         return fail(h, LF_MKD_ERR_BAD_ARG,
                     "set_image: image " + std::to_string(width) + "x" + std::to_string(height) +
@@ -615,7 +656,8 @@ int lf_mkd_set_images_device(lf_mkd *h, const float *d_images, uint32_t n_frames
     // a-trous layer 1 goes straight into it
     const bool share = h->d_coarse != nullptr && h->pd.levels >= 2;
     launch_build_pyramid(d_images, long(width) * height, h->d_pyr, h->pyr_stride, h->d_tmp_a, h->d_tmp_b, h->pd,
-                         int(n_frames), share ? h->d_coarse : nullptr, h->coarse_stride, s);
+                         int(n_frames), share ? h->d_coarse : nullptr, h->coarse_stride, s, nullptr, nullptr, nullptr, {},
+                         d_images_u8);
     h->coarse_l1_valid = share;
     LF_HIP(h, hipGetLastError());
     h->have_image = true;
@@ -624,8 +666,29 @@ int lf_mkd_set_images_device(lf_mkd *h, const float *d_images, uint32_t n_frames
     return LF_MKD_OK;
 }
 
+int lf_mkd_set_images_device(lf_mkd *h, const float *d_images, uint32_t n_frames, uint32_t width, uint32_t height,
+                             void *stream) {
+    if (h && !d_images) return fail(h, LF_MKD_ERR_BAD_ARG, "set_image: bad image");
+    return set_images_impl(h, d_images, nullptr, n_frames, width, height, stream);
+}
+
+int lf_mkd_set_images_u8_device(lf_mkd *h, const uint8_t *d_images, uint32_t n_frames, uint32_t width, uint32_t height,
+                                void *stream) {
+    if (h && !d_images) return fail(h, LF_MKD_ERR_BAD_ARG, "set_image_u8: bad image");
+    return set_images_impl(h, nullptr, d_images, n_frames, width, height, stream);
+}
+
 int lf_mkd_set_image_device(lf_mkd *h, const float *d_image, uint32_t width, uint32_t height, void *stream) {
     return lf_mkd_set_images_device(h, d_image, 1, width, height, stream);
+}
+
+// the 8-bit staging frame (1 B/px; lf_mkd_set_image_u8, lf_mkd_detect_u8), allocated on first use
+static int ensure_u8_staging(lf_mkd *h) {
+    if (h->d_image_u8) return LF_MKD_OK;
+    // (a recorded pipeline reads it by address: allocated once at the maximum frame size, it never moves)
+    LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_image_u8),
+                        (size_t(h->params.max_image_width) * h->params.max_image_height + 3) / 4 * 4));
+    return LF_MKD_OK;
 }
 
 int lf_mkd_set_image(lf_mkd *h, const float *image, uint32_t width, uint32_t height) {
@@ -636,6 +699,20 @@ int lf_mkd_set_image(lf_mkd *h, const float *image, uint32_t width, uint32_t hei
     LF_HIP(h, hipSetDevice(h->params.device));
     LF_HIP(h, hipMemcpyAsync(h->d_image, image, size_t(width) * height * 4, hipMemcpyHostToDevice, h->stream));
     const int rc = lf_mkd_set_image_device(h, h->d_image, width, height, h->stream);
+    if (rc) return rc;
+    LF_HIP(h, hipStreamSynchronize(h->stream));
+    return LF_MKD_OK;
+}
+
+int lf_mkd_set_image_u8(lf_mkd *h, const uint8_t *image, uint32_t width, uint32_t height) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!image) return fail(h, LF_MKD_ERR_BAD_ARG, "set_image_u8: null image");
+    if (!h->d_image || width > h->params.max_image_width || height > h->params.max_image_height)
+        return fail(h, LF_MKD_ERR_BAD_ARG, "set_image_u8: image exceeds max_image_width/height given at creation");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    if (int rc = ensure_u8_staging(h)) return rc;
+    LF_HIP(h, hipMemcpyAsync(h->d_image_u8, image, size_t(width) * height, hipMemcpyHostToDevice, h->stream));
+    const int rc = lf_mkd_set_images_u8_device(h, h->d_image_u8, 1, width, height, h->stream);
     if (rc) return rc;
     LF_HIP(h, hipStreamSynchronize(h->stream));
     return LF_MKD_OK;
@@ -772,24 +849,15 @@ int lf_mkd_filter_extrema_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, ui
     return LF_MKD_OK;
 }
 
-int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height, uint32_t top_n, float min_size,
-                  lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out, uint64_t *n_out,
-                  uint64_t *dropped_blobs, uint64_t *dropped_features) {
-    if (!h) return LF_MKD_ERR_BAD_ARG;
-    if (!n_out) return fail(h, LF_MKD_ERR_BAD_ARG, "detect: n_out is null");
-    *n_out = 0;
-    if (dropped_blobs) *dropped_blobs = 0;
-    if (dropped_features) *dropped_features = 0;
-    if (max_out && (!keypoints || !descriptors)) return fail(h, LF_MKD_ERR_BAD_ARG, "detect: null output pointer");
-    if (!image) return fail(h, LF_MKD_ERR_BAD_ARG, "detect: null image");
-    if (!h->d_image || !h->d_pyr || width < 2 || height < 2 || width > h->params.max_image_width ||
-        height > h->params.max_image_height)
-        return fail(h, LF_MKD_ERR_BAD_ARG, "detect: image exceeds max_image_width/height given at creation");
-    LF_HIP(h, hipSetDevice(h->params.device));
+// lf_mkd_detect stage by stage, every count fetched by the host before the next stage is sized (three waits on the stream):
+// how the call worked before round 5, kept as the verification form (LF_MKD_FLAG_DETECT_STEPWISE) and for max_out == 0.
+// The frame is already on the device (d_image or d_image_u8).
+static int detect_stepwise(lf_mkd *h, bool u8, uint32_t width, uint32_t height, uint32_t top_n, float min_size,
+                           lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out, uint64_t *n_out,
+                           uint64_t *dropped_blobs, uint64_t *dropped_features) {
     hipStream_t s = h->stream;
     // lf_mkd_set_image without its synchronisation, and -- once the a-trous stack exists, i.e. from the second call on --
     // with pyramid levels >= 1 (read by the sampler only) built on the side stream beside the a-trous passes and the scan
-    LF_HIP(h, hipMemcpyAsync(h->d_image, image, size_t(width) * height * 4, hipMemcpyHostToDevice, s));
     describe_pyramid(width, height, h->pd);
     const bool share = h->d_coarse != nullptr && h->pd.levels >= 2;
     if (share)
@@ -805,7 +873,8 @@ int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height
         };
     launch_build_pyramid(h->d_image, long(width) * height, h->d_pyr, h->pyr_stride, h->d_tmp_a, h->d_tmp_b, h->pd, 1,
                          share ? h->d_coarse : nullptr, h->coarse_stride, s, share ? h->side_stream : nullptr,
-                         share ? h->side_events[0] : nullptr, share ? h->side_events[1] : nullptr, stack_first);
+                         share ? h->side_events[0] : nullptr, share ? h->side_events[1] : nullptr, stack_first,
+                         u8 ? h->d_image_u8 : nullptr);
     LF_HIP(h, hipGetLastError());
     h->coarse_l1_valid = share;
     h->have_image = true;
@@ -845,6 +914,225 @@ int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height
     LF_HIP(h, hipStreamSynchronize(s));
     *n_out = n_kp;
     return LF_MKD_OK;
+}
+
+
+// Everything a recorded pipeline for frames of width x height touches, allocated BEFORE the capture starts (an allocation
+// inside a capture is an error, and one that moves a buffer retires every recording: retire_graph).
+static int prepare_pipeline(lf_mkd *h, uint32_t top_n, uint64_t cap) {
+    if (!h->d_coarse) {
+        h->layer_stride = long(h->params.max_image_width) * h->params.max_image_height;
+        h->coarse_stride = h->layer_stride * (h->n_layers - 1);
+        LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_coarse), size_t(h->coarse_stride) * h->max_frames * 4));
+    }
+    if (int rc = ensure_detect_scratch(h)) return rc;
+    if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, h->max_extrema, sizeof(lf_mkd_extremum))) return rc;
+    if (top_n) {
+        if (int rc = grow(h, &h->d_det_selected, &h->det_sel_cap, top_n, sizeof(lf_mkd_extremum))) return rc;
+        if (int rc = grow_topk_work(h, h->max_extrema, h->stream)) return rc;
+    }
+    return ensure_orient_scratch(h, cap, false, 0);
+}
+
+// Records the launch sequence of lf_mkd_detect for frames of width x height read from d_image (f32) or d_image_u8 -- pyramid,
+// a-trous stack, extremum scan, [top_n filter if top_n > 0], orientation, sampling + description -- with every count handed
+// from stage to stage in device memory (cnt [8]: see lf_mkd_stream_create in lf_mkd.h).  host_counts (nullable, pinned): a
+// last node copies cnt there.  h->pd must describe the frame; every buffer must exist (prepare_pipeline).
+static int record_pipeline(lf_mkd *h, uint32_t width, uint32_t height, uint32_t top_n, float min_size, uint64_t max_out,
+                           const float *d_image, const unsigned char *d_image_u8, lf_mkd_keypoint *d_keypoints,
+                           float *d_descriptors, unsigned long long *cnt, unsigned long long *host_counts,
+                           hipGraph_t *graph_out, hipGraphExec_t *exec_out) {
+    hipStream_t s = h->stream;
+    const uint64_t cap = top_n ? top_n : h->max_extrema;   // extrema that can reach orientation
+    // the detector needs pyramid level 0 and a-trous layer 1 only: the other levels (read by the sampler at the very end)
+    // are a branch of the graph beside the a-trous stack, the scan, the selection and the orientation
+    const bool fork = h->pd.levels >= 2;
+    if (fork)
+        if (int rc = ensure_side_stream(h, 2)) return rc;
+    LF_HIP(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    // (the a-trous stack is queued from inside, ahead of the branch: see launch_build_pyramid)
+    launch_build_pyramid(d_image, long(width) * height, h->d_pyr, h->pyr_stride, h->d_tmp_a, h->d_tmp_b, h->pd, 1,
+                         h->pd.levels >= 2 ? h->d_coarse : nullptr, h->coarse_stride, s, fork ? h->side_stream : nullptr,
+                         fork ? h->side_events[0] : nullptr, fork ? h->side_events[1] : nullptr, [&] {
+                             launch_build_coarse_stack(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse,
+                                                       h->coarse_stride, h->layer_stride, h->d_tmp_a, h->n_layers,
+                                                       h->pd.levels >= 2 ? 1 : 0, int(width), int(height), 1, s);
+                         }, d_image_u8);
+    launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride,
+                          h->n_layers, int(width), int(height), 1, kBorder, kSkipLayers, kContrastThreshold, h->d_slots,
+                          h->d_cube_counts, h->d_cube_sums, h->d_det_extrema, nullptr, nullptr, h->max_extrema, cnt + 0, s);
+    const float *d_sel = h->d_det_extrema;
+    const unsigned long long *n_sel = cnt + 0;
+    if (top_n) {
+        launch_topk_filter(h->d_det_extrema, nullptr, cnt + 0, 0, 1, 0xFFFFFFFFu, top_n, min_size, h->d_det_selected, nullptr,
+                           h->d_sel_count, cnt + 2, h->max_extrema, h->d_topk_work, s);
+        d_sel = h->d_det_selected;
+        n_sel = cnt + 2;
+    }
+    launch_orient(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride, h->n_layers,
+                  int(width), int(height), d_sel, nullptr, long(cap), n_sel, h->d_angles, h->d_counts, h->d_orient_sums,
+                  reinterpret_cast<float *>(d_keypoints), nullptr, max_out, cnt + 3, s);
+    // (the join costs ~12 us of queue latency wherever it stands, measured; the branch saves ~40)
+    if (fork) (void)hipStreamWaitEvent(s, h->side_events[1], 0);
+    if (fused_keypoints(h)) {
+        launch_describe_keypoints(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr, 1,
+                                  long(max_out), cnt + 3, h->params.patch_scale_factor, h->dc, h->params.angle_mode,
+                                  d_descriptors, h->num_cus, s);
+    } else {
+        launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr, 1,
+                              long(max_out), cnt + 3, h->params.patch_scale_factor, h->d_stream_patches, s);
+        launch_describe(h->d_stream_patches, long(max_out), cnt + 3, h->dc, h->params.angle_mode, h->params.pool_mode,
+                        d_descriptors, nullptr, h->num_cus, s);
+    }
+    if (host_counts) (void)hipMemcpyAsync(host_counts, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    hipGraph_t graph = nullptr;
+    hipError_t e_end = hipStreamEndCapture(s, &graph);
+    if (e_end != hipSuccess || !graph) {
+        h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e_end);
+        return LF_MKD_ERR_HIP;
+    }
+    hipError_t e_inst = hipGraphInstantiate(exec_out, graph, nullptr, nullptr, 0);
+    if (e_inst != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e_inst);
+        return LF_MKD_ERR_HIP;
+    }
+    *graph_out = graph;
+    return LF_MKD_OK;
+}
+
+// LocalFeaturesVulkan::detect / detect_top_n (mod.rs:346-593) from a HOST frame, f32 or 8-bit: one upload, one launch of the
+// pipeline recorded for this (frame size, top_n, min_size, max_out, pixel type) -- recorded on the first such call, kept
+// for the later ones -- one wait, the result copies.  The reference's callers make this call per image
+// (examples/match_images/src/main.rs:44-76) or per camera frame (examples/webcam/src/main.rs:136-160).
+constexpr size_t kMaxPlans = 8;
+
+static int detect_host(lf_mkd *h, const float *image, const unsigned char *image_u8, uint32_t width, uint32_t height,
+                       uint32_t top_n, float min_size, lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out,
+                       uint64_t *n_out, uint64_t *dropped_blobs, uint64_t *dropped_features) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!n_out) return fail(h, LF_MKD_ERR_BAD_ARG, "detect: n_out is null");
+    *n_out = 0;
+    if (dropped_blobs) *dropped_blobs = 0;
+    if (dropped_features) *dropped_features = 0;
+    if (max_out && (!keypoints || !descriptors)) return fail(h, LF_MKD_ERR_BAD_ARG, "detect: null output pointer");
+    if (!image && !image_u8) return fail(h, LF_MKD_ERR_BAD_ARG, "detect: null image");
+    if (!h->d_image || !h->d_pyr || width < 2 || height < 2 || width > h->params.max_image_width ||
+        height > h->params.max_image_height)
+        return fail(h, LF_MKD_ERR_BAD_ARG, "detect: image exceeds max_image_width/height given at creation");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    hipStream_t s = h->stream;
+    const bool u8 = image_u8 != nullptr;
+    if (u8)
+        if (int rc = ensure_u8_staging(h)) return rc;
+    const bool stepwise = (h->params.flags & LF_MKD_FLAG_DETECT_STEPWISE) || max_out == 0;
+    if (!stepwise) {
+        // every buffer the recording names, before the upload is queued (growing one waits for the device)
+        const uint64_t cap = top_n ? top_n : h->max_extrema;
+        if (int rc = prepare_pipeline(h, top_n, cap)) return rc;
+        if (int rc = ensure_orient_scratch(h, cap, true, max_out)) return rc;     // d_kps_out, d_det_desc [max_out]
+        if (!fused_keypoints(h))
+            if (int rc = grow(h, &h->d_stream_patches, &h->stream_patch_cap, max_out * kPx, sizeof(float))) return rc;
+        if (!h->d_det_counts) {
+            LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_det_counts), 8 * sizeof(unsigned long long)));
+            LF_HIP(h, hipMemsetAsync(h->d_det_counts, 0, 8 * sizeof(unsigned long long), s));
+            LF_HIP(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_det_counts), 8 * sizeof(unsigned long long), hipHostMallocDefault));
+            LF_HIP(h, hipStreamSynchronize(s));
+        }
+    }
+    const bool timed = (h->params.flags & LF_MKD_FLAG_KERNEL_TIMING) && !stepwise;
+    if (timed) {
+        for (auto &e : h->det_ev)
+            if (!e) LF_HIP(h, hipEventCreate(&e));
+        LF_HIP(h, hipEventRecord(h->det_ev[0], s));
+    }
+    if (u8) LF_HIP(h, hipMemcpyAsync(h->d_image_u8, image_u8, size_t(width) * height, hipMemcpyHostToDevice, s));
+    else LF_HIP(h, hipMemcpyAsync(h->d_image, image, size_t(width) * height * 4, hipMemcpyHostToDevice, s));
+    if (timed) LF_HIP(h, hipEventRecord(h->det_ev[1], s));
+    if (stepwise)
+        return detect_stepwise(h, u8, width, height, top_n, min_size, keypoints, descriptors, max_out, n_out, dropped_blobs,
+                               dropped_features);
+    describe_pyramid(width, height, h->pd);
+    uint32_t ms_bits;
+    std::memcpy(&ms_bits, &min_size, 4);
+    lf_mkd::DetectPlan *plan = nullptr;
+    for (auto &p : h->plans)
+        if (p.w == width && p.h == height && p.top_n == top_n && p.min_size_bits == ms_bits && p.max_out == max_out && p.u8 == u8)
+            plan = &p;
+    if (!plan) {
+        if (h->plans.size() >= kMaxPlans) {      // the least recently used recording makes room
+            size_t old = 0;
+            for (size_t i = 1; i < h->plans.size(); ++i)
+                if (h->plans[i].stamp < h->plans[old].stamp) old = i;
+            LF_HIP(h, hipStreamSynchronize(s));
+            (void)hipGraphExecDestroy(h->plans[old].exec);
+            (void)hipGraphDestroy(h->plans[old].graph);
+            h->plans.erase(h->plans.begin() + long(old));
+        }
+        lf_mkd::DetectPlan p;
+        p.w = width; p.h = height; p.top_n = top_n; p.min_size_bits = ms_bits; p.max_out = max_out; p.u8 = u8;
+        p.pd = h->pd;
+        // (the upload queued above is outside the capture: the capture records, it does not run anything)
+        if (int rc = record_pipeline(h, width, height, top_n, min_size, max_out, u8 ? nullptr : h->d_image,
+                                     u8 ? h->d_image_u8 : nullptr, reinterpret_cast<lf_mkd_keypoint *>(h->d_kps_out),
+                                     h->d_det_desc, h->d_det_counts, h->h_det_counts, &p.graph, &p.exec))
+            return rc;
+        h->plans.push_back(p);
+        plan = &h->plans.back();
+    }
+    plan->stamp = ++h->plan_clock;
+    LF_HIP(h, hipGraphLaunch(plan->exec, s));
+    if (timed) LF_HIP(h, hipEventRecord(h->det_ev[2], s));
+    h->n_frames = 1;
+    h->have_image = h->coarse_valid = h->coarse_l1_valid = true;   // the handle holds this frame's pyramid and a-trous stack
+    LF_HIP(h, hipStreamSynchronize(s));
+    const auto t_back = std::chrono::steady_clock::now();
+    if (timed) {
+        float a = 0, b = 0;
+        LF_HIP(h, hipEventElapsedTime(&a, h->det_ev[0], h->det_ev[1]));
+        LF_HIP(h, hipEventElapsedTime(&b, h->det_ev[1], h->det_ev[2]));
+        h->det_upload_ms = a;
+        h->det_pipeline_ms = b;
+        h->det_readback_ms = 0;
+    }
+    const unsigned long long *c = h->h_det_counts;
+    if (dropped_blobs) *dropped_blobs = c[1];
+    if (dropped_features) *dropped_features = c[4];
+    const uint64_t n_kp = std::min<uint64_t>(c[3], max_out);
+    if (n_kp == 0) return LF_MKD_OK;
+    static_assert(sizeof(lf_mkd_keypoint) == 20, "keypoint layout");
+    LF_HIP(h, hipMemcpyAsync(keypoints, h->d_kps_out, n_kp * sizeof(lf_mkd_keypoint), hipMemcpyDeviceToHost, s));
+    LF_HIP(h, hipMemcpyAsync(descriptors, h->d_det_desc, n_kp * kOut * 4, hipMemcpyDeviceToHost, s));
+    LF_HIP(h, hipStreamSynchronize(s));
+    if (timed) h->det_readback_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_back).count();
+    *n_out = n_kp;
+    return LF_MKD_OK;
+}
+
+int lf_mkd_detect_times(lf_mkd *h, double *upload_ms, double *pipeline_ms, double *readback_ms) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!(h->params.flags & LF_MKD_FLAG_KERNEL_TIMING))
+        return fail(h, LF_MKD_ERR_BAD_ARG, "detect_times: the handle was not created with LF_MKD_FLAG_KERNEL_TIMING");
+    if (upload_ms) *upload_ms = h->det_upload_ms;
+    if (pipeline_ms) *pipeline_ms = h->det_pipeline_ms;
+    if (readback_ms) *readback_ms = h->det_readback_ms;
+    return LF_MKD_OK;
+}
+
+int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height, uint32_t top_n, float min_size,
+                  lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out, uint64_t *n_out,
+                  uint64_t *dropped_blobs, uint64_t *dropped_features) {
+    if (h && !image) return fail(h, LF_MKD_ERR_BAD_ARG, "detect: null image");
+    return detect_host(h, image, nullptr, width, height, top_n, min_size, keypoints, descriptors, max_out, n_out,
+                       dropped_blobs, dropped_features);
+}
+
+int lf_mkd_detect_u8(lf_mkd *h, const uint8_t *image, uint32_t width, uint32_t height, uint32_t top_n, float min_size,
+                     lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out, uint64_t *n_out,
+                     uint64_t *dropped_blobs, uint64_t *dropped_features) {
+    if (h && !image) return fail(h, LF_MKD_ERR_BAD_ARG, "detect_u8: null image");
+    return detect_host(h, nullptr, image, width, height, top_n, min_size, keypoints, descriptors, max_out, n_out,
+                       dropped_blobs, dropped_features);
 }
 
 int lf_mkd_detect_frames_device(lf_mkd *h, const float *d_images, uint32_t n_frames, uint32_t width, uint32_t height,
@@ -909,7 +1197,14 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
         return fail(h, LF_MKD_ERR_BAD_ARG, "stream_create: frame exceeds max_image_width/height given at creation");
     LF_HIP(h, hipSetDevice(h->params.device));
     LF_HIP(h, hipStreamSynchronize(h->stream));
-    retire_graph(h);   // an earlier recording may still be running on a caller's stream
+    // an earlier recording may still be running on a caller's stream
+    if (h->graph_exec) {
+        (void)hipDeviceSynchronize();
+        (void)hipGraphExecDestroy(h->graph_exec);
+        (void)hipGraphDestroy(h->graph);
+        h->graph_exec = nullptr;
+        h->graph = nullptr;
+    }
     // every allocation happens before the capture starts
     describe_pyramid(width, height, h->pd);
     h->n_frames = 1;
@@ -917,72 +1212,16 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
     // stack hold nothing the keypoint / orientation / verification entry points could use
     h->have_image = false;
     h->coarse_valid = h->coarse_l1_valid = false;
-    if (!h->d_coarse) {
-        h->layer_stride = long(h->params.max_image_width) * h->params.max_image_height;
-        h->coarse_stride = h->layer_stride * (h->n_layers - 1);
-        LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_coarse), size_t(h->coarse_stride) * h->max_frames * 4));
-    }
-    if (int rc = ensure_detect_scratch(h)) return rc;
-    if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, h->max_extrema, sizeof(lf_mkd_extremum))) return rc;
     const uint64_t cap = top_n ? top_n : h->max_extrema;   // extrema that can reach orientation
-    if (top_n) {
-        if (int rc = grow(h, &h->d_det_selected, &h->det_sel_cap, top_n, sizeof(lf_mkd_extremum))) return rc;
-        if (int rc = grow_topk_work(h, h->max_extrema, h->stream)) return rc;
-    }
-    if (int rc = ensure_orient_scratch(h, cap, false, 0)) return rc;
+    if (int rc = prepare_pipeline(h, top_n, cap)) return rc;
     if (!fused_keypoints(h))
         if (int rc = grow(h, &h->d_stream_patches, &h->stream_patch_cap, max_out * kPx, sizeof(float))) return rc;
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(d_counts);
     LF_HIP(h, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), h->stream));
     LF_HIP(h, hipStreamSynchronize(h->stream));
-
-    hipStream_t s = h->stream;
-    // the detector needs pyramid level 0 and a-trous layer 1 only: the other levels (read by the sampler at the very end)
-    // are a branch of the graph beside the a-trous stack, the scan, the selection and the orientation
-    const bool fork = h->pd.levels >= 2;
-    if (fork)
-        if (int rc = ensure_side_stream(h, 2)) return rc;
-    LF_HIP(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    // (the a-trous stack is queued from inside, ahead of the branch: see launch_build_pyramid)
-    launch_build_pyramid(d_image, long(width) * height, h->d_pyr, h->pyr_stride, h->d_tmp_a, h->d_tmp_b, h->pd, 1,
-                         h->pd.levels >= 2 ? h->d_coarse : nullptr, h->coarse_stride, s, fork ? h->side_stream : nullptr,
-                         fork ? h->side_events[0] : nullptr, fork ? h->side_events[1] : nullptr, [&] {
-                             launch_build_coarse_stack(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse,
-                                                       h->coarse_stride, h->layer_stride, h->d_tmp_a, h->n_layers,
-                                                       h->pd.levels >= 2 ? 1 : 0, int(width), int(height), 1, s);
-                         });
-    launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride,
-                          h->n_layers, int(width), int(height), 1, kBorder, kSkipLayers, kContrastThreshold, h->d_slots,
-                          h->d_cube_counts, h->d_cube_sums, h->d_det_extrema, nullptr, nullptr, h->max_extrema, cnt + 0, s);
-    const float *d_sel = h->d_det_extrema;
-    const unsigned long long *n_sel = cnt + 0;
-    if (top_n) {
-        launch_topk_filter(h->d_det_extrema, nullptr, cnt + 0, 0, 1, 0xFFFFFFFFu, top_n, min_size, h->d_det_selected, nullptr,
-                           h->d_sel_count, cnt + 2, h->max_extrema, h->d_topk_work, s);
-        d_sel = h->d_det_selected;
-        n_sel = cnt + 2;
-    }
-    launch_orient(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride, h->n_layers,
-                  int(width), int(height), d_sel, nullptr, long(cap), n_sel, h->d_angles, h->d_counts, h->d_orient_sums,
-                  reinterpret_cast<float *>(d_keypoints), nullptr, max_out, cnt + 3, s);
-    // (the join costs ~12 us of queue latency wherever it stands, measured; the branch saves ~40)
-    if (fork) (void)hipStreamWaitEvent(s, h->side_events[1], 0);
-    if (fused_keypoints(h)) {
-        launch_describe_keypoints(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr, 1,
-                                  long(max_out), cnt + 3, h->params.patch_scale_factor, h->dc, h->params.angle_mode,
-                                  d_descriptors, h->num_cus, s);
-    } else {
-        launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr, 1,
-                              long(max_out), cnt + 3, h->params.patch_scale_factor, h->d_stream_patches, s);
-        launch_describe(h->d_stream_patches, long(max_out), cnt + 3, h->dc, h->params.angle_mode, h->params.pool_mode,
-                        d_descriptors, nullptr, h->num_cus, s);
-    }
-    hipError_t e_end = hipStreamEndCapture(s, &h->graph);
-    if (e_end != hipSuccess || !h->graph) {
-        h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e_end);
-        return LF_MKD_ERR_HIP;
-    }
-    LF_HIP(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+    if (int rc = record_pipeline(h, width, height, top_n, min_size, max_out, d_image, nullptr, d_keypoints, d_descriptors, cnt,
+                                 nullptr, &h->graph, &h->graph_exec))
+        return rc;
     h->graph_pd = h->pd;
     return LF_MKD_OK;
 }
@@ -1012,6 +1251,8 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
     if ((d_exclude_lo == nullptr) != (d_exclude_hi == nullptr))
         return fail(h, LF_MKD_ERR_BAD_ARG, "match_device: exclude_lo and exclude_hi go together");
     if (na > 0x7FFFFFFFull || nb > 0x7FFFFFFFull) return fail(h, LF_MKD_ERR_BAD_ARG, "match: more than 2^31 rows");
+    if ((reinterpret_cast<uintptr_t>(d_a) | reinterpret_cast<uintptr_t>(d_b)) & 15)
+        return fail(h, LF_MKD_ERR_BAD_ARG, "match_device: d_a and d_b must be 16-byte aligned");
     LF_HIP(h, hipSetDevice(h->params.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     // Which form: the two passes win once the scan would take about a millisecond and a has enough rows to fill the chip
@@ -1029,9 +1270,10 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
         LF_HIP(h, hipGetLastError());
         return LF_MKD_OK;
     }
-    const bool three_term_only = form && form[0] == 's' && form[1] == 'c' && form[2] == 'a'
-                                     ? true
-                                     : (form && form[0] == 's' && form[1] == 'c' ? false : !(na >= 16384 && na * nb >= (1ull << 29)));
+    // (=small where it does not fit: the scan, as include/lf_mkd.h says -- never silently the two-pass form)
+    const bool force_scan = form && ((form[0] == 's' && form[1] == 'c' && form[2] == 'a') || (form[0] == 's' && form[1] == 'm'));
+    const bool three_term_only = force_scan ? true
+                                            : (form && form[0] == 's' && form[1] == 'c' ? false : !(na >= 16384 && na * nb >= (1ull << 29)));
     // a goes through in chunks, so that the per-row scratch (2 KiB of candidate records per a row and b split) stays bounded
     const uint64_t chunk = three_term_only ? na : std::min<uint64_t>(na, kMatchChunk);
     const int splits = match_splits(long(chunk), long(nb), h->num_cus);

@@ -141,7 +141,19 @@ std::string load_pca_safetensors(const std::string &path, PcaModel &out) {
     return err.empty() ? "" : path + ": " + err;
 }
 
-void build_host_consts(const PcaModel &pca, HostConsts &hc) {
+std::string build_host_consts(const PcaModel &pca, HostConsts &hc) {
+    // The whitening scale is eigvals^-0.35 (mod.rs:1604-1612): a non-positive or non-finite eigenvalue among the 128 it uses,
+    // or a non-finite mean / eigenvector entry, would put NaNs into every descriptor.  The reference unwraps its embedded
+    // models (mkd_ref.rs:352-391); a caller-supplied model is checked and refused instead.
+    if (pca.mean.size() != size_t(kRaw) || pca.eigvals.size() != size_t(kRaw) || pca.eigvecs.size() != size_t(kRaw) * kRaw)
+        return "PCA model: mean[238], eigvals[238] and eigvecs[238*238] are required";
+    for (int r = 0; r < kOut; ++r)
+        if (!(pca.eigvals[r] > 0.f) || !std::isfinite(pca.eigvals[r]))
+            return "PCA model: eigvals[" + std::to_string(r) + "] must be positive and finite (the whitening scales by eigvals^-0.35)";
+    for (float v : pca.mean)
+        if (!std::isfinite(v)) return "PCA model: mean holds a non-finite value";
+    for (float v : pca.eigvecs)
+        if (!std::isfinite(v)) return "PCA model: eigvecs holds a non-finite value";
     static const Grid grid;
     const float kPi = 3.14159265358979323846f, kSqrt2 = 1.41421356237309504880f;
 
@@ -196,7 +208,8 @@ void build_host_consts(const PcaModel &pca, HostConsts &hc) {
                 if (d >= 0) ++seen[d];
             }
         for (int d = 0; d < kRaw; ++d)
-            if (seen[d] != 1) std::abort();   // every descriptor entry has exactly one packed column
+            if (seen[d] != 1)   // every descriptor entry has exactly one packed column (a property of packed_desc alone)
+                return "internal: descriptor entry " + std::to_string(d) + " has " + std::to_string(seen[d]) + " packed columns";
     }
     auto lut_value = [&](const LutColumn &col, int px) -> float {
         if (!col.used) return 0.f;
@@ -288,6 +301,7 @@ void build_host_consts(const PcaModel &pca, HostConsts &hc) {
         for (int d = 0; d < kRaw; ++d) b -= double(hc.w_t[size_t(n) * kRaw + d]) * double(pca.mean[d]);
         hc.white_bias[n] = float(b);
     }
+    return "";
 }
 
 }  // namespace lfmkd

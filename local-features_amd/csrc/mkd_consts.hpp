@@ -80,6 +80,7 @@ struct HostConsts {
     std::vector<float> white_bias;  // [128] = -sum_d W_T[n][d] mean[d]  (whitening.glsl subtracts the mean first)
 };
 
-void build_host_consts(const PcaModel &pca, HostConsts &out);
+// Returns "" or why the model cannot be used (never aborts: include/lf_mkd.h promises a status for every failure).
+std::string build_host_consts(const PcaModel &pca, HostConsts &out);
 
 }  // namespace lfmkd

@@ -67,7 +67,9 @@ void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidD
 void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,
                           float *tmp_b, const PyramidDesc &pd, int frames, float *layer1, long layer1_stride,
                           hipStream_t stream, hipStream_t rest_stream = nullptr, hipEvent_t fork = nullptr,
-                          hipEvent_t join = nullptr, const std::function<void()> &main_next = {});
+                          hipEvent_t join = nullptr, const std::function<void()> &main_next = {},
+                          const unsigned char *image_u8 = nullptr);
+// (image_u8 != nullptr: the frames are 8-bit luma, image_stride BYTES apart, `image` is ignored; a pixel is (float)v / 255.0f)
 
 // a-trous layers 1 .. n_layers-1 over layer0 (= pyramid level 0); tmp holds frames x w x h floats
 void launch_build_coarse_stack(const float *layer0, long layer0_stride, int layer0_pitch, float *coarse, long coarse_stride,

@@ -762,7 +762,11 @@ void launch_match(const unsigned char *a_tiles, long na, const unsigned char *b_
 
 // every workgroup walks all of b: beyond a few thousand candidates the scan's shared operand tiles win (measured: 8192 x 2048
 // and 1000 x 16000 are faster through the scan, 4000 x 4000 is level: the limit is half of that)
-bool match_small_fits(long na, long nb) { return na > 0 && nb >= 2 && nb <= 4096 && (double)na * (double)nb <= 8388608.0; }
+// (a workgroup's 16 waves take b's 16-row tiles round-robin: with fewer than 8 tiles most of them idle, which only a request of few
+// a rows -- launch-bound whatever the form -- can afford: a million a rows against eight candidates go through the scan)
+bool match_small_fits(long na, long nb) {
+    return na > 0 && nb >= 2 && nb <= 4096 && (double)na * (double)nb <= 8388608.0 && (nb >= 128 || na <= 4096);
+}
 
 void launch_match_small(const float *a, long na, const float *b, long nb, const unsigned *excl_lo, const unsigned *excl_hi,
                         float ratio, int *match, float *best, float *second, unsigned *overflowed_word,

@@ -34,14 +34,27 @@ __device__ __forceinline__ int edge_idx(int i, int n) {
     return i >= n ? 2 * n - 1 - i : i;
 }
 
-template <bool REFLECT = false>
-__device__ __forceinline__ float sep3_pixel(const float *__restrict__ in, int w, int h, int pitch, int x, int y, float w0,
+// The frame as the caller holds it: f32 in [0, 1], or the 8-bit luma it was made from (lf_mkd_set_image_u8: 1 B/px over PCIe
+// and from HBM instead of 4).  An 8-bit pixel becomes (float)v / 255.0f with a true, correctly rounded division -- what the
+// reference's callers compute on the host (`u8 as f32 / 255.`, examples/webcam/src/main.rs:136; the `image` crate's
+// convert(), examples/match_images/src/main.rs:59-60) -- so both inputs give the same level 0 bit for bit.
+__device__ __forceinline__ float px_f32(float v) { return v; }
+__device__ __forceinline__ float px_f32(unsigned char v) { return (float)v / 255.0f; }
+__device__ __forceinline__ f32x4 load_px4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ f32x4 load_px4(const unsigned char *p) {   // p 4-byte aligned
+    const unsigned v = *reinterpret_cast<const unsigned *>(p);
+    return f32x4{px_f32((unsigned char)(v & 255u)), px_f32((unsigned char)((v >> 8) & 255u)),
+                 px_f32((unsigned char)((v >> 16) & 255u)), px_f32((unsigned char)(v >> 24))};
+}
+
+template <bool REFLECT = false, typename PX = float>
+__device__ __forceinline__ float sep3_pixel(const PX *__restrict__ in, int w, int h, int pitch, int x, int y, float w0,
                                             float w1, float off, int vertical) {
 #pragma clang fp contract(off)   // the detector's decisions sit on these values: round like the restatement they are tested against
     const float c = (float)(vertical ? y : x) + 0.5f;
     const int n = vertical ? h : w;
     const long stride = vertical ? pitch : 1;
-    const float *line = vertical ? in + x : in + (size_t)y * pitch;
+    const PX *line = vertical ? in + x : in + (size_t)y * pitch;
     float side[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -50,9 +63,9 @@ __device__ __forceinline__ float sep3_pixel(const float *__restrict__ in, int w,
         const float f0 = floorf(fu);
         const float a = fu - f0;
         const int i0 = edge_idx<REFLECT>((int)f0, n), i1 = edge_idx<REFLECT>((int)f0 + 1, n);
-        side[k] = line[i0 * stride] * (1.f - a) + line[i1 * stride] * a;
+        side[k] = px_f32(line[i0 * stride]) * (1.f - a) + px_f32(line[i1 * stride]) * a;
     }
-    float s = in[(size_t)y * pitch + x] * w0;
+    float s = px_f32(in[(size_t)y * pitch + x]) * w0;
     s += (side[0] + side[1]) * w1;
     return s;
 }
@@ -90,7 +103,8 @@ __device__ __forceinline__ void store_with_apron(float *__restrict__ lvl0, int p
 // rows y-2 .. y+2.  Same arithmetic as the two pyr_sep3 dispatches: bit-identical.
 // (waves_per_eu: left alone the scheduler aims at 8 waves per SIMD, 36 registers, and waits for every pair of loads of the
 // horizontal pass; with ten in flight the kernel is 40 % faster)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 6))) void pyr_sep3_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
+template <typename PX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 6))) void pyr_sep3_fused(const PX *__restrict__ in, float *__restrict__ out, long in_stride,
                                                       long out_stride, int w, int h, int opitch, int oapron, float w0, float w1,
                                                       float off) {
 #pragma clang fp contract(off)
@@ -100,7 +114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 6))) voi
     const int y0 = (int)blockIdx.y * 12;
     const int xr = (int)blockIdx.x * 256 + (int)threadIdx.x, x = xr < w ? xr : w - 1;
 #pragma unroll 4
-    for (int m = 0; m < 16; ++m) s_h[m][threadIdx.x] = sep3_pixel(in, w, h, w, x, mirror_idx(y0 - 2 + m, h), w0, w1, off, 0);
+    for (int m = 0; m < 16; ++m) s_h[m][threadIdx.x] = sep3_pixel<false, PX>(in, w, h, w, x, mirror_idx(y0 - 2 + m, h), w0, w1, off, 0);
     __syncthreads();
 #pragma unroll 4
     for (int k = 0; k < 12; ++k) {
@@ -129,7 +143,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 6))) voi
 // columns (256 minus 4 texels of halo a side) and 12 rows.  Widths that are multiples of 4; tap offsets in (1, 2): the
 // vertical taps of output row y0 + k blend slots k, k + 1 and k + 3, k + 4 (floor(y -+ off) = y - 2, y + 1), which is what
 // lets the horizontal results live in registers.  Same arithmetic in the same order as pyr_sep3_fused: bit-identical.
-__global__ __launch_bounds__(256) void pyr_sep3_staged(const float *__restrict__ in, float *__restrict__ out, long in_stride,
+template <typename PX>
+__global__ __launch_bounds__(256) void pyr_sep3_staged(const PX *__restrict__ in, float *__restrict__ out, long in_stride,
                                                        long out_stride, int w, int h, int opitch, int oapron, float w0, float w1,
                                                        float off) {
 #pragma clang fp contract(off)
@@ -148,9 +163,9 @@ __global__ __launch_bounds__(256) void pyr_sep3_staged(const float *__restrict__
     f32x4 seg[kSlots / 4];
 #pragma unroll
     for (int i = 0; i < kSlots / 4; ++i) {
-        const float *row = in + (size_t)mirror_idx(y0 - 2 + wave + 4 * i, h) * w;
-        if (whole) seg[i] = *reinterpret_cast<const f32x4 *>(row + c0);
-        else seg[i] = f32x4{row[cm[0]], row[cm[1]], row[cm[2]], row[cm[3]]};
+        const PX *row = in + (size_t)mirror_idx(y0 - 2 + wave + 4 * i, h) * w;
+        if (whole) seg[i] = load_px4(row + c0);
+        else seg[i] = f32x4{px_f32(row[cm[0]]), px_f32(row[cm[1]]), px_f32(row[cm[2]]), px_f32(row[cm[3]])};
     }
 #pragma unroll
     for (int i = 0; i < kSlots / 4; ++i) *reinterpret_cast<f32x4 *>(&s_raw[wave + 4 * i][4 * lane]) = seg[i];
@@ -700,7 +715,7 @@ static void launch_apron_fill(float *pyr, long pyr_stride, const PyramidDesc &pd
 void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,
                           float *tmp_b, const PyramidDesc &pd, int frames, float *layer1, long layer1_stride,
                           hipStream_t stream, hipStream_t rest_stream, hipEvent_t fork, hipEvent_t join,
-                          const std::function<void()> &main_next) {
+                          const std::function<void()> &main_next, const unsigned char *image_u8) {
     const int w = pd.w[0], h = pd.h[0];
     const long ts = (long)w * h;
     const dim3 blk(32, 8);
@@ -718,12 +733,22 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     while (fill_from < n_direct && std::min(pd.w[fill_from], pd.h[fill_from]) >= pd.apron[fill_from]) ++fill_from;
     auto apron_of = [&](int l) { return l < fill_from ? pd.apron[l] : 0; };
     // level 0: sigma-0.6 blur, H then V (tasks_detect.rs:150-161, mod.rs:1043-1067)
-    if (w % 4 == 0 && image_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(image) & 15) == 0)
-        hipLaunchKernelGGL(pyr_sep3_staged, dim3((w + 247) / 248, (h + 11) / 12, frames), dim3(256), 0, stream, image,
+    // (image_u8 != nullptr: the frames are 8-bit, image_stride bytes apart; converted as they are read: px_f32)
+    if (image_u8) {
+        if (w % 4 == 0 && image_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(image_u8) & 3) == 0)
+            hipLaunchKernelGGL(pyr_sep3_staged<unsigned char>, dim3((w + 247) / 248, (h + 11) / 12, frames), dim3(256), 0, stream,
+                               image_u8, pyr + pd.offset[0], image_stride, pyr_stride, w, h, pd.pitch[0], apron_of(0),
+                               0.66381836f, 0.16809084f, 1.015267163f);
+        else
+            hipLaunchKernelGGL(pyr_sep3_fused<unsigned char>, dim3((w + 255) / 256, (h + 11) / 12, frames), dim3(256), 0, stream,
+                               image_u8, pyr + pd.offset[0], image_stride, pyr_stride, w, h, pd.pitch[0], apron_of(0),
+                               0.66381836f, 0.16809084f, 1.015267163f);
+    } else if (w % 4 == 0 && image_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(image) & 15) == 0)
+        hipLaunchKernelGGL(pyr_sep3_staged<float>, dim3((w + 247) / 248, (h + 11) / 12, frames), dim3(256), 0, stream, image,
                            pyr + pd.offset[0], image_stride, pyr_stride, w, h, pd.pitch[0], apron_of(0), 0.66381836f,
                            0.16809084f, 1.015267163f);
     else
-        hipLaunchKernelGGL(pyr_sep3_fused, dim3((w + 255) / 256, (h + 11) / 12, frames), dim3(256), 0, stream, image,
+        hipLaunchKernelGGL(pyr_sep3_fused<float>, dim3((w + 255) / 256, (h + 11) / 12, frames), dim3(256), 0, stream, image,
                            pyr + pd.offset[0], image_stride, pyr_stride, w, h, pd.pitch[0], apron_of(0), 0.66381836f,
                            0.16809084f, 1.015267163f);
     if (pd.levels < 2) {

@@ -13,12 +13,12 @@ import threading
 
 import numpy as np
 
-from ._lib import (ANGLE_EXACT, ANGLE_EXACT_ZERO, ANGLE_SHADER, FLAG_KERNEL_TIMING, FLAG_UNFUSED_KEYPOINTS, KEYPOINT_DTYPE, LIB_PATH, MODEL_DIR, PCA_NAMES,
+from ._lib import (ANGLE_EXACT, ANGLE_EXACT_ZERO, ANGLE_SHADER, FLAG_DETECT_STEPWISE, FLAG_KERNEL_TIMING, FLAG_UNFUSED_KEYPOINTS, KEYPOINT_DTYPE, LIB_PATH, MODEL_DIR, PCA_NAMES,
                    POOL_DEFAULT, POOL_F16X3, POOL_F32, POOL_F16_FP6, SYMBOLS, COMM_ID_BYTES, GATHER_DIRECT, GATHER_RING, Comm, MkdHandle,
                    comm_unique_id, load_library, model_path)
 
 __all__ = ["Keypoint", "LocalFeatures", "MkdHandle", "ANGLE_SHADER", "ANGLE_EXACT", "ANGLE_EXACT_ZERO", "POOL_DEFAULT", "POOL_F32", "POOL_F16_FP6",
-           "POOL_F16X3", "FLAG_KERNEL_TIMING", "FLAG_UNFUSED_KEYPOINTS", "KEYPOINT_DTYPE", "PCA_NAMES", "SYMBOLS", "LIB_PATH", "MODEL_DIR",
+           "POOL_F16X3", "FLAG_KERNEL_TIMING", "FLAG_UNFUSED_KEYPOINTS", "FLAG_DETECT_STEPWISE", "KEYPOINT_DTYPE", "PCA_NAMES", "SYMBOLS", "LIB_PATH", "MODEL_DIR",
            "load_library", "model_path", "Comm", "comm_unique_id", "COMM_ID_BYTES", "GATHER_DIRECT", "GATHER_RING"]
 
 
@@ -55,14 +55,14 @@ class LocalFeatures:
     `dropped_blobs` / `dropped_features`."""
 
     def __init__(self, max_image_width, max_image_height, max_features, max_blobs=8000, n_scales=4,
-                 pca="liberty", device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_DEFAULT, max_frames=1):
+                 pca="liberty", device=0, angle_mode=ANGLE_SHADER, pool_mode=POOL_DEFAULT, max_frames=1, flags=0):
         if pca not in PCA_NAMES:
             raise RuntimeError("Invalid PCA argument")
         try:
             self._inner = MkdHandle(pca=pca, max_features=max_features, max_image_width=max_image_width,
                                     max_image_height=max_image_height, device=device,
                                     angle_mode=angle_mode, pool_mode=pool_mode, n_scales=n_scales,
-                                    max_blobs=max_blobs, max_frames=max_frames)
+                                    max_blobs=max_blobs, max_frames=max_frames, flags=flags)
         except RuntimeError as e:   # python/src/lib.rs:77-82
             raise RuntimeError("Failed to initialize local features", str(e)) from e
         self._lock = threading.Lock()   # Mutex<LocalFeaturesVulkan>, python/src/lib.rs:38

@@ -12,6 +12,7 @@ MODEL_DIR = os.path.join(_ROOT, "models", "mkd")
 
 FLAG_KERNEL_TIMING = 1
 FLAG_UNFUSED_KEYPOINTS = 2
+FLAG_DETECT_STEPWISE = 4
 ANGLE_SHADER, ANGLE_EXACT, ANGLE_EXACT_ZERO = 0, 1, 2
 POOL_DEFAULT, POOL_F16X3, POOL_F32, POOL_F16_FP6 = 0, 1, 2, 3   # lf_mkd_pool_mode; the default is the f16x3 split
 PCA_NAMES = ("liberty", "notredame", "yosemite")   # enum MKDPCA, lib.rs:26-32
@@ -21,6 +22,7 @@ SYMBOLS = (
     "lf_mkd_create", "lf_mkd_create_from_file", "lf_mkd_destroy", "lf_mkd_last_error",
     "lf_mkd_describe_patches", "lf_mkd_describe_patches_device", "lf_mkd_raw_descriptors_device",
     "lf_mkd_set_image", "lf_mkd_set_image_device", "lf_mkd_set_images_device", "lf_mkd_describe_keypoints",
+    "lf_mkd_set_image_u8", "lf_mkd_set_images_u8_device", "lf_mkd_detect_u8", "lf_mkd_detect_times",
     "lf_mkd_describe_keypoints_frames_device",
     "lf_mkd_describe_keypoints_device", "lf_mkd_sample_patches_device", "lf_mkd_get_pyramid_level",
     "lf_mkd_get_pyramid_level_apron",
@@ -87,6 +89,8 @@ def load_library():
     L.lf_mkd_set_image.argtypes = [vp, vp, u32, u32]
     L.lf_mkd_set_image_device.argtypes = [vp, vp, u32, u32, vp]
     L.lf_mkd_set_images_device.argtypes = [vp, vp, u32, u32, u32, vp]
+    L.lf_mkd_set_image_u8.argtypes = [vp, vp, u32, u32]
+    L.lf_mkd_set_images_u8_device.argtypes = [vp, vp, u32, u32, u32, vp]
     L.lf_mkd_describe_keypoints_frames_device.argtypes = [vp, vp, vp, u64, vp, vp]
     L.lf_mkd_describe_keypoints.argtypes = [vp, vp, u64, vp]
     L.lf_mkd_describe_keypoints_device.argtypes = [vp, vp, u64, vp, vp]
@@ -104,6 +108,8 @@ def load_library():
     L.lf_mkd_detect_extrema_device.argtypes = [vp, vp, vp, u64, pu64, pu64, vp]
     L.lf_mkd_filter_extrema_device.argtypes = [vp, vp, u64, u32, ctypes.c_float, vp, vp, pu64, vp]
     L.lf_mkd_detect.argtypes = [vp, vp, u32, u32, u32, ctypes.c_float, vp, vp, u64, pu64, pu64, pu64]
+    L.lf_mkd_detect_u8.argtypes = L.lf_mkd_detect.argtypes
+    L.lf_mkd_detect_times.argtypes = [vp] + [ctypes.POINTER(ctypes.c_double)] * 3
     L.lf_mkd_match_device.argtypes = [vp, vp, u64, vp, u64, vp, vp, ctypes.c_float, vp, vp, vp, vp]
     L.lf_mkd_match.argtypes = [vp, vp, u64, vp, u64, ctypes.c_float, vp]
     L.lf_mkd_match_overflowed.argtypes = [vp, vp, ctypes.POINTER(u64)]
@@ -212,8 +218,13 @@ class MkdHandle:
         return out
 
     def set_image(self, img):
+        """f32 frame in [0, 1], or the uint8 luma it would be made from (1 B/px to the device, converted there: same bits)"""
         if img.ndim != 2:
             raise RuntimeError("image must be 2-D")
+        if img.dtype == np.uint8:
+            a = np.ascontiguousarray(img)
+            self._check(self.L.lf_mkd_set_image_u8(self._h, a.ctypes.data, a.shape[1], a.shape[0]), "lf_mkd_set_image_u8")
+            return
         a = np.ascontiguousarray(img, np.float32)
         self._check(self.L.lf_mkd_set_image(self._h, a.ctypes.data, a.shape[1], a.shape[0]), "lf_mkd_set_image")
 
@@ -247,19 +258,45 @@ class MkdHandle:
                                                  ctypes.byref(dropped)), "lf_mkd_detect_extrema")
         return out[:m.value].copy(), dropped.value
 
-    def detect(self, img, top_n=0, min_size=0.0, max_out=None):
-        """lf_mkd_detect: (keypoints [m,5], descriptors [m,128], dropped_blobs, dropped_features)."""
+    def detect_into(self, img, top_n, min_size, kps, desc):
+        """lf_mkd_detect / lf_mkd_detect_u8 (by the frame's dtype) into caller-held arrays kps [cap,5] f32, desc [cap,128] f32:
+        (m, dropped_blobs, dropped_features).  What a caller that reuses its buffers pays: the C call and nothing else."""
         if img.ndim != 2:
             raise RuntimeError("image must be 2-D")
-        a = np.ascontiguousarray(img, np.float32)
+        cap = kps.shape[0]
+        assert kps.dtype == np.float32 and desc.dtype == np.float32 and desc.shape[0] == cap and kps.flags.c_contiguous and desc.flags.c_contiguous
+        m, db, df = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        if img.dtype == np.uint8:
+            a = np.ascontiguousarray(img)
+            fn, what = self.L.lf_mkd_detect_u8, "lf_mkd_detect_u8"
+        else:
+            a = np.ascontiguousarray(img, np.float32)
+            fn, what = self.L.lf_mkd_detect, "lf_mkd_detect"
+        self._check(fn(self._h, a.ctypes.data, a.shape[1], a.shape[0], top_n, min_size, kps.ctypes.data, desc.ctypes.data, cap,
+                       ctypes.byref(m), ctypes.byref(db), ctypes.byref(df)), what)
+        return m.value, db.value, df.value
+
+    def detect_times(self):
+        """(upload_ms, pipeline_ms, readback_ms) of the latest detect call; needs FLAG_KERNEL_TIMING."""
+        a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._check(self.L.lf_mkd_detect_times(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "lf_mkd_detect_times")
+        return a.value, b.value, c.value
+
+    def detect(self, img, top_n=0, min_size=0.0, max_out=None):
+        """lf_mkd_detect (f32 frame) or lf_mkd_detect_u8 (uint8 frame): (keypoints [m,5], descriptors [m,128], dropped_blobs,
+        dropped_features)."""
         cap = int(max_out if max_out is not None else self.max_features)
         kps = np.empty((max(cap, 1), 5), np.float32)
         desc = np.empty((max(cap, 1), 128), np.float32)
-        m, db, df = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
-        self._check(self.L.lf_mkd_detect(self._h, a.ctypes.data, a.shape[1], a.shape[0], top_n, min_size,
-                                         kps.ctypes.data, desc.ctypes.data, cap, ctypes.byref(m), ctypes.byref(db),
-                                         ctypes.byref(df)), "lf_mkd_detect")
-        return kps[:m.value].copy(), desc[:m.value].copy(), db.value, df.value
+        if cap == 0:
+            m, db, df = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+            a = np.ascontiguousarray(img) if img.dtype == np.uint8 else np.ascontiguousarray(img, np.float32)
+            fn = self.L.lf_mkd_detect_u8 if img.dtype == np.uint8 else self.L.lf_mkd_detect
+            self._check(fn(self._h, a.ctypes.data, a.shape[1], a.shape[0], top_n, min_size, kps.ctypes.data, desc.ctypes.data, 0,
+                           ctypes.byref(m), ctypes.byref(db), ctypes.byref(df)), "lf_mkd_detect")
+            return kps[:0].copy(), desc[:0].copy(), db.value, df.value
+        m, db, df = self.detect_into(img, top_n, min_size, kps, desc)
+        return kps[:m].copy(), desc[:m].copy(), db, df
 
     def match(self, a, b, ratio=0.8):
         """match_features (examples/match_images/src/main.rs:8-27): int32 [na], index into b or -1."""
@@ -342,6 +379,10 @@ class MkdHandle:
     def set_images_device(self, d_images, n_frames, width, height, stream=None):
         self._device_call(stream, lambda s: self.L.lf_mkd_set_images_device(self._h, d_images, n_frames, width, height, s),
                           "lf_mkd_set_images_device")
+
+    def set_images_u8_device(self, d_images, n_frames, width, height, stream=None):
+        self._device_call(stream, lambda s: self.L.lf_mkd_set_images_u8_device(self._h, d_images, n_frames, width, height, s),
+                          "lf_mkd_set_images_u8_device")
 
     def describe_keypoints_frames_device(self, d_kps, d_frame_of_kp, n, d_out, stream=None):
         self._device_call(stream, lambda s: self.L.lf_mkd_describe_keypoints_frames_device(self._h, d_kps, d_frame_of_kp, n,

@@ -602,8 +602,21 @@ void mkd_oracle_build_pyramid(const float *img, int w, int h, float *pyr)
 /* shaders/mkd/patch_gradients.glsl:42-70: sample one 32x32 patch.
  * kp = {x, y, size, angle_deg}.  Level clamped to [0, L-1] (the detector never
  * emits sizes below 1.64). */
+/* `contract` != 0: the second legitimate reading of patch_gradients.glsl:60-67 -- the shader is not `precise`, so its
+ * compiler may fuse `dx*ca - dy*sa` and `xx*r + x/2^L` into fma (one rounding instead of two).  The two readings place a
+ * sample up to one ulp of its coordinate apart (2.4e-4 texel for coordinates in [2048, 4096)): the whole of the thinnest
+ * parity margin of the -m gpu run (profiles/r05_parity_report.txt).  The HIP sampler (csrc/mkd_sample.h) is this reading. */
+static void sample_patch_reading(const float *pyr, int w, int h, const float *kp, float patch_scale_factor, float *patch,
+                                 int contract);
+
 void mkd_oracle_sample_patch(const float *pyr, int w, int h, const float *kp,
                              float patch_scale_factor, float *patch)
+{
+    sample_patch_reading(pyr, w, h, kp, patch_scale_factor, patch, 0);
+}
+
+static void sample_patch_reading(const float *pyr, int w, int h, const float *kp, float patch_scale_factor, float *patch,
+                                 int contract)
 {
     const int L = mkd_oracle_pyramid_levels(w, h);
     const float scale = kp[2] * patch_scale_factor / (float)PS;
@@ -626,10 +639,10 @@ void mkd_oracle_sample_patch(const float *pyr, int w, int h, const float *kp,
     for (int ly = 0; ly < PS; ly++)
         for (int lx = 0; lx < PS; lx++) {
             const float dx = (float)lx - 16.f, dy = (float)ly - 16.f;
-            const float xx = dx * ca - dy * sa;
-            const float yy = dx * sa + dy * ca;
-            const float sx = xx * rem_scale + kp[0] * inv;
-            const float sy = yy * rem_scale + kp[1] * inv;
+            const float xx = contract ? fmaf(dx, ca, -dy * sa) : dx * ca - dy * sa;
+            const float yy = contract ? fmaf(dx, sa, dy * ca) : dx * sa + dy * ca;
+            const float sx = contract ? fmaf(xx, rem_scale, kp[0] * inv) : xx * rem_scale + kp[0] * inv;
+            const float sy = contract ? fmaf(yy, rem_scale, kp[1] * inv) : yy * rem_scale + kp[1] * inv;
             /* textureLod at ((s+0.5)/size): unnormalised coordinate s+0.5 */
             patch[ly * PS + lx] = tex_bilinear(img, lw, lh, sx + 0.5f, sy + 0.5f);
         }
@@ -640,6 +653,13 @@ void mkd_oracle_sample_patches(const float *pyr, int w, int h, const float *kps 
 {
     for (long i = 0; i < n; i++)
         mkd_oracle_sample_patch(pyr, w, h, kps + 4 * i, patch_scale_factor, patches + i * NPX);
+}
+
+void mkd_oracle_sample_patches_reading(const float *pyr, int w, int h, const float *kps /*[n][4]*/, long n,
+                                       float patch_scale_factor, int contract, float *patches)
+{
+    for (long i = 0; i < n; i++)
+        sample_patch_reading(pyr, w, h, kps + 4 * i, patch_scale_factor, patches + i * NPX, contract);
 }
 
 unsigned long mkd_oracle_sizeof_consts(void) { return sizeof(mkd_consts); }

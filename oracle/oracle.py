@@ -50,6 +50,8 @@ class MkdOracle:
         L.mkd_cpu_fast_describe_patches.argtypes = [ctypes.c_void_p, _fp, ctypes.c_long, _fp, ctypes.c_int, ctypes.c_int]
         L.mkd_oracle_sample_patches.argtypes = [
             _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_long, ctypes.c_float, _fp]
+        L.mkd_oracle_sample_patches_reading.argtypes = [
+            _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_long, ctypes.c_float, ctypes.c_int, _fp]
         L.mkd_oracle_build_pyramid.argtypes = [_fp, ctypes.c_int, ctypes.c_int, _fp]
         L.mkd_oracle_patch_gradients.argtypes = [_fp, _fp, _fp, ctypes.c_int]
         L.mkd_oracle_dog.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]
@@ -153,13 +155,14 @@ class MkdOracle:
             off += lw * lh
         return out
 
-    def sample_patches(self, pyr, w, h, kps, patch_scale_factor=24.0):
-        """kps: [n,4] (x, y, size, angle_deg)."""
+    def sample_patches(self, pyr, w, h, kps, patch_scale_factor=24.0, contract=False):
+        """kps: [n,4] (x, y, size, angle_deg).  contract: the reference's other reading of the sample position
+        (patch_gradients.glsl:60-67 without `precise`: mul+add fused into fma), up to one coordinate ulp away."""
         k = _f32(kps).reshape(-1, 4)
         n = k.shape[0]
         patches = np.zeros((n, 32, 32), np.float32)
-        self.L.mkd_oracle_sample_patches(_ptr(pyr), w, h, _ptr(k), n, patch_scale_factor,
-                                         _ptr(patches))
+        self.L.mkd_oracle_sample_patches_reading(_ptr(pyr), w, h, _ptr(k), n, patch_scale_factor, int(bool(contract)),
+                                                 _ptr(patches))
         return patches
 
     def build_coarse_stack(self, img, n_scales=4):

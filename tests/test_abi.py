@@ -15,7 +15,7 @@ import local_features_python as lfp
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "lf_mkd.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(lf_mkd_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(lf_mkd_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -55,6 +55,30 @@ def test_bad_arguments_are_reported_not_fatal():
     assert b"nonexistent" in L.lf_mkd_last_error(None)
     with pytest.raises(RuntimeError, match="Invalid PCA argument"):       # python/src/lib.rs:60-64
         lfp.LocalFeatures(640, 480, 100, pca="oxford")
+
+
+def test_an_unusable_pca_model_is_an_error_not_an_abort(oracle):
+    """include/lf_mkd.h: "they never abort".  The whitening scales by eigvals^-0.35 (vulkan/mod.rs:1604-1612): a model whose
+    eigenvalues are not positive, or that holds NaNs, is refused with LF_MKD_ERR_BAD_ARG and a message -- by the
+    constants tap (no device needed) and by lf_mkd_create before it looks for a device."""
+    L = lfp.load_library()
+    mean, vals, vecs = oracle.mean.copy(), oracle.eigvals.copy(), oracle.eigvecs.copy()
+    p = lfp._lib.Params(device=0)
+    h = ctypes.c_void_p()
+    for what, breaker in (("eigvals[5]", lambda: vals.__setitem__(5, 0.0)), ("eigvals[127]", lambda: vals.__setitem__(127, -1e-3)),
+                          ("eigvals[0]", lambda: vals.__setitem__(0, np.nan)), ("mean", lambda: mean.__setitem__(17, np.inf)),
+                          ("eigvecs", lambda: vecs.reshape(-1).__setitem__(1234, np.nan))):
+        mean, vals, vecs = oracle.mean.copy(), oracle.eigvals.copy(), oracle.eigvecs.copy()
+        breaker()
+        assert L.lf_mkd_build_constants(mean.ctypes.data, vals.ctypes.data, vecs.ctypes.data, None, None, None, None) == -1
+        assert what.encode() in L.lf_mkd_last_error(None), (what, L.lf_mkd_last_error(None))
+        assert L.lf_mkd_create(ctypes.byref(p), mean.ctypes.data, vals.ctypes.data, vecs.ctypes.data, ctypes.byref(h)) == -1
+        assert not h.value and what.encode() in L.lf_mkd_last_error(None)
+    # eigenvalues beyond the 128 the whitening uses may be anything non-negative (the models' tails are ~1e-7)
+    vals = oracle.eigvals.copy()
+    vals[200] = 0.0
+    assert L.lf_mkd_build_constants(oracle.mean.ctypes.data, vals.ctypes.data, oracle.eigvecs.ctypes.data, None, None, None, None) == 0
+    assert b"abort" not in open(os.path.join(ROOT, "local-features_amd", "csrc", "mkd_consts.cpp"), "rb").read().replace(b"never aborts", b"")
 
 
 def test_no_gpu_fails_loudly():

@@ -209,6 +209,90 @@ def test_detect_counts_what_does_not_fit(lfp, oracle):
     assert dist.max() < 1e-3
 
 
+def _u8_frame(w, hgt, seed, n_blobs):
+    """an 8-bit frame and the f32 frame the reference's callers make of it (u8 as f32 / 255., examples/webcam/src/main.rs:136)"""
+    u8 = np.ascontiguousarray(np.clip(np.rint(blob_image(w, hgt, seed, n_blobs) * 255.0), 0, 255).astype(np.uint8))
+    return u8, np.ascontiguousarray(u8.astype(np.float32) / np.float32(255.0))
+
+
+@pytest.mark.parametrize("w,hgt,blobs", [(640, 480, 900), (333, 257, 300)])
+def test_detect_recorded_stepwise_and_u8_return_the_same_bits(lfp, torch, oracle, w, hgt, blobs):
+    """Round 5: lf_mkd_detect is one upload + ONE hipGraph launch recorded per (frame size, top_n, min_size, max_out, pixel
+    type), and lf_mkd_detect_u8 takes the 8-bit frame (1 B/px over PCIe, (float)v / 255.0f on the device).  All of them must
+    return the bits of the stage-by-stage form the call had before (LF_MKD_FLAG_DETECT_STEPWISE keeps it): keypoints,
+    descriptors and both dropped counters, on the first call (recording) and on later ones (replay), for aligned frames (the
+    staged level-0 kernel) and odd ones (the unaligned kernel), with and without the top-n filter, with an output capacity
+    that cuts the list, and with more distinct requests than the handle keeps recordings for."""
+    u8, f32 = _u8_frame(w, hgt, 11, blobs)
+    rec = lfp.MkdHandle(max_features=4000, max_image_width=w, max_image_height=hgt, max_blobs=2048)
+    ref = lfp.MkdHandle(max_features=4000, max_image_width=w, max_image_height=hgt, max_blobs=2048, flags=lfp.FLAG_DETECT_STEPWISE)
+    requests = [(0, 0.0, 4000), (200, 0.0, 4000), (200, 3.0, 4000), (200, 0.0, 64), (0, 0.0, 100)]
+    requests += [(50 + 10 * i, 0.0, 4000) for i in range(9)]        # 14 distinct requests x 2 pixel types > 8 kept recordings
+    seen_n = set()
+    for rnd in range(2):                                            # second round: every request again (some replayed, some re-recorded)
+        for top_n, min_size, cap in requests:
+            want = ref.detect(f32, top_n, min_size, cap)
+            assert len(want[0]) > 0
+            for img in (f32, u8, f32):
+                got = rec.detect(img, top_n, min_size, cap)
+                assert got[2:] == want[2:], (top_n, min_size, cap, got[2:], want[2:])
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (rnd, top_n, min_size, cap, img.dtype)
+            assert np.array_equal(ref.detect(u8, top_n, min_size, cap)[1], want[1])
+            seen_n.add(len(want[0]))
+    assert len(seen_n) > 5
+    # a capacity that cuts the list counts what it cut
+    k, d, db, df = rec.detect(u8, 0, 0.0, 100)
+    assert len(k) == 100 and df > 0
+    # after the call the handle holds the frame like lf_mkd_set_image: describing the returned keypoints reproduces the rows
+    k, d, _, _ = rec.detect(u8, 200, 0.0, 4000)
+    assert np.array_equal(rec.describe_keypoints(k), d)
+    # ... and it is the oracle's detect (the f32 frame the 8-bit one stands for)
+    want_k, _ = oracle.detect(f32, top_n=200, max_blobs=2048)
+    assert k.shape == want_k.shape
+    assert_same_extrema(k[:, [0, 1, 2, 4]], want_k[:, [0, 1, 2, 4]], "detect_u8")
+    # the 8-bit frame gives the f32 frame's pyramid, bit for bit
+    rec.set_image(u8)
+    a = [rec.pyramid_level(l).copy() for l in range(4)]
+    rec.set_image(f32)
+    for l in range(4):
+        assert np.array_equal(a[l], rec.pyramid_level(l)), l
+    # a recorded stream pipeline on the same handle and the detect recordings do not disturb each other
+    d_img = torch.from_numpy(f32).cuda()
+    d_k, d_d = torch.zeros((4000, 5), device="cuda"), torch.zeros((4000, 128), device="cuda")
+    d_c = torch.zeros((8,), dtype=torch.int64, device="cuda")
+    rec.stream_create(w, hgt, 200, 0.0, 4000, d_img.data_ptr(), d_k.data_ptr(), d_d.data_ptr(), d_c.data_ptr())
+    rec.stream_frame()
+    rec.synchronize()
+    n = int(d_c[3].item())
+    k2, d2, _, _ = rec.detect(u8, 200, 0.0, 4000)
+    assert n == len(k2) and np.array_equal(d_d[:n].cpu().numpy(), d2) and np.array_equal(d_k[:n].cpu().numpy(), k2)
+    rec.stream_frame()
+    rec.synchronize()
+    assert np.array_equal(d_d[:n].cpu().numpy(), d2)
+
+
+def test_detect_u8_errors_and_empty_frames(lfp):
+    """the 8-bit entry points report what the f32 ones report; a flat frame yields no keypoints through the recorded pipeline"""
+    h = lfp.MkdHandle(max_features=256, max_image_width=128, max_image_height=96)
+    flat = np.full((96, 128), 127, np.uint8)
+    for _ in range(2):
+        k, d, db, df = h.detect(flat, 50, 0.0, 256)
+        assert len(k) == 0 and d.shape == (0, 128) and db == 0 and df == 0
+    with pytest.raises(RuntimeError, match="exceeds"):
+        h.detect(np.zeros((97, 128), np.uint8), 0, 0.0, 16)
+    with pytest.raises(RuntimeError, match="exceeds"):
+        h.set_image(np.zeros((96, 129), np.uint8))
+    L = h.L
+    import ctypes
+    m = ctypes.c_uint64()
+    assert L.lf_mkd_detect_u8(h._h, None, 128, 96, 0, 0.0, None, None, 0, ctypes.byref(m), None, None) == -1
+    assert L.lf_mkd_set_image_u8(h._h, None, 128, 96) == -1
+    # max_out == 0: counts only (the stage-by-stage form serves it)
+    busy = np.ascontiguousarray((np.random.default_rng(3).random((96, 128)) > 0.5).astype(np.uint8) * 255)
+    k, d, db, df = h.detect(busy, 0, 0.0, 0)
+    assert len(k) == 0
+
+
 @pytest.mark.parametrize("top_n", [0, 150])
 def test_graph_captured_stream_pipeline_equals_detect(lfp, torch, top_n):
     """lf_mkd_stream_*: the per-frame pipeline recorded as one hipGraph, counts handed over on the device.  Frame after

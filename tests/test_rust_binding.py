@@ -48,7 +48,7 @@ def _c_type(t):
 def header_prototypes():
     text = _strip_comments(open(HDR).read())
     protos = {}
-    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(lf_mkd_[a-z_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(lf_mkd_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
         params = []
         if args != "void":
@@ -101,7 +101,7 @@ def test_ctypes_prototypes_have_the_headers_arity_and_classes():
 def test_the_backend_type_only_calls_declared_functions():
     items = rust_items()
     src = _strip_comments(open(MOD).read(), rust=True)
-    called = set(re.findall(r"ffi::(lf_mkd_[a-z_]+)\s*\(", src))
+    called = set(re.findall(r"ffi::(lf_mkd_[a-z0-9_]+)\s*\(", src))
     assert called and called <= set(items), called - set(items)
     for must in ("lf_mkd_create", "lf_mkd_destroy", "lf_mkd_detect", "lf_mkd_detect_extrema", "lf_mkd_orient_keypoints",
                  "lf_mkd_describe_keypoints", "lf_mkd_match", "lf_mkd_last_error"):
@@ -151,7 +151,7 @@ STRUCTS = {
 CONSTANTS = ["LF_MKD_OK", "LF_MKD_ERR_BAD_ARG", "LF_MKD_ERR_HIP", "LF_MKD_ERR_IO", "LF_MKD_ERR_NO_IMAGE",
              "LF_MKD_ERR_NO_DEVICE", "LF_MKD_ERR_COMM", "LF_MKD_COMM_ID_BYTES", "LF_MKD_GATHER_DIRECT", "LF_MKD_GATHER_RING",
              "LF_MKD_ANGLE_SHADER", "LF_MKD_ANGLE_EXACT", "LF_MKD_ANGLE_EXACT_ZERO",
-             "LF_MKD_POOL_DEFAULT", "LF_MKD_POOL_F16X3", "LF_MKD_POOL_F32", "LF_MKD_POOL_F16_FP6", "LF_MKD_FLAG_KERNEL_TIMING", "LF_MKD_FLAG_UNFUSED_KEYPOINTS",
+             "LF_MKD_POOL_DEFAULT", "LF_MKD_POOL_F16X3", "LF_MKD_POOL_F32", "LF_MKD_POOL_F16_FP6", "LF_MKD_FLAG_KERNEL_TIMING", "LF_MKD_FLAG_UNFUSED_KEYPOINTS", "LF_MKD_FLAG_DETECT_STEPWISE",
              "LF_MKD_MAX_ANGLES_PER_EXTREMUM", "LF_MKD_PCA_LIBERTY", "LF_MKD_PCA_NOTREDAME", "LF_MKD_PCA_YOSEMITE",
              "LF_MKD_PATCH_SIZE", "LF_MKD_RAW_LEN", "LF_MKD_DESC_LEN"]
 

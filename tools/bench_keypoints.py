@@ -99,6 +99,55 @@ def run_orient(w, h, ne, frames, tag):
           f"{acc[1]:.3f} ms (incl. host sync for the count), sample+describe {acc[2]:.3f} ms", flush=True)
 
 
+def locality_order(k5, fid, psf=24.0, tile=64):
+    """host-side sort key (frame, pyramid level, 64 x 64 tile of that level, row-major): what a device binning pass
+     would produce -- patch_gradients.glsl:42-50 picks the level"""
+    scale = k5[:, 2] * psf / 32.0
+    lvl = np.clip(np.floor(np.log2(scale)), 0, 15).astype(np.int64)
+    tx = (k5[:, 0] / 2.0 ** lvl).astype(np.int64) // tile
+    ty = (k5[:, 1] / 2.0 ** lvl).astype(np.int64) // tile
+    return np.lexsort((tx, ty, lvl, fid))
+
+
+def run_locality(w, h, nk, frames, tag, order, reps=5, counters_only=False):
+    """describe-only time of the SAME keypoints in the given order: 'random' (as generated) or 'sorted'
+    (frame, level, 64 x 64 tile).  Pyramids are built once, outside the timed region."""
+    n = nk * frames
+    hnd = lfp.MkdHandle(max_features=n, max_image_width=w, max_image_height=h, pool_mode=lfp.POOL_F16X3, max_frames=frames)
+    s = torch.cuda.current_stream().cuda_stream
+    imgs = torch.stack([frame(h, w, 100 + (f % 8)) for f in range(frames)]).contiguous()
+    base = [np.concatenate([random_keypoints(nk, w, h, 200 + f, margin=64.0), np.zeros((nk, 1), np.float32)], axis=1) for f in range(8)]
+    k5 = np.concatenate([base[f % 8] for f in range(frames)]).astype(np.float32)
+    fid = np.repeat(np.arange(frames, dtype=np.int32), nk)
+    if order == "sorted":
+        o = locality_order(k5, fid)
+        k5, fid = np.ascontiguousarray(k5[o]), np.ascontiguousarray(fid[o])
+    kps, d_fid = torch.from_numpy(k5).cuda(), torch.from_numpy(fid).cuda()
+    out = torch.empty((n, 128), device="cuda")
+    hnd.set_images_device(imgs.data_ptr(), frames, w, h, s)
+    for _ in range(2):
+        hnd.describe_keypoints_frames_device(kps.data_ptr(), d_fid.data_ptr(), n, out.data_ptr(), s)
+    torch.cuda.synchronize()
+    if counters_only:
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(reps):
+        e0.record(); hnd.describe_keypoints_frames_device(kps.data_ptr(), d_fid.data_ptr(), n, out.data_ptr(), s); e1.record()
+        torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    print(f"{tag} [{order:6s}]: {frames} x {w}x{h} x {nk} keypoints: describe-only {np.median(ts):.4f} ms (min {min(ts):.4f}) "
+          f"= {n/np.median(ts)/1e3:.1f} M desc/s", flush=True)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "locality":
+    # usage: bench_keypoints.py locality [configs3|configs1] [random|sorted] [counters]
+    which = sys.argv[2] if len(sys.argv) > 2 else "both"
+    orders = [sys.argv[3]] if len(sys.argv) > 3 else ["random", "sorted", "random", "sorted"]
+    co = len(sys.argv) > 4
+    for o in orders:
+        if which in ("both", "configs3"): run_locality(1920, 1080, 8192, 128, "configs[3] own form", o, counters_only=co)
+        if which in ("both", "configs1"): run_locality(1920, 1080, 10000, 1, "configs[1]", o, reps=20, counters_only=co)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "orient":
     run_orient(1920, 1080, 7000, 20, "configs[1] from extrema")
     run_orient(640, 480, 1400, 20, "configs[2] frame from extrema")
