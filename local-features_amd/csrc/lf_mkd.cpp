@@ -77,6 +77,13 @@ struct lf_mkd {
     unsigned char *d_image_u8 = nullptr;              // 8-bit frame(s) on their way to level 0, allocated on first use
     unsigned long long *d_det_counts = nullptr;       // [8] the recorded detect pipeline's counts (as lf_mkd_stream_create's d_counts)
     unsigned long long *h_det_counts = nullptr;       // the same in pinned host memory: the last node of a plan copies them here
+    // ... and the keypoints, copied there by the pipeline's last node.
+    // (The descriptors stay in device memory until the count is known: having the describe kernel store them straight into
+    // pinned host memory was measured -- +20 us of kernel time at 100 keypoints, +45 us at 3000, PCIe writes stall its
+    // epilogue -- and so was a copy node of all max_out rows followed by a host memcpy of n: reading memory the device has
+    // just written runs at 25 GB/s on one core, 60 us for 3000 rows, where the runtime's own copy into the caller's array takes 15.)
+    lf_mkd_keypoint *h_res_kps = nullptr;
+    uint64_t h_res_cap = 0;
     hipEvent_t det_ev[3] = {nullptr, nullptr, nullptr};   // LF_MKD_FLAG_KERNEL_TIMING: before the upload, after it, after the pipeline
     double det_upload_ms = 0, det_pipeline_ms = 0, det_readback_ms = 0;
     // matcher scratch
@@ -535,6 +542,7 @@ void lf_mkd_destroy(lf_mkd *h) {
         if (e) (void)hipEventDestroy(e);
     if (h->d_det_counts) (void)hipFree(h->d_det_counts);
     if (h->h_det_counts) (void)hipHostFree(h->h_det_counts);
+    if (h->h_res_kps) (void)hipHostFree(h->h_res_kps);
     if (h->d_stream_patches) (void)hipFree(h->d_stream_patches);
     for (hipEvent_t e : h->ev_pending) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
@@ -941,7 +949,7 @@ static int prepare_pipeline(lf_mkd *h, uint32_t top_n, uint64_t cap) {
 static int record_pipeline(lf_mkd *h, uint32_t width, uint32_t height, uint32_t top_n, float min_size, uint64_t max_out,
                            const float *d_image, const unsigned char *d_image_u8, lf_mkd_keypoint *d_keypoints,
                            float *d_descriptors, unsigned long long *cnt, unsigned long long *host_counts,
-                           hipGraph_t *graph_out, hipGraphExec_t *exec_out) {
+                           lf_mkd_keypoint *host_keypoints, hipGraph_t *graph_out, hipGraphExec_t *exec_out) {
     hipStream_t s = h->stream;
     const uint64_t cap = top_n ? top_n : h->max_extrema;   // extrema that can reach orientation
     // the detector needs pyramid level 0 and a-trous layer 1 only: the other levels (read by the sampler at the very end)
@@ -984,7 +992,11 @@ static int record_pipeline(lf_mkd *h, uint32_t width, uint32_t height, uint32_t 
         launch_describe(h->d_stream_patches, long(max_out), cnt + 3, h->dc, h->params.angle_mode, h->params.pool_mode,
                         d_descriptors, nullptr, h->num_cus, s);
     }
+    // the counts and the keypoints go to pinned host memory as the last nodes (on a branch of their own beside the describe
+    // launch they were measured 15 us slower: every join of two branches costs ~12 us of queue latency)
     if (host_counts) (void)hipMemcpyAsync(host_counts, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    if (host_keypoints)
+        (void)hipMemcpyAsync(host_keypoints, d_keypoints, max_out * sizeof(lf_mkd_keypoint), hipMemcpyDeviceToHost, s);
     hipGraph_t graph = nullptr;
     hipError_t e_end = hipStreamEndCapture(s, &graph);
     if (e_end != hipSuccess || !graph) {
@@ -1033,6 +1045,14 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
         if (int rc = ensure_orient_scratch(h, cap, true, max_out)) return rc;     // d_kps_out, d_det_desc [max_out]
         if (!fused_keypoints(h))
             if (int rc = grow(h, &h->d_stream_patches, &h->stream_patch_cap, max_out * kPx, sizeof(float))) return rc;
+        if (max_out > h->h_res_cap) {          // the recordings store into it by address
+            retire_graph(h);
+            if (h->h_res_kps) (void)hipHostFree(h->h_res_kps);
+            h->h_res_kps = nullptr;
+            h->h_res_cap = 0;
+            LF_HIP(h, hipHostMalloc(reinterpret_cast<void **>(&h->h_res_kps), max_out * sizeof(lf_mkd_keypoint), hipHostMallocDefault));
+            h->h_res_cap = max_out;
+        }
         if (!h->d_det_counts) {
             LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_det_counts), 8 * sizeof(unsigned long long)));
             LF_HIP(h, hipMemsetAsync(h->d_det_counts, 0, 8 * sizeof(unsigned long long), s));
@@ -1075,7 +1095,7 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
         // (the upload queued above is outside the capture: the capture records, it does not run anything)
         if (int rc = record_pipeline(h, width, height, top_n, min_size, max_out, u8 ? nullptr : h->d_image,
                                      u8 ? h->d_image_u8 : nullptr, reinterpret_cast<lf_mkd_keypoint *>(h->d_kps_out),
-                                     h->d_det_desc, h->d_det_counts, h->h_det_counts, &p.graph, &p.exec))
+                                     h->d_det_desc, h->d_det_counts, h->h_det_counts, h->h_res_kps, &p.graph, &p.exec))
             return rc;
         h->plans.push_back(p);
         plan = &h->plans.back();
@@ -1100,9 +1120,8 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
     if (dropped_features) *dropped_features = c[4];
     const uint64_t n_kp = std::min<uint64_t>(c[3], max_out);
     if (n_kp == 0) return LF_MKD_OK;
-    static_assert(sizeof(lf_mkd_keypoint) == 20, "keypoint layout");
-    LF_HIP(h, hipMemcpyAsync(keypoints, h->d_kps_out, n_kp * sizeof(lf_mkd_keypoint), hipMemcpyDeviceToHost, s));
     LF_HIP(h, hipMemcpyAsync(descriptors, h->d_det_desc, n_kp * kOut * 4, hipMemcpyDeviceToHost, s));
+    std::memcpy(keypoints, h->h_res_kps, n_kp * sizeof(lf_mkd_keypoint));
     LF_HIP(h, hipStreamSynchronize(s));
     if (timed) h->det_readback_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_back).count();
     *n_out = n_kp;
@@ -1220,7 +1239,7 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
     LF_HIP(h, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), h->stream));
     LF_HIP(h, hipStreamSynchronize(h->stream));
     if (int rc = record_pipeline(h, width, height, top_n, min_size, max_out, d_image, nullptr, d_keypoints, d_descriptors, cnt,
-                                 nullptr, &h->graph, &h->graph_exec))
+                                 nullptr, nullptr, &h->graph, &h->graph_exec))
         return rc;
     h->graph_pd = h->pd;
     return LF_MKD_OK;
