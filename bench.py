@@ -278,8 +278,28 @@ def pipeline_extras(lfp, torch, device):
                 "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                              "traffic": kp_traffic.get(tag), "algorithmic_bytes_per_call": alg,
                              "algorithmic_bytes_per_descriptor": alg / n,
+                             "why_traffic_exceeds_algorithmic": WHY_KEYPOINT_TRAFFIC,
                              "kernels": "pyr_* + mkd_pool<.., keypoints> (no patch crosses HBM)"}}
             del hnd, imgs, kps, fid, o
+        # the reference's own benchmark (benches/bench.rs:41-112: detect_top_n on houses.jpg 4096 x 3072, feature-count and
+        # image-scale sweeps at n_scales 3 and 5) through the call its callers make -- host image in, host results out --
+        # as f32 (lf_mkd_detect), as the 8-bit frame it was made from (lf_mkd_detect_u8), and stage by stage as before round 5
+        try:
+            import bench_reference_sweep as brs
+            rows = brs.sweep(full=True, calls=12)
+            pcie = 56.0     # GB/s host -> device measured on this pool for pinned and for pageable memory alike (profiles/r05_upload_probe.txt)
+            out["reference_bench_houses"] = {
+                "what": "benches/bench.rs on tests/golden/houses.jpg (the reference's sample_data/houses.jpg): detect_top_n(image, "
+                        "max_features, 0.) with max_blobs = 5 x max_features, host f32 / host u8 frame in, keypoints + descriptors in "
+                        "host arrays out; median wall ms of 12 calls; upload / compute / readback = the library's own split "
+                        "(lf_mkd_detect_times); every form returns the same bits (checked in the run)",
+                "rows": rows,
+                "pcie_floor_ms_4096x3072": {"f32": 4096 * 3072 * 4 / pcie / 1e6, "u8": 4096 * 3072 / pcie / 1e6,
+                                            "what": "bytes over the 56 GB/s this pool's PCIe link moves (pinned or pageable, DMA or a "
+                                                    "kernel reading host memory: profiles/r05_upload_probe*.txt): the f32 call cannot "
+                                                    "be shorter than this plus the part of the pipeline that needs the whole frame"}}
+        except Exception as e:
+            out["reference_bench_houses"] = {"error": f"{type(e).__name__}: {e}"}
         # patch mode at the keypoint counts of configs[1] and configs[2]: the same describe call, smaller n
         for n in (10000, 512000):
             g = torch.Generator(device="cuda").manual_seed(10)
@@ -452,6 +472,17 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
             res[f"allgather_{mode}_ms_per_rank"] = per_rank(round(mine, 3))
             res[f"allgather_{mode}_gbs_per_rank"] = res["received_bytes_per_rank"] / best / 1e6
         res["allgather_ms"] = min(res["allgather_direct_ms"], res["allgather_ring_ms"])
+        # priced against xGMI: a rank receives (N - 1) shards, and in the direct form they arrive on N - 1 of its 7 point-to-point
+        # links at once (~153 GB/s per link and direction); a ring moves the same bytes
+        # over ONE link per hop, so its ceiling is a single link's rate
+        link = 153.0
+        ach = res["received_bytes_per_rank"] / res["allgather_direct_ms"] / 1e6
+        res["allgather_roofline"] = {"bound": "xgmi", "achieved": ach, "peak": link * min(world - 1, 7), "unit": "GB/s",
+                                     "frac": ach / (link * min(world - 1, 7)),
+                                     "what": f"direct form (grouped send/recv): bytes a rank receives over its time; peak = "
+                                             f"{min(world - 1, 7)} links x {link:.0f} GB/s; the ring form's ceiling is one link "
+                                             f"({link:.0f} GB/s)", "ring_achieved": res["received_bytes_per_rank"] / res["allgather_ring_ms"] / 1e6,
+                                     "rehearsal": bool(rehearsal)}
         # every shard must have arrived: row norms of the whole gathered set are 1
         nrm = gathered.norm(dim=1)
         agree(bool(((nrm - 1).abs() < 1e-4).all().item()), "gathered descriptors are not all unit norm (a shard did not arrive)")
@@ -589,6 +620,14 @@ def source_stamp():
     return hsh.hexdigest()[:16]
 
 
+WHY_KEYPOINT_TRAFFIC = ("the algorithmic bytes count a frame once and 528 B per keypoint; the counters see the pyramid written and "
+                        "read (1.33 x the frame, plus level 0 re-read for level 1) and the producers' 8-byte gathers of 1024 bilinear "
+                        "taps per keypoint from a pyramid larger than L2.  Sorting the keypoints by (frame, level, 64 x 64 tile) cuts "
+                        "the describe kernel's FETCH_SIZE by 27 % (configs[3]) / 46 % (configs[1]) and its time by < 0.5 % "
+                        "(profiles/r05_gather_locality.txt): the kernel is bound by instruction issue, not by these bytes, so no "
+                        "binning pass was added")
+
+
 def keypoint_source_stamp():
     import hashlib
     hsh = hashlib.sha256()
@@ -678,7 +717,14 @@ def main():
     dt = time.perf_counter() - t0
     pool_ms, whiten_ms, launches = h.kernel_times()
     clock_mhz, wg0_ms = h.kernel_clock(stream)     # stamps of the last timed launch's workgroup 0
+    dt_mine, kern_mine = dt, pool_ms / 1e3 / max(launches, 1)
     dt = sharding.max_over_ranks(dt, "cpu" if rehearsal else "cuda")
+    # every rank's own figures, so that a straggler is visible on the N > 1 line without a second run
+    per_rank_headline = [{"rank": rank, "descriptors_per_s": n * args.steps / dt_mine, "kernel_ms": kern_mine * 1e3}]
+    if dist is not None:
+        per_rank_headline = [None] * world
+        dist.all_gather_object(per_rank_headline, {"rank": rank, "descriptors_per_s": n * args.steps / dt_mine,
+                                                   "kernel_ms": kern_mine * 1e3})
 
     # secondary figure: the same workload with the exact gradient direction (plus the shader's angle 0 at gx == 0)
     # instead of the shader's polynomial atan2: LF_MKD_ANGLE_EXACT_ZERO, within 1e-4 of the shader reference on every
@@ -738,6 +784,10 @@ def main():
     desync = False         # an exception on this rank alone: its peers may be waiting in a collective
     if rank == 0:
         line.update(headline_line(args, world, n, total, dt, kern_s, achieved, alt, alt_f32, alt_fp6, clock_mhz, wg0_ms))
+        line["per_rank"] = {"descriptors_per_s": [round(r["descriptors_per_s"]) for r in per_rank_headline],
+                            "kernel_ms": [round(r["kernel_ms"], 4) for r in per_rank_headline],
+                            "what": "each rank's own 2^20-patch steps over its own wall time between the two fences, and its own "
+                                    "mean describe-kernel time (HIP events); value = all ranks' descriptors over the slowest rank's time"}
 
     # configs[3] in its own form (keypoint mode, frames sharded by image): every rank runs its share, with no collective
     # inside; one object gather afterwards, reached by every rank whatever happened locally
@@ -763,6 +813,8 @@ def main():
                           "describe kernel), one call each per step; every rank's own HIP-event time, no collective",
                   "ranks_ok": len(good), "ranks": world,
                   "ms_per_call_per_rank": [round(g["ms_per_call"], 3) if g.get("ok") else None for g in legs],
+                  "descriptors_per_s_per_rank": [round(g["descriptors"] / (g["ms_per_call"] * 1e-3)) if g.get("ok") else None
+                                                 for g in legs],
                   "describe_kernel_ms_per_rank": [round(g["describe_kernel_ms"], 3) if g.get("ok") else None for g in legs],
                   "errors": [g.get("error") for g in legs if not g.get("ok")] or None}
             if len(good) == world:
@@ -788,6 +840,7 @@ def main():
                                                          if kp_traffic else None,
                                         "algorithmic_bytes_per_call": alg,
                                         "algorithmic_bytes_per_descriptor": alg / good[0]["descriptors"],
+                                        "why_traffic_exceeds_algorithmic": WHY_KEYPOINT_TRAFFIC,
                                         "what": "per GPU: 528 B per keypoint (16 in, 512 out) + the frames' bytes, over the "
                                                 "slowest rank's set_images + describe time",
                                         "kernels": "pyr_* + mkd_pool<.., keypoints> (no patch crosses HBM)"}})

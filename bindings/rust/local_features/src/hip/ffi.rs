@@ -153,6 +153,8 @@ extern "C" {
     pub fn lf_mkd_match_device(h: *mut lf_mkd, d_a: *const f32, na: u64, d_b: *const f32, nb: u64,
                                d_exclude_lo: *const u32, d_exclude_hi: *const u32, ratio: f32, d_match: *mut i32,
                                d_best: *mut f32, d_second: *mut f32, stream: *mut c_void) -> c_int;
+    pub fn lf_mkd_match_both_device(h: *mut lf_mkd, d_a: *const f32, na: u64, d_b: *const f32, nb: u64, ratio: f32,
+                                    d_match_ab: *mut i32, d_match_ba: *mut i32, stream: *mut c_void) -> c_int;
     pub fn lf_mkd_match(h: *mut lf_mkd, a: *const f32, na: u64, b: *const f32, nb: u64, ratio: f32,
                         matches: *mut i32) -> c_int;
     pub fn lf_mkd_match_overflowed(h: *mut lf_mkd, stream: *mut c_void, n_rows: *mut u64) -> c_int;

@@ -303,6 +303,13 @@ int lf_mkd_stream_frame(lf_mkd *h, void *stream);
 int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d_b, uint64_t nb,
                         const uint32_t *d_exclude_lo, const uint32_t *d_exclude_hi, float ratio,
                         int32_t *d_match, float *d_best, float *d_second, void *stream);
+/* Both directions of the reference's example in one call (examples/match_images/src/main.rs:113-116 matches image 1 against
+ * image 2 and image 2 against image 1): d_match_ab [na] as lf_mkd_match_device(a, b) gives it, d_match_ba [nb] as
+ * lf_mkd_match_device(b, a) does -- decision for decision.  Where both directions fit the one-launch form (the example's own
+ * 2000 x 2000) they ARE one launch: the second direction costs no second launch.  Device pointers (16-byte aligned),
+ * asynchronous on `stream`; na, nb >= 2. */
+int lf_mkd_match_both_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d_b, uint64_t nb, float ratio,
+                             int32_t *d_match_ab, int32_t *d_match_ba, void *stream);
 /* Host pointers, synchronous. */
 int lf_mkd_match(lf_mkd *h, const float *a, uint64_t na, const float *b, uint64_t nb, float ratio,
                  int32_t *match);

@@ -1345,6 +1345,28 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
     return LF_MKD_OK;
 }
 
+int lf_mkd_match_both_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d_b, uint64_t nb, float ratio,
+                             int32_t *d_match_ab, int32_t *d_match_ba, void *stream) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (na == 0 && nb == 0) return LF_MKD_OK;
+    if (!d_a || !d_b || !d_match_ab || !d_match_ba) return fail(h, LF_MKD_ERR_BAD_ARG, "match_both_device: null pointer");
+    if (na < 2 || nb < 2) return fail(h, LF_MKD_ERR_BAD_ARG, "match_both: needs at least two rows on either side (main.rs:20)");
+    if ((reinterpret_cast<uintptr_t>(d_a) | reinterpret_cast<uintptr_t>(d_b)) & 15)
+        return fail(h, LF_MKD_ERR_BAD_ARG, "match_both_device: d_a and d_b must be 16-byte aligned");
+    LF_HIP(h, hipSetDevice(h->params.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    const char *form = getenv("LF_MKD_MATCH");
+    if (!form && match_small_fits(long(na), long(nb)) && match_small_fits(long(nb), long(na))) {
+        launch_match_small_both(d_a, long(na), d_b, long(nb), ratio, d_match_ab, d_match_ba,
+                                h->d_match_misc ? h->d_match_misc + 2 : nullptr, s);
+        LF_HIP(h, hipGetLastError());
+        return LF_MKD_OK;
+    }
+    // larger problems (or a forced form): one call per direction, each in the form its size takes
+    if (int rc = lf_mkd_match_device(h, d_a, na, d_b, nb, nullptr, nullptr, ratio, d_match_ab, nullptr, nullptr, s)) return rc;
+    return lf_mkd_match_device(h, d_b, nb, d_a, na, nullptr, nullptr, ratio, d_match_ba, nullptr, nullptr, s);
+}
+
 int lf_mkd_match_overflowed(lf_mkd *h, void *stream, uint64_t *n_rows) {
     if (!h) return LF_MKD_ERR_BAD_ARG;
     if (!n_rows) return fail(h, LF_MKD_ERR_BAD_ARG, "match_overflowed: null pointer");

@@ -125,6 +125,9 @@ void launch_match(const unsigned char *a_tiles, long na, const unsigned char *b_
 bool match_small_fits(long na, long nb);
 void launch_match_small(const float *a, long na, const float *b, long nb, const unsigned *excl_lo, const unsigned *excl_hi,
                         float ratio, int *match, float *best, float *second, unsigned *overflowed_word, hipStream_t stream);
+// both directions (a's rows against b, b's rows against a) in one launch; both must fit match_small_fits
+void launch_match_small_both(const float *a, long na, const float *b, long nb, float ratio, int *match_ab, int *match_ba,
+                             unsigned *overflowed_word, hipStream_t stream);
 // the same scan over the overflowed rows alone (few_words: their indices first, written by launch_match_verify)
 size_t match_few_tiles_bytes();
 size_t match_few_words();

@@ -306,19 +306,16 @@ __global__ __launch_bounds__(256) void match_merge(const float *__restrict__ p_b
 // device-scope atomics, five workgroups per word.  One range it stays.)
 constexpr int kSmallWaves = 16;
 
-__global__ __launch_bounds__(64 * kSmallWaves) void match_small(const float *__restrict__ a, long na,
-                                                                const float *__restrict__ b, long nb,
-                                                                const unsigned *__restrict__ excl_lo,
-                                                                const unsigned *__restrict__ excl_hi, float ratio,
-                                                                int *__restrict__ match, float *__restrict__ best_out,
-                                                                float *__restrict__ second_out,
-                                                                unsigned *__restrict__ overflowed_word) {
+// (the body of a workgroup: `block` = which 16 rows of a it owns)
+__device__ __forceinline__ void match_small_block(const float *__restrict__ a, long na, const float *__restrict__ b, long nb,
+                                                  const unsigned *__restrict__ excl_lo, const unsigned *__restrict__ excl_hi,
+                                                  float ratio, int *__restrict__ match, float *__restrict__ best_out,
+                                                  float *__restrict__ second_out, long block) {
     __shared__ float s_best[kSmallWaves][16], s_second[kSmallWaves][16];
     __shared__ int s_idx[kSmallWaves][16];
-    if (overflowed_word && blockIdx.x == 0 && threadIdx.x == 0) *overflowed_word = 0u;   // this form redoes nothing
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = lane & 15, g = lane >> 4;
-    const long arow = (long)blockIdx.x * 16 + n;
+    const long arow = block * 16 + n;
     const long arow_c = arow < na ? arow : na - 1;
     struct Raw { f32x4 v[8]; };   // a row's share of the four k-steps: k = 32 s + 8 g .. + 7
     auto load_row = [&](const float *row) {
@@ -419,6 +416,35 @@ __global__ __launch_bounds__(64 * kSmallWaves) void match_small(const float *__r
         if (best_out) best_out[arow] = bb;
         if (second_out) second_out[arow] = ss;
     }
+}
+
+__global__ __launch_bounds__(64 * kSmallWaves) void match_small(const float *__restrict__ a, long na,
+                                                                const float *__restrict__ b, long nb,
+                                                                const unsigned *__restrict__ excl_lo,
+                                                                const unsigned *__restrict__ excl_hi, float ratio,
+                                                                int *__restrict__ match, float *__restrict__ best_out,
+                                                                float *__restrict__ second_out,
+                                                                unsigned *__restrict__ overflowed_word) {
+    if (overflowed_word && blockIdx.x == 0 && threadIdx.x == 0) *overflowed_word = 0u;   // this form redoes nothing
+    match_small_block(a, na, b, nb, excl_lo, excl_hi, ratio, match, best_out, second_out, (long)blockIdx.x);
+}
+
+// BOTH directions of the reference's example in one launch (examples/match_images/src/main.rs:113-116 matches 1 -> 2 and
+// 2 -> 1): the first ceil(na / 16) workgroups match a's rows against b, the others b's rows against a -- the same body with the
+// operands' roles exchanged, so each direction decides exactly as a launch of match_small in that direction would.  At
+// 2000 x 2000 the two directions are 250 workgroups, one round of the chip: the second direction costs no second launch and
+// next to no time.  (Keeping a column top-2 beside the row top-2 and merging it across the a blocks would save the second
+// direction's arithmetic, but needs workgroups to meet through memory -- measured twice in round 4 at +40 % and +400 %.)
+__global__ __launch_bounds__(64 * kSmallWaves) void match_small_both(const float *__restrict__ a, long na,
+                                                                     const float *__restrict__ b, long nb, float ratio,
+                                                                     int *__restrict__ match_ab, int *__restrict__ match_ba,
+                                                                     unsigned *__restrict__ overflowed_word) {
+    if (overflowed_word && blockIdx.x == 0 && threadIdx.x == 0) *overflowed_word = 0u;
+    const long blocks_ab = (na + 15) / 16;
+    if ((long)blockIdx.x < blocks_ab)
+        match_small_block(a, na, b, nb, nullptr, nullptr, ratio, match_ab, nullptr, nullptr, (long)blockIdx.x);
+    else
+        match_small_block(b, nb, a, na, nullptr, nullptr, ratio, match_ba, nullptr, nullptr, (long)blockIdx.x - blocks_ab);
 }
 
 // ---- two-pass form ----------------------------------------------------------------------------------------------
@@ -774,6 +800,13 @@ void launch_match_small(const float *a, long na, const float *b, long nb, const 
     if (na <= 0) return;
     hipLaunchKernelGGL(match_small, dim3((unsigned)((na + 15) / 16)), dim3(64 * kSmallWaves), 0, stream, a, na, b, nb,
                        excl_lo, excl_hi, ratio, match, best, second, overflowed_word);
+}
+
+void launch_match_small_both(const float *a, long na, const float *b, long nb, float ratio, int *match_ab, int *match_ba,
+                             unsigned *overflowed_word, hipStream_t stream) {
+    if (na <= 0 || nb <= 0) return;
+    hipLaunchKernelGGL(match_small_both, dim3((unsigned)((na + 15) / 16 + (nb + 15) / 16)), dim3(64 * kSmallWaves), 0, stream, a,
+                       na, b, nb, ratio, match_ab, match_ba, overflowed_word);
 }
 
 size_t match_few_tiles_bytes() { return match_tiles_bytes(kOverRows); }

@@ -459,6 +459,12 @@ __global__ __launch_bounds__(128) void pyr_level1_staged(const float *__restrict
     }
 }
 
+// (Round 5 built levels 0 AND 1 from one read of the frame, twice -- one column per thread like the kernels above, then four
+// columns per lane with two-wide packed arithmetic -- bit-identical both times and no faster than pyr_sep3_staged followed by
+// pyr_level1_staged (128 frames of 1080p: 704 us for the two launches, 700 and 775 us fused): each of the two kernels already
+// sits at its HBM time AND at its instruction issue time, so the fused kernel pays the sum of their arithmetic on less traffic.
+// profiles/r05_ab_pyramid.txt; removed.)
+
 // blur_pyramid.glsl:36-49 vertical pass: binomial taps centred on texel (2x, 2y) of the H result.
 template <bool REFLECT = false>
 __device__ __forceinline__ float down_v_pixel(const float *__restrict__ in, int w, int h, int x, int y) {
@@ -520,6 +526,80 @@ __global__ __launch_bounds__(256) void pyr_down_fused(const float *__restrict__ 
         float sum = s_h[2 * k + 2][threadIdx.x] * 0.375f;
         sum += (side[0] + side[1]) * 0.3125f;
         if (xr < ow) store_with_apron(out, opitch, ow, oh, oapron, xr, y, sum);
+    }
+}
+
+// pyr_down_fused with the source rows staged in LDS by 16-byte requests (round 5; pyr_swt_staged has the why: the fused form
+// gathers every other texel of level l-1 with one dword per lane, 75 such loads per thread).  A workgroup of two waves writes 124
+// columns and ROWS rows of level l: the 256-texel segment starts at source column 2 x0 - 4 (virtual: mirrored where it leaves
+// the level), output column x0 + t has its centre tap at segment texel 2 t + 4 and its side taps at floor(2 x -+ 1.2) and the
+// texel after; slot m holds source row 2 y0 - 2 + m (mirrored), output row y0 + k reads slots 2k .. 2k + 4.  The tap weights
+// are computed from the coordinates exactly as sep3_pixel and pyr_down_fused compute them.  For level widths (of l-1) that are
+// multiples of 4 with 16-byte aligned rows.  Same arithmetic in the same order: bit-identical.
+template <int ROWS>
+__global__ __launch_bounds__(128) void pyr_down_staged(const float *__restrict__ in, float *__restrict__ out, long in_stride,
+                                                       long out_stride, int pw, int ph, int ppitch, int ow, int oh, int opitch,
+                                                       int oapron) {
+#pragma clang fp contract(off)
+    constexpr int kSlots = 2 * ROWS + 4, kOutCols = 124;      // (2 ROWS + 3 are read; an even count keeps the two waves' loops alike)
+    __shared__ __attribute__((aligned(16))) float s_raw[kSlots][256];
+    const TileId tile = xcd_tile();
+    in += tile.z * in_stride;
+    out += tile.z * out_stride;
+    const int y0 = (int)tile.y * ROWS, x0 = (int)tile.x * kOutCols;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = 2 * x0 - 4 + 4 * lane, v0 = 2 * y0 - 2;
+    const bool whole = c0 >= 0 && c0 + 3 < pw;
+    int cm[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cm[j] = mirror_idx(c0 + j, pw);
+    f32x4 seg[kSlots / 2];
+#pragma unroll
+    for (int i = 0; i < kSlots / 2; ++i) {
+        const float *row = in + (size_t)mirror_idx(v0 + wave + 2 * i, ph) * ppitch;
+        if (whole) seg[i] = *reinterpret_cast<const f32x4 *>(row + c0);
+        else seg[i] = f32x4{row[cm[0]], row[cm[1]], row[cm[2]], row[cm[3]]};
+    }
+#pragma unroll
+    for (int i = 0; i < kSlots / 2; ++i) *reinterpret_cast<f32x4 *>(&s_raw[wave + 2 * i][4 * lane]) = seg[i];
+    __syncthreads();
+    const int t = (int)threadIdx.x, xr = x0 + t;
+    if (t >= kOutCols || xr >= ow) return;
+    // horizontal pass at source column sx = 2 xr (sep3_pixel, horizontal, w0 = 0.375, w1 = 0.3125, off = 1.2)
+    const int sx = 2 * xr, base = 2 * x0 - 4;
+    int j0[2];
+    float a[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float c = (float)sx + 0.5f, u = k == 0 ? c - 1.2f : c + 1.2f;
+        const float fu = u - 0.5f, f0 = floorf(fu);
+        a[k] = fu - f0;
+        const int j = (int)f0 - base;
+        j0[k] = j < 0 ? 0 : (j > 254 ? 254 : j);   // never binding: the taps are texels 2t + 2 .. 2t + 6 of the segment
+    }
+    float hres[2 * ROWS + 3];
+#pragma unroll
+    for (int m = 0; m < 2 * ROWS + 3; ++m) {
+        const float *row = s_raw[m];
+        const float side0 = row[j0[0]] * (1.f - a[0]) + row[j0[0] + 1] * a[0];
+        const float side1 = row[j0[1]] * (1.f - a[1]) + row[j0[1] + 1] * a[1];
+        float sum = row[sx - base] * 0.375f;
+        sum += (side0 + side1) * 0.3125f;
+        hres[m] = sum;
+    }
+    // vertical pass (pyr_down_fused's): taps at rows floor(2y -+ 1.2) and the row after, centre 2y
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        const int y = y0 + k;
+        if (y >= oh) break;
+        const float cy = 2.f * (float)y + 0.5f;
+        const float fl = (cy - 1.2f) - 0.5f, fh = (cy + 1.2f) - 0.5f;
+        const float al = fl - floorf(fl), ah = fh - floorf(fh);
+        const float side0 = hres[2 * k] * (1.f - al) + hres[2 * k + 1] * al;
+        const float side1 = hres[2 * k + 3] * (1.f - ah) + hres[2 * k + 4] * ah;
+        float sum = hres[2 * k + 2] * 0.375f;
+        sum += (side0 + side1) * 0.3125f;
+        store_with_apron(out, opitch, ow, oh, oapron, xr, y, sum);
     }
 }
 
@@ -799,10 +879,23 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
             hipLaunchKernelGGL(pyr_level1_fused<8>, dim3((pd.w[1] + kL1Cols - 1) / kL1Cols, (pd.h[1] + 7) / 8, frames),
                                dim3(kL1Cols), 0, stream, (const float *)(pyr + pd.offset[0]), pyr + pd.offset[1], pyr_stride,
                                pyr_stride, w, h, pd.pitch[0], pd.w[1], pd.h[1], pd.pitch[1], apron_of(1));
-    for (int l = 2; l < l0; ++l)
-        hipLaunchKernelGGL(pyr_down_fused, dim3((pd.w[l] + 255) / 256, (pd.h[l] + kDownRows - 1) / kDownRows, frames),
-                           dim3(256), 0, stream, (const float *)(pyr + pd.offset[l - 1]), pyr + pd.offset[l], pyr_stride,
-                           pyr_stride, pd.w[l - 1], pd.h[l - 1], pd.pitch[l - 1], pd.w[l], pd.h[l], pd.pitch[l], apron_of(l));
+    for (int l = 2; l < l0; ++l) {
+        // the staged form where its 16-byte requests are aligned (level l-1's texel (0, 0) of every frame and its pitch)
+        const bool staged = pd.w[l - 1] % 4 == 0 && pd.pitch[l - 1] % 4 == 0 && pyr_stride % 4 == 0 &&
+                            (reinterpret_cast<uintptr_t>(pyr + pd.offset[l - 1]) & 15) == 0 && getenv("LF_MKD_NO_DOWN_STAGED") == nullptr;
+        if (staged && frames >= 8)
+            hipLaunchKernelGGL(pyr_down_staged<12>, dim3((pd.w[l] + 123) / 124, (pd.h[l] + 11) / 12, frames), dim3(128), 0, stream,
+                               (const float *)(pyr + pd.offset[l - 1]), pyr + pd.offset[l], pyr_stride, pyr_stride, pd.w[l - 1],
+                               pd.h[l - 1], pd.pitch[l - 1], pd.w[l], pd.h[l], pd.pitch[l], apron_of(l));
+        else if (staged)
+            hipLaunchKernelGGL(pyr_down_staged<6>, dim3((pd.w[l] + 123) / 124, (pd.h[l] + 5) / 6, frames), dim3(128), 0, stream,
+                               (const float *)(pyr + pd.offset[l - 1]), pyr + pd.offset[l], pyr_stride, pyr_stride, pd.w[l - 1],
+                               pd.h[l - 1], pd.pitch[l - 1], pd.w[l], pd.h[l], pd.pitch[l], apron_of(l));
+        else
+            hipLaunchKernelGGL(pyr_down_fused, dim3((pd.w[l] + 255) / 256, (pd.h[l] + kDownRows - 1) / kDownRows, frames),
+                               dim3(256), 0, stream, (const float *)(pyr + pd.offset[l - 1]), pyr + pd.offset[l], pyr_stride,
+                               pyr_stride, pd.w[l - 1], pd.h[l - 1], pd.pitch[l - 1], pd.w[l], pd.h[l], pd.pitch[l], apron_of(l));
+    }
     if (l0 < pd.levels)
         hipLaunchKernelGGL(pyr_tail, dim3(frames), dim3(1024), 0, stream, pyr, pyr_stride, pd, l0, tail_aprons ? 1 : 0);
     launch_apron_fill(pyr, pyr_stride, pd, fill_from, fill_end, frames, stream);

@@ -25,7 +25,8 @@ def match_images(img1, img2, top_n=2000, min_size=0.0):
                               max_blobs=8000, n_scales=5, pca="liberty", pool_mode=lfp.POOL_F16X3)
     kp1, d1 = feats.detect_top_n(img1, top_n, min_size)
     kp2, d2 = feats.detect_top_n(img2, top_n, min_size)
-    return kp1, kp2, d1, d2, feats.match(d1, d2), feats.match(d2, d1)
+    m12, m21 = feats.match_both(d1, d2)        # main.rs:113-116: both directions, one launch on the device
+    return kp1, kp2, d1, d2, m12, m21
 
 
 def draw(img1, img2, kp1, kp2, matches, out_path):

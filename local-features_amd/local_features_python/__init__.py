@@ -117,6 +117,28 @@ class LocalFeatures:
             m = self._inner.match(desc_a, desc_b, ratio)
         return [(int(i), int(j)) for i, j in enumerate(m) if j >= 0]
 
+    def match_both(self, desc_a, desc_b, ratio=0.8):
+        """Both directions of the example (examples/match_images/src/main.rs:113-116: match_features(f1, f2) and
+        match_features(f2, f1)) in one library call -- one launch at the example's own size (lf_mkd_match_both_device).
+        Returns (matches a -> b, matches b -> a), each as `match` returns them."""
+        import torch
+        a = np.ascontiguousarray(desc_a, np.float32).reshape(-1, 128)
+        b = np.ascontiguousarray(desc_b, np.float32).reshape(-1, 128)
+        if len(a) < 2 or len(b) < 2:
+            return self.match(a, b, ratio) if len(a) and len(b) >= 2 else [], self.match(b, a, ratio) if len(b) and len(a) >= 2 else []
+        dev = torch.device("cuda", self.device)
+        with self._lock, torch.cuda.device(dev):
+            d_a, d_b = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+            m_ab = torch.empty((len(a),), dtype=torch.int32, device=dev)
+            m_ba = torch.empty((len(b),), dtype=torch.int32, device=dev)
+            s = torch.cuda.current_stream(dev)
+            self._inner.match_both_device(d_a.data_ptr(), len(a), d_b.data_ptr(), len(b), m_ab.data_ptr(), m_ba.data_ptr(),
+                                          ratio, s.cuda_stream)
+            s.synchronize()
+            self._inner.synchronize()       # (torch's default stream is handle 0 = "the library's own stream" to the ABI)
+            m_ab, m_ba = m_ab.cpu().numpy(), m_ba.cpu().numpy()
+        return ([(int(i), int(j)) for i, j in enumerate(m_ab) if j >= 0], [(int(i), int(j)) for i, j in enumerate(m_ba) if j >= 0])
+
     def match_ip_distance(self, desc_a, desc_b, factor=0.75):
         """The webcam example's acceptance rule (examples/webcam/src/main.rs:97-104,261-265): nearest and second-nearest
         neighbour of desc_a[i] in desc_b under the inner-product distance d = 1 - <a, b> (usearch MetricKind::IP), accepted

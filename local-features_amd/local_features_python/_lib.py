@@ -29,7 +29,7 @@ SYMBOLS = (
     "lf_mkd_build_constants", "lf_mkd_kernel_times", "lf_mkd_kernel_clock", "lf_mkd_synchronize", "lf_mkd_version",
     "lf_mkd_orient_keypoints", "lf_mkd_orient_keypoints_device", "lf_mkd_get_coarse_layer",
     "lf_mkd_detect_extrema", "lf_mkd_detect_extrema_device", "lf_mkd_filter_extrema_device", "lf_mkd_detect",
-    "lf_mkd_match", "lf_mkd_match_device", "lf_mkd_match_overflowed", "lf_mkd_stream_create", "lf_mkd_stream_frame",
+    "lf_mkd_match", "lf_mkd_match_device", "lf_mkd_match_both_device", "lf_mkd_match_overflowed", "lf_mkd_stream_create", "lf_mkd_stream_frame",
     "lf_mkd_detect_frames_device", "lf_mkd_orient_keypoints_blocked",
     "lf_mkd_comm_unique_id", "lf_mkd_comm_create", "lf_mkd_comm_destroy", "lf_mkd_comm_info", "lf_mkd_allgather_descriptors",
 )
@@ -112,6 +112,7 @@ def load_library():
     L.lf_mkd_detect_times.argtypes = [vp] + [ctypes.POINTER(ctypes.c_double)] * 3
     L.lf_mkd_match_device.argtypes = [vp, vp, u64, vp, u64, vp, vp, ctypes.c_float, vp, vp, vp, vp]
     L.lf_mkd_match.argtypes = [vp, vp, u64, vp, u64, ctypes.c_float, vp]
+    L.lf_mkd_match_both_device.argtypes = [vp, vp, u64, vp, u64, ctypes.c_float, vp, vp, vp]
     L.lf_mkd_match_overflowed.argtypes = [vp, vp, ctypes.POINTER(u64)]
     L.lf_mkd_stream_create.argtypes = [vp, u32, u32, u32, ctypes.c_float, u64, vp, vp, vp, vp]
     L.lf_mkd_stream_frame.argtypes = [vp, vp]
@@ -417,6 +418,11 @@ class MkdHandle:
                      d_second=None, stream=None):
         self._device_call(stream, lambda s: self.L.lf_mkd_match_device(
             self._h, d_a, na, d_b, nb, d_exclude_lo, d_exclude_hi, ratio, d_match, d_best, d_second, s), "lf_mkd_match_device")
+
+    def match_both_device(self, d_a, na, d_b, nb, d_match_ab, d_match_ba, ratio=0.8, stream=None):
+        """both directions in one call: match_ab [na] = match(a, b), match_ba [nb] = match(b, a)"""
+        self._device_call(stream, lambda s: self.L.lf_mkd_match_both_device(self._h, d_a, na, d_b, nb, ratio, d_match_ab,
+                                                                             d_match_ba, s), "lf_mkd_match_both_device")
 
     def match_overflowed(self, stream=None):
         """Rows of the latest match call that were redone by the full scan (diagnostic; waits for the call)."""

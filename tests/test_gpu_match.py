@@ -72,6 +72,57 @@ def test_match_vs_oracle(lfp, torch, oracle, na, nb):
     assert np.array_equal(h.match(a, b), d_m.cpu().numpy())   # host entry point = device entry point
 
 
+@pytest.mark.parametrize("na,nb", [(2000, 2000), (2, 2), (31, 33), (1900, 2100), (500, 4000), (3000, 2800), (64, 40000)])
+def test_both_directions_in_one_call(lfp, torch, oracle, na, nb):
+    """lf_mkd_match_both_device: the example's two match_features calls (examples/match_images/src/main.rs:113-116) in one
+    library call, ONE launch where both directions fit the one-launch form.  Each direction must decide exactly as the
+    one-direction entry point does (same kernel body, operands exchanged), and as the oracle's match does in that direction
+    (ties to the highest index included: planted below)."""
+    a, b = descriptor_sets(na, nb, 3 * na + nb)
+    if na >= 31:                       # exact ties in both directions: duplicated rows on either side
+        b[7], b[19] = b[3].copy(), b[3].copy()
+        a[11], a[5] = a[2].copy(), a[2].copy()
+    h = lfp.MkdHandle(max_features=64)
+    d_a, d_b = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    m_ab, m_ba = torch.empty(na, dtype=torch.int32, device="cuda"), torch.empty(nb, dtype=torch.int32, device="cuda")
+    one_ab, one_ba = torch.empty_like(m_ab), torch.empty_like(m_ba)
+    s = torch.cuda.current_stream().cuda_stream
+    h.match_both_device(d_a.data_ptr(), na, d_b.data_ptr(), nb, m_ab.data_ptr(), m_ba.data_ptr(), 0.8, s)
+    h.match_device(d_a.data_ptr(), na, d_b.data_ptr(), nb, one_ab.data_ptr(), 0.8, stream=s)
+    h.match_device(d_b.data_ptr(), nb, d_a.data_ptr(), na, one_ba.data_ptr(), 0.8, stream=s)
+    torch.cuda.synchronize()
+    assert torch.equal(m_ab, one_ab) and torch.equal(m_ba, one_ba), (na, nb)
+    for got, (x, y) in ((m_ab.cpu().numpy(), (a, b)), (m_ba.cpu().numpy(), (b, a))):
+        want, s1, s2 = oracle.match(x, y)
+        diff = np.flatnonzero(got != want)
+        for i in diff:                 # a differing decision must be a near-tie (see compare)
+            assert abs(s1[i] * np.float32(0.8) - s2[i]) < 2e-6 or abs(s1[i] - s2[i]) < 2e-6, (na, nb, i, got[i], want[i])
+        assert len(diff) <= max(2, len(want) // 500)
+    if na >= 31:                       # the planted duplicates: with the ratio test switched off the HIGHEST index among equal maxima wins,
+        # in both directions
+        h.match_both_device(d_a.data_ptr(), na, d_b.data_ptr(), nb, m_ab.data_ptr(), m_ba.data_ptr(), 0.0, s)
+        torch.cuda.synchronize()
+        w_ab, _, _ = oracle.match(a, b, ratio=0.0)
+        w_ba, _, _ = oracle.match(b, a, ratio=0.0)
+        assert np.array_equal(m_ab.cpu().numpy()[[2, 5, 11]], w_ab[[2, 5, 11]])
+        assert np.array_equal(m_ba.cpu().numpy()[[3, 7, 19]], w_ba[[3, 7, 19]])
+        assert m_ba[3].item() == m_ba[7].item() == m_ba[19].item()
+
+
+def test_match_both_errors(lfp, torch):
+    h = lfp.MkdHandle(max_features=64)
+    x = torch.zeros((4, 128), device="cuda")
+    m = torch.zeros(4, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="at least two"):
+        h.match_both_device(x.data_ptr(), 1, x.data_ptr(), 4, m.data_ptr(), m.data_ptr())
+    with pytest.raises(RuntimeError, match="null"):
+        h.match_both_device(x.data_ptr(), 4, x.data_ptr(), 4, None, m.data_ptr())
+    with pytest.raises(RuntimeError, match="aligned"):
+        h.match_both_device(x.data_ptr() + 4, 2, x.data_ptr(), 4, m.data_ptr(), m.data_ptr())
+    with pytest.raises(RuntimeError, match="aligned"):
+        h.match_device(x.data_ptr() + 4, 2, x.data_ptr(), 4, m.data_ptr())
+
+
 def test_match_ties_and_errors(lfp, oracle):
     h = lfp.MkdHandle(max_features=64)
     rng = np.random.default_rng(1)

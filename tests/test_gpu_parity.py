@@ -214,13 +214,67 @@ def test_pyramid_levels_are_bit_exact(lfp, oracle):
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     from gen_golden import smooth_image
-    for w, hgt in ((640, 480), (333, 257), (97, 64), (1920, 1080)):
+    # (the shapes after 1920 x 1080 end in partial tiles of the staged kernels)
+    for w, hgt in ((640, 480), (333, 257), (97, 64), (1920, 1080), (256, 98), (500, 26), (1000, 50), (252, 24)):
         img = np.ascontiguousarray(smooth_image(hgt, w, w), np.float32)
         h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt)
         h.set_image(img)
         pyr = oracle.split_pyramid(oracle.build_pyramid(img), w, hgt)
         for l, lv in enumerate(pyr):
             assert np.array_equal(h.pyramid_level(l), lv), (w, hgt, l)
+
+
+def test_the_staged_decimation_and_8_bit_frames_give_the_bits_of_the_kernels_they_replace(lfp, torch, monkeypatch):
+    """Round 5: the decimated pyramid levels are built with their source rows staged in LDS (pyr_down_staged) and must have
+    the bits of the gathering kernel they replace (LF_MKD_NO_DOWN_STAGED in the environment brings it back), aprons included,
+    for single frames and batches, f32 and 8-bit frames, tiles cut by the levels' edges."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_golden import smooth_image
+    for w, hgt, frames in ((1920, 1080, 1), (640, 480, 9), (256, 98, 2), (500, 26, 8), (1000, 50, 1), (4096, 64, 1), (252, 2000, 1)):
+        img = np.ascontiguousarray(smooth_image(hgt, w, w + 3), np.float32)
+        u8 = np.ascontiguousarray(np.rint(img * 255).astype(np.uint8))
+        stack32 = np.stack([img] + [np.ascontiguousarray(img[::-1])] * (frames - 1))
+        stack8 = np.stack([u8] + [np.ascontiguousarray(u8[::-1])] * (frames - 1))
+        got = {}
+        for form in ("new", "old"):
+            if form == "old":
+                monkeypatch.setenv("LF_MKD_NO_DOWN_STAGED", "1")
+            else:
+                monkeypatch.delenv("LF_MKD_NO_DOWN_STAGED", raising=False)
+            for px, stack in (("f32", stack32), ("u8", stack8)):
+                h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt, max_frames=frames)
+                d = torch.from_numpy(stack).cuda()
+                if px == "f32":
+                    h.set_images_device(d.data_ptr(), frames, w, hgt)
+                else:
+                    h.set_images_u8_device(d.data_ptr(), frames, w, hgt)
+                h.synchronize()
+                lv, l = [], 0
+                while True:
+                    try:
+                        lv.append(h.pyramid_level_apron(l)[0])
+                    except RuntimeError:
+                        break
+                    l += 1
+                # a keypoint of the LAST frame sees that frame's pyramid: describe a few there too
+                k = np.array([[w / 2, hgt / 2, 2.0 + i, 30.0 * i, 0] for i in range(8)], np.float32)
+                dk, df = torch.from_numpy(k).cuda(), torch.full((8,), frames - 1, dtype=torch.int32, device="cuda")
+                out = torch.empty((8, 128), device="cuda")
+                h.describe_keypoints_frames_device(dk.data_ptr(), df.data_ptr(), 8, out.data_ptr())
+                h.synchronize()
+                got[form, px] = (lv, out.cpu().numpy())
+        for px in ("f32", "u8"):
+            a, b = got["new", px], got["old", px]
+            assert len(a[0]) == len(b[0]) >= 4
+            for l, (x, y) in enumerate(zip(a[0], b[0])):
+                assert np.array_equal(x, y), (w, hgt, frames, px, l)
+            assert np.array_equal(a[1], b[1]), (w, hgt, frames, px)
+        # the 8-bit frame stands for u8 / 255: its pyramid is that f32 frame's
+        h = lfp.MkdHandle(max_features=64, max_image_width=w, max_image_height=hgt)
+        h.set_image(u8.astype(np.float32) / np.float32(255))
+        for l in range(len(got["new", "u8"][0])):
+            assert np.array_equal(h.pyramid_level_apron(l)[0], got["new", "u8"][0][l]), (w, hgt, l)
 
 
 def test_full_size_properties(lfp, torch):
