@@ -70,6 +70,12 @@ struct lf_mkd {
         bool u8 = false;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
+        // banded form (frames large enough to be worth it): the frame is uploaded in two pieces, rows [0, band_rows) first;
+        // `head` is the share of the pipeline's front those rows allow (RowBands part 0) and runs while the second piece is on
+        // its way, `graph` is then part 1 + everything else
+        uint32_t band_rows = 0;
+        hipGraph_t head_graph = nullptr;
+        hipGraphExec_t head = nullptr;
         PyramidDesc pd{};
     };
     std::vector<DetectPlan> plans;
@@ -84,6 +90,8 @@ struct lf_mkd {
     // just written runs at 25 GB/s on one core, 60 us for 3000 rows, where the runtime's own copy into the caller's array takes 15.)
     lf_mkd_keypoint *h_res_kps = nullptr;
     uint64_t h_res_cap = 0;
+    hipStream_t copy_stream = nullptr;                    // the banded upload: pieces are copied here, the pipeline's parts wait for them
+    hipEvent_t copy_ev[2] = {nullptr, nullptr};
     hipEvent_t det_ev[3] = {nullptr, nullptr, nullptr};   // LF_MKD_FLAG_KERNEL_TIMING: before the upload, after it, after the pipeline
     double det_upload_ms = 0, det_pipeline_ms = 0, det_readback_ms = 0;
     // matcher scratch
@@ -340,6 +348,8 @@ void retire_graph(lf_mkd *h) {
     for (auto &p : h->plans) {       // lf_mkd_detect's recordings hold the same raw pointers: the next call records anew
         if (p.exec) (void)hipGraphExecDestroy(p.exec);
         if (p.graph) (void)hipGraphDestroy(p.graph);
+        if (p.head) (void)hipGraphExecDestroy(p.head);
+        if (p.head_graph) (void)hipGraphDestroy(p.head_graph);
     }
     h->plans.clear();
 }
@@ -536,7 +546,12 @@ void lf_mkd_destroy(lf_mkd *h) {
     for (auto &p : h->plans) {
         if (p.exec) (void)hipGraphExecDestroy(p.exec);
         if (p.graph) (void)hipGraphDestroy(p.graph);
+        if (p.head) (void)hipGraphExecDestroy(p.head);
+        if (p.head_graph) (void)hipGraphDestroy(p.head_graph);
     }
+    for (hipEvent_t e : h->copy_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->d_image_u8) (void)hipFree(h->d_image_u8);
     for (hipEvent_t e : h->det_ev)
         if (e) (void)hipEventDestroy(e);
@@ -949,12 +964,14 @@ static int prepare_pipeline(lf_mkd *h, uint32_t top_n, uint64_t cap) {
 static int record_pipeline(lf_mkd *h, uint32_t width, uint32_t height, uint32_t top_n, float min_size, uint64_t max_out,
                            const float *d_image, const unsigned char *d_image_u8, lf_mkd_keypoint *d_keypoints,
                            float *d_descriptors, unsigned long long *cnt, unsigned long long *host_counts,
-                           lf_mkd_keypoint *host_keypoints, hipGraph_t *graph_out, hipGraphExec_t *exec_out) {
+                           lf_mkd_keypoint *host_keypoints, hipGraph_t *graph_out, hipGraphExec_t *exec_out,
+                           const RowBands *bands = nullptr) {
     hipStream_t s = h->stream;
     const uint64_t cap = top_n ? top_n : h->max_extrema;   // extrema that can reach orientation
     // the detector needs pyramid level 0 and a-trous layer 1 only: the other levels (read by the sampler at the very end)
     // are a branch of the graph beside the a-trous stack, the scan, the selection and the orientation
-    const bool fork = h->pd.levels >= 2;
+    const bool head_only = bands && bands->part == 0;       // (the first band's share: the front's kernels on its rows, nothing else)
+    const bool fork = h->pd.levels >= 2 && !head_only;
     if (fork)
         if (int rc = ensure_side_stream(h, 2)) return rc;
     LF_HIP(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -964,11 +981,27 @@ static int record_pipeline(lf_mkd *h, uint32_t width, uint32_t height, uint32_t 
                          fork ? h->side_events[0] : nullptr, fork ? h->side_events[1] : nullptr, [&] {
                              launch_build_coarse_stack(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse,
                                                        h->coarse_stride, h->layer_stride, h->d_tmp_a, h->n_layers,
-                                                       h->pd.levels >= 2 ? 1 : 0, int(width), int(height), 1, s);
-                         }, d_image_u8);
+                                                       h->pd.levels >= 2 ? 1 : 0, int(width), int(height), 1, s, bands);
+                         }, d_image_u8, bands);
     launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride,
                           h->n_layers, int(width), int(height), 1, kBorder, kSkipLayers, kContrastThreshold, h->d_slots,
-                          h->d_cube_counts, h->d_cube_sums, h->d_det_extrema, nullptr, nullptr, h->max_extrema, cnt + 0, s);
+                          h->d_cube_counts, h->d_cube_sums, h->d_det_extrema, nullptr, nullptr, h->max_extrema, cnt + 0, s, bands);
+    if (head_only) {
+        hipGraph_t g0 = nullptr;
+        hipError_t e0 = hipStreamEndCapture(s, &g0);
+        if (e0 != hipSuccess || !g0) {
+            h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e0);
+            return LF_MKD_ERR_HIP;
+        }
+        hipError_t e1 = hipGraphInstantiate(exec_out, g0, nullptr, nullptr, 0);
+        if (e1 != hipSuccess) {
+            (void)hipGraphDestroy(g0);
+            h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e1);
+            return LF_MKD_ERR_HIP;
+        }
+        *graph_out = g0;
+        return LF_MKD_OK;
+    }
     const float *d_sel = h->d_det_extrema;
     const unsigned long long *n_sel = cnt + 0;
     if (top_n) {
@@ -1066,12 +1099,16 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
             if (!e) LF_HIP(h, hipEventCreate(&e));
         LF_HIP(h, hipEventRecord(h->det_ev[0], s));
     }
-    if (u8) LF_HIP(h, hipMemcpyAsync(h->d_image_u8, image_u8, size_t(width) * height, hipMemcpyHostToDevice, s));
-    else LF_HIP(h, hipMemcpyAsync(h->d_image, image, size_t(width) * height * 4, hipMemcpyHostToDevice, s));
-    if (timed) LF_HIP(h, hipEventRecord(h->det_ev[1], s));
-    if (stepwise)
+    auto upload_whole = [&]() -> int {
+        if (u8) LF_HIP(h, hipMemcpyAsync(h->d_image_u8, image_u8, size_t(width) * height, hipMemcpyHostToDevice, s));
+        else LF_HIP(h, hipMemcpyAsync(h->d_image, image, size_t(width) * height * 4, hipMemcpyHostToDevice, s));
+        return LF_MKD_OK;
+    };
+    if (stepwise) {
+        if (int rc = upload_whole()) return rc;
         return detect_stepwise(h, u8, width, height, top_n, min_size, keypoints, descriptors, max_out, n_out, dropped_blobs,
                                dropped_features);
+    }
     describe_pyramid(width, height, h->pd);
     uint32_t ms_bits;
     std::memcpy(&ms_bits, &min_size, 4);
@@ -1092,15 +1129,70 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
         lf_mkd::DetectPlan p;
         p.w = width; p.h = height; p.top_n = top_n; p.min_size_bits = ms_bits; p.max_out = max_out; p.u8 = u8;
         p.pd = h->pd;
-        // (the upload queued above is outside the capture: the capture records, it does not run anything)
+        // Frames of a megapixel and more go over PCIe in two pieces, and the pipeline's front runs on the first piece's rows
+        // while the second is on its way (RowBands).  Where to cut: the first piece's share of the front (~0.6 of the
+        // pipeline) should take as long as the second piece's upload -- an 8-bit frame uploads in about the time the front
+        // takes (cut in the middle), an f32 frame in four times that (cut at three quarters).  LF_MKD_DETECT_BANDS=0: one piece.
+        // Worth it from about 12 MB of upload (measured on the reference's houses.jpg sweep: an 8-bit frame of 7 MP gains
+        // nothing, an f32 frame of 3 MP gains 6 %, the 12.6 MP frame 8 % either way; a second copy costs ~25 us by itself).  A deep
+        // a-trous stack (n_scales 5: dilation 64, tiles of 768 rows) needs a later cut before its last layer gets any rows.
+        RowBands bands{};
+        const char *env_b = getenv("LF_MKD_DETECT_BANDS"), *env_f = getenv("LF_MKD_BAND_SPLIT");
+        const bool want_bands = env_f || (uint64_t(width) * height * (u8 ? 1 : 4) >= 12000000ull && !(env_b && env_b[0] == '0'));
+        uint32_t cut = 0;
+        bool banded = false;
+        for (double frac = env_f ? atof(env_f) : (u8 ? 0.5 : 0.75); want_bands && !banded && h->pd.levels >= 2 && frac < 0.96;
+             frac += 0.1) {
+            cut = uint32_t(double(height) * std::min(std::max(frac, 0.05), 0.95)) / 4 * 4;
+            banded = plan_row_bands(int(cut), int(width), int(height), h->n_layers, kBorder, bands) &&
+                     (env_f || bands.scan_tile_rows * 8 * 4 >= int(height));      // the head gets a quarter of the frame at least
+            if (env_f) break;
+        }
+        if (banded) {
+            if (!h->copy_stream) {
+                LF_HIP(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+                for (auto &e : h->copy_ev) LF_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+            bands.part = 0;
+            if (int rc = record_pipeline(h, width, height, top_n, min_size, max_out, u8 ? nullptr : h->d_image,
+                                         u8 ? h->d_image_u8 : nullptr, reinterpret_cast<lf_mkd_keypoint *>(h->d_kps_out),
+                                         h->d_det_desc, h->d_det_counts, h->h_det_counts, h->h_res_kps, &p.head_graph, &p.head,
+                                         &bands))
+                return rc;
+            p.band_rows = cut;
+            bands.part = 1;
+        }
         if (int rc = record_pipeline(h, width, height, top_n, min_size, max_out, u8 ? nullptr : h->d_image,
                                      u8 ? h->d_image_u8 : nullptr, reinterpret_cast<lf_mkd_keypoint *>(h->d_kps_out),
-                                     h->d_det_desc, h->d_det_counts, h->h_det_counts, h->h_res_kps, &p.graph, &p.exec))
+                                     h->d_det_desc, h->d_det_counts, h->h_det_counts, h->h_res_kps, &p.graph, &p.exec,
+                                     banded ? &bands : nullptr)) {
+            if (p.head) (void)hipGraphExecDestroy(p.head);
+            if (p.head_graph) (void)hipGraphDestroy(p.head_graph);
             return rc;
+        }
         h->plans.push_back(p);
         plan = &h->plans.back();
     }
     plan->stamp = ++h->plan_clock;
+    if (!plan->head) {
+        if (int rc = upload_whole()) return rc;
+        if (timed) LF_HIP(h, hipEventRecord(h->det_ev[1], s));
+    } else {
+        // piece 1 (the call has waited for the device at its previous return: nothing still reads the staging frame), the
+        // head on its rows; piece 2 beside it; then the rest.  A copy from pageable memory returns when its bytes are on
+        // their way, so the host is in the second copy while the device runs the head.
+        const size_t bpp = u8 ? 1 : 4, row = size_t(width) * bpp, cut = plan->band_rows;
+        const unsigned char *src = u8 ? image_u8 : reinterpret_cast<const unsigned char *>(image);
+        unsigned char *dst = u8 ? h->d_image_u8 : reinterpret_cast<unsigned char *>(h->d_image);
+        LF_HIP(h, hipMemcpyAsync(dst, src, row * cut, hipMemcpyHostToDevice, h->copy_stream));
+        LF_HIP(h, hipEventRecord(h->copy_ev[0], h->copy_stream));
+        LF_HIP(h, hipStreamWaitEvent(s, h->copy_ev[0], 0));
+        LF_HIP(h, hipGraphLaunch(plan->head, s));
+        LF_HIP(h, hipMemcpyAsync(dst + row * cut, src + row * cut, row * (height - cut), hipMemcpyHostToDevice, h->copy_stream));
+        LF_HIP(h, hipEventRecord(h->copy_ev[1], h->copy_stream));
+        LF_HIP(h, hipStreamWaitEvent(s, h->copy_ev[1], 0));
+        if (timed) LF_HIP(h, hipEventRecord(h->det_ev[1], s));     // (on s behind the wait: the moment the whole frame is there)
+    }
     LF_HIP(h, hipGraphLaunch(plan->exec, s));
     if (timed) LF_HIP(h, hipEventRecord(h->det_ev[2], s));
     h->n_frames = 1;

@@ -3,6 +3,8 @@
 //   scan_extrema      swt_sub.glsl:17-30 + scan_extrema.glsl:36-241; cubes_* = its ordered compaction
 //   topk_*            the host blob filter of detect_top_n (vulkan/mod.rs:1753-1786) on the device; segments_* batch it
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -31,7 +33,7 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
                                                     int skip_layers, float contrast_threshold, int gx, int gy, int gz,
                                                     int aligned,
                                                     float *__restrict__ slots /*[frames*cubes][8][4]*/,
-                                                    unsigned *__restrict__ counts /*[frames*cubes]*/) {
+                                                    unsigned *__restrict__ counts /*[frames*cubes]*/, int by_base) {
 #pragma clang fp contract(off)
     // a row of the LDS tile: the TX + 2 texels the cubes reach, inside a window of TX + 8 that starts on a multiple of four
     // texels when the layers can be read 16 bytes at a time (`aligned`: widths and strides multiples of 4)
@@ -39,7 +41,8 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
     __shared__ __attribute__((aligned(16))) float s_dog[kScanMaxFine * kScanPlane];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned f = blockIdx.z;
-    const int tx0 = blockIdx.x * kScanTX + border, ty0 = blockIdx.y * kScanTY + border;   // first candidate texel
+    const int by = (int)blockIdx.y + by_base;   // (by_base: a launch over part of the frame's tile rows, see RowBands)
+    const int tx0 = blockIdx.x * kScanTX + border, ty0 = by * kScanTY + border;   // first candidate texel
     const float *l0 = layer0 + f * layer0_stride, *cs = coarse + f * coarse_stride;
     const int seg0 = aligned ? (tx0 - 1) & ~3 : tx0 - 1;   // frame column of the window's first texel
     const int shift = tx0 - 1 - seg0;
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
     constexpr int kCX = kScanTX / 4, kCY = kScanTY / 4;   // cubes of a tile per cube layer
     for (int q = wave; q < kCX * kCY * gz; q += 4) {   // cube q of this tile: (cube layer, cube row, cube column)
         const int qz = q / (kCX * kCY), qy = (q / kCX) % kCY, qx = q % kCX;
-        const int cx = blockIdx.x * kCX + qx, cy = blockIdx.y * kCY + qy;
+        const int cx = blockIdx.x * kCX + qx, cy = by * kCY + qy;
         if (cx >= gx || cy >= gy) continue;      // uniform per wave
         const int x = tx0 + qx * 4 + lx, y = ty0 + qy * 4 + ly, z = qz * 4 + lz + 1 + skip_layers;
         const bool inside = !(x < b1 || x >= w - b1 || y < b1 || y >= h - b1 || z <= 0 || z >= n_fine - 1);
@@ -763,7 +766,7 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, int layer0_p
                            long layer_stride, int n_layers, int w, int h, int frames, int border, int skip_layers,
                            float contrast_threshold, float *slots, unsigned *counts, unsigned *sums, float *extrema,
                            unsigned *frame_of, unsigned *frame_start, unsigned long long max_out,
-                           unsigned long long *totals, hipStream_t stream) {
+                           unsigned long long *totals, hipStream_t stream, const RowBands *bands) {
     int gx, gy, gz;
     scan_grid(w, h, n_layers - 1, border, skip_layers, gx, gy, gz);
     const long ncubes = (long)gx * gy * gz, n = ncubes * frames;
@@ -773,14 +776,23 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, int layer0_p
         const int aligned = w % 4 == 0 && layer0_pitch % 4 == 0 && layer0_stride % 4 == 0 && coarse_stride % 4 == 0 &&
                             layer_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(layer0) & 15) == 0 &&
                             (reinterpret_cast<uintptr_t>(coarse) & 15) == 0;
+        // (bands: part 0 scans the tile rows the frame's first band allows and stops; part 1 scans the rest and compacts)
+        const int part = bands ? bands->part : -1;
+        const int all_rows = (gy + kScanTY / 4 - 1) / (kScanTY / 4);
+        const int by_first = part == 1 ? std::min(bands->scan_tile_rows, all_rows) : 0;
+        const int by_rows = (part == 0 ? std::min(bands->scan_tile_rows, all_rows) : all_rows) - by_first;
         auto scan = [&](auto kernel, int tx) {
-            hipLaunchKernelGGL(kernel, dim3((gx + tx / 4 - 1) / (tx / 4), (gy + kScanTY / 4 - 1) / (kScanTY / 4), frames),
-                               dim3(256), 0, stream, layer0, layer0_stride, layer0_pitch, coarse, coarse_stride, layer_stride,
-                               n_layers - 1, w, h, border, skip_layers, contrast_threshold, gx, gy, gz, aligned, slots, counts);
+            if (by_rows > 0)
+                hipLaunchKernelGGL(kernel, dim3((gx + tx / 4 - 1) / (tx / 4), by_rows, frames), dim3(256), 0, stream, layer0,
+                                   layer0_stride, layer0_pitch, coarse, coarse_stride, layer_stride, n_layers - 1, w, h, border,
+                                   skip_layers, contrast_threshold, gx, gy, gz, aligned, slots, counts, by_first);
         };
         if ((long)frames * w * h >= 2000000L) scan(scan_extrema<64>, 64);
         else scan(scan_extrema<32>, 32);
+        if (part == 0) return;
         hipLaunchKernelGGL(cubes_block_sums, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts, n, sums);
+    } else if (bands && bands->part == 0) {
+        return;
     }
     if (ncubes > 0)
         hipLaunchKernelGGL(cubes_scatter, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts,

@@ -33,6 +33,18 @@ struct PyramidDesc {
     long offset[kMaxPyrLevels];  // in floats, of texel (0, 0)
 };
 
+// Row bands (lf_mkd_detect's upload / compute overlap, round 5): the frame reaches the device in two pieces, and the row-tiled
+// kernels of the pipeline's front -- level 0, the a-trous layers, the extremum scan -- run once for the rows the first piece
+// allows (part 0, while the second piece is still on its way over PCIe) and once for the rest (part 1).  A stage's split is a
+// tile boundary of its kernel, chosen so that part 0 reads nothing part 1's rows produce: plan_row_bands.
+struct RowBands {
+    int part;             // 0: the rows before each split; 1: the rows from each split on (and everything that is not row-tiled)
+    int level0_rows;      // pyramid level 0 = a-trous layer 0: rows [0, level0_rows) are part 0 (a multiple of 12)
+    int layer_rows[8];    // a-trous layer l + 1 (dilation 2^l): rows [0, layer_rows[l]) are part 0 (a multiple of 12 * 2^l)
+    int scan_tile_rows;   // extremum scan: tile rows (8 candidate rows each) [0, scan_tile_rows) are part 0
+};
+bool plan_row_bands(int raw_rows, int w, int h, int n_layers, int border, RowBands &bands);
+
 // Device copies of HostConsts' device layouts (mkd_consts.hpp).
 struct DeviceConsts {
     short *colmap = nullptr;        // [336]
@@ -68,13 +80,13 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
                           float *tmp_b, const PyramidDesc &pd, int frames, float *layer1, long layer1_stride,
                           hipStream_t stream, hipStream_t rest_stream = nullptr, hipEvent_t fork = nullptr,
                           hipEvent_t join = nullptr, const std::function<void()> &main_next = {},
-                          const unsigned char *image_u8 = nullptr);
+                          const unsigned char *image_u8 = nullptr, const RowBands *bands = nullptr);
 // (image_u8 != nullptr: the frames are 8-bit luma, image_stride BYTES apart, `image` is ignored; a pixel is (float)v / 255.0f)
 
 // a-trous layers 1 .. n_layers-1 over layer0 (= pyramid level 0); tmp holds frames x w x h floats
 void launch_build_coarse_stack(const float *layer0, long layer0_stride, int layer0_pitch, float *coarse, long coarse_stride,
                                long layer_stride, float *tmp, int n_layers, int first_layer, int w, int h, int frames,
-                               hipStream_t stream);
+                               hipStream_t stream, const RowBands *bands = nullptr);
 // extrema [n][4] -> kps [<= max_out][5] ordered by extremum then bin; angles [n][18], counts [n], sums [n/1024+1]
 // are scratch (sums may be null for n <= 8192);
 // totals[0] = written, totals[1] = dropped
@@ -91,7 +103,7 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, int layer0_p
                            long layer_stride, int n_layers, int w, int h, int frames, int border, int skip_layers,
                            float contrast_threshold, float *slots, unsigned *counts, unsigned *sums, float *extrema,
                            unsigned *frame_of, unsigned *frame_start, unsigned long long max_out,
-                           unsigned long long *totals, hipStream_t stream);
+                           unsigned long long *totals, hipStream_t stream, const RowBands *bands = nullptr);
 // per frame: blobs with size >= min_size, the n_keep best by contrast, index order; out [n_frames][n_keep][4]
 // (the number of extrema is read from n_in on the device, or taken from n_host when n_in is null)
 void launch_topk_filter(const float *extrema, const unsigned *seg_start, const unsigned long long *n_in,

@@ -106,12 +106,12 @@ __device__ __forceinline__ void store_with_apron(float *__restrict__ lvl0, int p
 template <typename PX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 6))) void pyr_sep3_fused(const PX *__restrict__ in, float *__restrict__ out, long in_stride,
                                                       long out_stride, int w, int h, int opitch, int oapron, float w0, float w1,
-                                                      float off) {
+                                                      float off, int ty_base) {
 #pragma clang fp contract(off)
     __shared__ float s_h[16][256];   // kSwtRows + 4 rows
     in += blockIdx.z * in_stride;
     out += blockIdx.z * out_stride;
-    const int y0 = (int)blockIdx.y * 12;
+    const int y0 = ((int)blockIdx.y + ty_base) * 12;   // (ty_base: a launch over part of the frame's rows, see RowBands)
     const int xr = (int)blockIdx.x * 256 + (int)threadIdx.x, x = xr < w ? xr : w - 1;
 #pragma unroll 4
     for (int m = 0; m < 16; ++m) s_h[m][threadIdx.x] = sep3_pixel<false, PX>(in, w, h, w, x, mirror_idx(y0 - 2 + m, h), w0, w1, off, 0);
@@ -146,14 +146,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 6))) voi
 template <typename PX>
 __global__ __launch_bounds__(256) void pyr_sep3_staged(const PX *__restrict__ in, float *__restrict__ out, long in_stride,
                                                        long out_stride, int w, int h, int opitch, int oapron, float w0, float w1,
-                                                       float off) {
+                                                       float off, int ty_base) {
 #pragma clang fp contract(off)
     constexpr int kSlots = 16, kH4 = 4, kOutCols = 256 - 2 * kH4;
     __shared__ __attribute__((aligned(16))) float s_raw[kSlots][256];
     const TileId tile = xcd_tile();
     in += tile.z * in_stride;
     out += tile.z * out_stride;
-    const int y0 = (int)tile.y * 12, xs = (int)tile.x * kOutCols;
+    const int y0 = ((int)tile.y + ty_base) * 12, xs = (int)tile.x * kOutCols;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = xs - kH4 + 4 * lane;
     const bool whole = c0 >= 0 && c0 + 3 < w;
@@ -219,14 +219,15 @@ __global__ __launch_bounds__(256) void pyr_sep3_staged(const PX *__restrict__ in
 constexpr int kSwtRows = 12, kSwtCols = 256;
 
 __global__ __launch_bounds__(256) void pyr_swt_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
-                                                     long out_stride, int w, int h, int ipitch, int d, int blocks_per_class) {
+                                                     long out_stride, int w, int h, int ipitch, int d, int blocks_per_class,
+                                                     int kb_base) {
 #pragma clang fp contract(off)
     __shared__ float s_h[kSwtRows + 4][kSwtCols];
     const float k0 = 6.f / 16.f, k1 = 4.f / 16.f, k2 = 1.f / 16.f;
     in += blockIdx.z * in_stride;
     out += blockIdx.z * out_stride;
     const int r = blockIdx.y / blocks_per_class;                    // residue class of the rows
-    const int kb = (blockIdx.y - r * blocks_per_class) * kSwtRows;  // first lattice index of this workgroup
+    const int kb = (blockIdx.y - r * blocks_per_class + kb_base) * kSwtRows;  // first lattice index of this workgroup
     const int xs = (int)blockIdx.x * kSwtCols;   // signed: xs - 2 d must be able to go negative
     const int xr = xs + (int)threadIdx.x, x = xr < w ? xr : w - 1;
     const bool interior = xs - 2 * d >= 0 && xs + kSwtCols - 1 + 2 * d < w;
@@ -275,7 +276,7 @@ struct SwtBlit { float *out; long stride; int pitch, apron; };
 template <int H4>
 __global__ __launch_bounds__(256) void pyr_swt_staged(const float *__restrict__ in, float *__restrict__ out, long in_stride,
                                                       long out_stride, int w, int h, int ipitch, int d, int blocks_per_class,
-                                                      SwtBlit blit) {
+                                                      SwtBlit blit, int kb_base) {
 #pragma clang fp contract(off)
     constexpr int kSlots = kSwtRows + 4, kOutCols = kSwtCols - 2 * H4;
     __shared__ __attribute__((aligned(16))) float s_raw[kSlots][kSwtCols];
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void pyr_swt_staged(const float *__restrict__ 
     in += tile.z * in_stride;
     out += tile.z * out_stride;
     const int r = tile.y / blocks_per_class;
-    const int kb = (tile.y - r * blocks_per_class) * kSwtRows;
+    const int kb = (tile.y - r * blocks_per_class + kb_base) * kSwtRows;
     const int xs = (int)tile.x * kOutCols;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // this lane's four texels of a segment: columns c0 .. c0 + 3 (virtual: mirrored where they leave the frame)
@@ -752,11 +753,17 @@ void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc 
 // hold frames x w x h floats each.
 // one a-trous layer (both passes) for `frames` frames
 // returns whether the launch also wrote `blit` (pyramid level 1, from the dilation-1 layer)
+// (row_lo, row_hi: the launch covers output rows [row_lo, row_hi) only -- multiples of 12 d, or the frame's height for row_hi:
+//  whole tiles of every residue class; the default is the whole frame)
 static bool launch_swt(const float *in, long in_stride, int in_pitch, float *out, long out_stride, int w, int h, int d,
-                       int frames, hipStream_t stream, SwtBlit blit = SwtBlit{nullptr, 0, 0, 0}) {
+                       int frames, hipStream_t stream, SwtBlit blit = SwtBlit{nullptr, 0, 0, 0}, int row_lo = 0, int row_hi = -1) {
     const int classes = d < h ? d : h;                                   // residue classes that hold rows
     const int lattice = (h + d - 1) / d;                                 // rows of the longest class
-    const int per_class = (lattice + kSwtRows - 1) / kSwtRows;
+    const int all_tiles = (lattice + kSwtRows - 1) / kSwtRows;           // tiles of a class over the whole frame
+    const int kb_base = row_lo / (kSwtRows * d);
+    const int kb_end = row_hi < 0 || row_hi >= h ? all_tiles : row_hi / (kSwtRows * d);
+    const int per_class = kb_end - kb_base;
+    if (per_class <= 0) return false;
     // the staged form where its 16-byte requests are aligned and its halo fits
     // (d = 32 leaves 128 of the segment's 256 columns to write and is still ahead: 17 against 21 us on a 4K frame)
     if (d <= 32 && w % 4 == 0 && in_pitch % 4 == 0 && in_stride % 4 == 0 &&
@@ -766,7 +773,7 @@ static bool launch_swt(const float *in, long in_stride, int in_pitch, float *out
         auto go = [&](auto kernel, int h4) {
             const int oc = kSwtCols - 2 * h4;
             hipLaunchKernelGGL(kernel, dim3((w + oc - 1) / oc, classes * per_class, frames), dim3(256), 0, stream, in, out,
-                               in_stride, out_stride, w, h, in_pitch, d, per_class, blit);
+                               in_stride, out_stride, w, h, in_pitch, d, per_class, blit, kb_base);
         };
         if (d <= 2) go(pyr_swt_staged<4>, 4);
         else if (d == 4) go(pyr_swt_staged<8>, 8);
@@ -776,7 +783,7 @@ static bool launch_swt(const float *in, long in_stride, int in_pitch, float *out
         return with_blit;
     }
     hipLaunchKernelGGL(pyr_swt_fused, dim3((w + kSwtCols - 1) / kSwtCols, classes * per_class, frames), dim3(256), 0, stream,
-                       in, out, in_stride, out_stride, w, h, in_pitch, d, per_class);
+                       in, out, in_stride, out_stride, w, h, in_pitch, d, per_class, kb_base);
     return false;
 }
 
@@ -795,8 +802,13 @@ static void launch_apron_fill(float *pyr, long pyr_stride, const PyramidDesc &pd
 void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,
                           float *tmp_b, const PyramidDesc &pd, int frames, float *layer1, long layer1_stride,
                           hipStream_t stream, hipStream_t rest_stream, hipEvent_t fork, hipEvent_t join,
-                          const std::function<void()> &main_next, const unsigned char *image_u8) {
+                          const std::function<void()> &main_next, const unsigned char *image_u8, const RowBands *bands) {
     const int w = pd.w[0], h = pd.h[0];
+    // (bands: this launch sequence is one of the two parts of a banded frame -- part 0 stops after the rows the first band
+    //  allows and builds nothing below level 1; part 1 does the remaining rows and everything else)
+    const int part = bands ? bands->part : -1;
+    const int l0_first = part == 1 ? bands->level0_rows / 12 : 0;
+    const int l0_tiles = (part == 0 ? bands->level0_rows / 12 : (h + 11) / 12) - l0_first;
     const long ts = (long)w * h;
     const dim3 blk(32, 8);
     auto grid = [&](int gw, int gh) { return dim3((gw + 31) / 32, (gh + 7) / 8, frames); };
@@ -814,23 +826,24 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     auto apron_of = [&](int l) { return l < fill_from ? pd.apron[l] : 0; };
     // level 0: sigma-0.6 blur, H then V (tasks_detect.rs:150-161, mod.rs:1043-1067)
     // (image_u8 != nullptr: the frames are 8-bit, image_stride bytes apart; converted as they are read: px_f32)
-    if (image_u8) {
+    if (l0_tiles <= 0) {
+    } else if (image_u8) {
         if (w % 4 == 0 && image_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(image_u8) & 3) == 0)
-            hipLaunchKernelGGL(pyr_sep3_staged<unsigned char>, dim3((w + 247) / 248, (h + 11) / 12, frames), dim3(256), 0, stream,
+            hipLaunchKernelGGL(pyr_sep3_staged<unsigned char>, dim3((w + 247) / 248, l0_tiles, frames), dim3(256), 0, stream,
                                image_u8, pyr + pd.offset[0], image_stride, pyr_stride, w, h, pd.pitch[0], apron_of(0),
-                               0.66381836f, 0.16809084f, 1.015267163f);
+                               0.66381836f, 0.16809084f, 1.015267163f, l0_first);
         else
-            hipLaunchKernelGGL(pyr_sep3_fused<unsigned char>, dim3((w + 255) / 256, (h + 11) / 12, frames), dim3(256), 0, stream,
+            hipLaunchKernelGGL(pyr_sep3_fused<unsigned char>, dim3((w + 255) / 256, l0_tiles, frames), dim3(256), 0, stream,
                                image_u8, pyr + pd.offset[0], image_stride, pyr_stride, w, h, pd.pitch[0], apron_of(0),
-                               0.66381836f, 0.16809084f, 1.015267163f);
+                               0.66381836f, 0.16809084f, 1.015267163f, l0_first);
     } else if (w % 4 == 0 && image_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(image) & 15) == 0)
-        hipLaunchKernelGGL(pyr_sep3_staged<float>, dim3((w + 247) / 248, (h + 11) / 12, frames), dim3(256), 0, stream, image,
+        hipLaunchKernelGGL(pyr_sep3_staged<float>, dim3((w + 247) / 248, l0_tiles, frames), dim3(256), 0, stream, image,
                            pyr + pd.offset[0], image_stride, pyr_stride, w, h, pd.pitch[0], apron_of(0), 0.66381836f,
-                           0.16809084f, 1.015267163f);
+                           0.16809084f, 1.015267163f, l0_first);
     else
-        hipLaunchKernelGGL(pyr_sep3_fused<float>, dim3((w + 255) / 256, (h + 11) / 12, frames), dim3(256), 0, stream, image,
+        hipLaunchKernelGGL(pyr_sep3_fused<float>, dim3((w + 255) / 256, l0_tiles, frames), dim3(256), 0, stream, image,
                            pyr + pd.offset[0], image_stride, pyr_stride, w, h, pd.pitch[0], apron_of(0), 0.66381836f,
-                           0.16809084f, 1.015267163f);
+                           0.16809084f, 1.015267163f, l0_first);
     if (pd.levels < 2) {
         launch_apron_fill(pyr, pyr_stride, pd, fill_from, fill_end, frames, stream);
         if (main_next) main_next();
@@ -844,7 +857,12 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     bool level1_done = false;
     if (need_layer1)
         level1_done = launch_swt(pyr + pd.offset[0], pyr_stride, pd.pitch[0], l1, l1s, w, h, 1, frames, stream,
-                                 SwtBlit{pyr + pd.offset[1], pyr_stride, pd.pitch[1], apron_of(1)});
+                                 SwtBlit{pyr + pd.offset[1], pyr_stride, pd.pitch[1], apron_of(1)},
+                                 part == 1 ? bands->layer_rows[0] : 0, part == 0 ? bands->layer_rows[0] : -1);
+    if (part == 0) {          // the first band's share ends with the a-trous layers its rows allow (queued by the caller)
+        if (main_next) main_next();
+        return;
+    }
     // Levels >= 1 are only read by the patch sampler: a caller whose next steps need level 0 and layer 1 alone (the
     // detector) can have them built on `rest_stream` beside those steps and wait for `join` before it samples.
     // `main_next` queues the caller's next steps on `stream` BEFORE the branch is queued: of two launches that wait for the
@@ -906,14 +924,33 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
 // with taps 2^l apart.  Layer 0 is pyramid level 0 (the sigma-0.6 blur), so it is read in place.
 void launch_build_coarse_stack(const float *layer0, long layer0_stride, int layer0_pitch, float *coarse, long coarse_stride,
                                long layer_stride, float *tmp, int n_layers, int first_layer, int w, int h, int frames,
-                               hipStream_t stream) {
+                               hipStream_t stream, const RowBands *bands) {
     (void)tmp;
+    const int part = bands ? bands->part : -1;
     for (int l = first_layer; l + 1 < n_layers; ++l) {   // first_layer = 1: layer 1 came with the pyramid
         const float *in = l == 0 ? layer0 : coarse + (long)(l - 1) * layer_stride;
         const long in_stride = l == 0 ? layer0_stride : coarse_stride;
         launch_swt(in, in_stride, l == 0 ? layer0_pitch : w, coarse + (long)l * layer_stride, coarse_stride, w, h, 1 << l, frames,
-                   stream);
+                   stream, SwtBlit{nullptr, 0, 0, 0}, part == 1 ? bands->layer_rows[l] : 0, part == 0 ? bands->layer_rows[l] : -1);
     }
+}
+
+// Which rows each stage of the pipeline's front can produce from the frame's first `raw_rows` rows (see RowBands): level 0
+// needs two raw rows below an output row, a-trous layer l + 1 (dilation d = 2^l) needs 2 d rows of layer l, the extremum scan one
+// row of every layer below a tile's candidates; every split falls on a tile boundary of its kernel.  False: not worth it
+// (a stage would get no rows, or the layers are not the staged kernels' shapes).
+bool plan_row_bands(int raw_rows, int w, int h, int n_layers, int border, RowBands &b) {
+    if (w % 4 || h % 2 || n_layers - 1 > 8 || raw_rows >= h) return false;
+    b.part = 0;
+    b.level0_rows = (raw_rows - 2) / 12 * 12;
+    int prev = b.level0_rows;
+    for (int l = 0; l + 1 < n_layers; ++l) {
+        const int d = 1 << l, g = kSwtRows * d;
+        b.layer_rows[l] = prev - 2 * d > 0 ? (prev - 2 * d) / g * g : 0;
+        prev = b.layer_rows[l];
+    }
+    b.scan_tile_rows = prev - border - 1 > 0 ? (prev - border - 1) / 8 : 0;     // tile rows of 8 candidates from row `border`
+    return b.level0_rows > 0 && prev > 0 && b.scan_tile_rows > 0;
 }
 
 }  // namespace lfmkd

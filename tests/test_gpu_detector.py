@@ -271,6 +271,42 @@ def test_detect_recorded_stepwise_and_u8_return_the_same_bits(lfp, torch, oracle
     assert np.array_equal(d_d[:n].cpu().numpy(), d2)
 
 
+@pytest.mark.parametrize("w,hgt,n_scales", [(1280, 1024, 4), (2048, 1100, 3), (1024, 1536, 5)])
+def test_banded_upload_returns_the_unbanded_bits(lfp, oracle, monkeypatch, w, hgt, n_scales):
+    """Frames of a megapixel and more reach the device in two pieces, and the pipeline's front (level 0, the a-trous layers,
+    the extremum scan) runs on the rows the first piece allows while the second is still on its way (RowBands).  Wherever the
+    cut falls, whatever the pixel type, the call must return what the one-piece form (LF_MKD_DETECT_BANDS=0) and the
+    stage-by-stage form return: every extremum (top_n = 0, so that a row lost at a band boundary would show), keypoints,
+    descriptors, counters."""
+    u8, f32 = _u8_frame(w, hgt, 23, 2500)
+    kw = dict(max_features=20000, max_image_width=w, max_image_height=hgt, max_blobs=16384, n_scales=n_scales)
+    ref = lfp.MkdHandle(flags=lfp.FLAG_DETECT_STEPWISE, **kw)
+    want = ref.detect(f32, 0, 0.0, 20000)
+    assert len(want[0]) > 1500 and want[2] == 0
+    monkeypatch.setenv("LF_MKD_DETECT_BANDS", "0")
+    one = lfp.MkdHandle(**kw)
+    for img in (f32, u8):
+        got = one.detect(img, 0, 0.0, 20000)
+        assert got[2:] == want[2:] and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    monkeypatch.delenv("LF_MKD_DETECT_BANDS")
+    for frac in (None, "0.12", "0.33", "0.5", "0.77", "0.94"):
+        if frac is None:
+            monkeypatch.delenv("LF_MKD_BAND_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("LF_MKD_BAND_SPLIT", frac)
+        h = lfp.MkdHandle(**kw)                                  # (the cut is fixed when a request is first recorded)
+        for img in (f32, u8, f32):
+            for top_n in (0, 700):
+                got = h.detect(img, top_n, 0.0, 20000)
+                exp = want if top_n == 0 else ref.detect(f32, top_n, 0.0, 20000)
+                assert got[2:] == exp[2:], (frac, img.dtype, top_n)
+                assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]), (frac, img.dtype, top_n)
+    # and what the call returns is the oracle's detect of the frame
+    want_k, _ = oracle.detect(f32, n_scales=n_scales, max_blobs=16384)
+    assert want[0].shape == want_k.shape
+    assert_same_extrema(want[0][:, [0, 1, 2, 4]], want_k[:, [0, 1, 2, 4]], "banded")
+
+
 def test_detect_u8_errors_and_empty_frames(lfp):
     """the 8-bit entry points report what the f32 ones report; a flat frame yields no keypoints through the recorded pipeline"""
     h = lfp.MkdHandle(max_features=256, max_image_width=128, max_image_height=96)
