@@ -38,6 +38,11 @@ constexpr bool kNoFrontEnd = true;
 #else
 constexpr bool kNoFrontEnd = false;
 #endif
+#ifdef LF_ABLATE_MUL_FIRST_TAP   // the horizontal blur's first tap as a plain product (round 4's form: a blurred value can be -0.0)
+constexpr bool kMulFirstTap = true;
+#else
+constexpr bool kMulFirstTap = false;
+#endif
 #ifdef LF_ABLATE_SYNC
 constexpr bool kNoRowSync = true;
 #else

@@ -432,7 +432,11 @@ __device__ __forceinline__ void blur_row_impl(const unsigned char *ring_lane, Sl
     for (int x = 0; x < 8; ++x) ext[2 + x] = vb[x];
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
-        float s = kB0 * ext[x];
+        // (the first tap as an fma onto +0.0: the same bits as the product for every non-zero result, and +0.0 where the
+        //  product would be -0.0 -- a blurred value is then never -0.0, so neither is gx = left - right, and the sign bit
+        //  gradient_direction takes from gx is never the sign of a zero: the shader's (cos, sin) = (1, 0) at gx == -0.0,
+        //  atan2.glsl:29-45, at no instruction's cost)
+        float s = ablate::kMulFirstTap ? kB0 * ext[x] : fmaf(kB0, ext[x], 0.0f);
         s = fmaf(kB1, ext[x + 1], s);
         s = fmaf(kB2, ext[x + 2], s);
         s = fmaf(kB1, ext[x + 3], s);

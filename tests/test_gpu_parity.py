@@ -483,6 +483,42 @@ def test_extreme_patch_values(lfp, oracle):
         assert rel_l2(d[:6], ref[:6]).max() < GATE, (pool, rel_l2(d, ref))
 
 
+def test_negative_zero_pixels_take_the_shaders_angle(lfp, oracle):
+    """gx = left - right is -0.0 exactly when the blurred value on the left is -0.0 and the one on the right +0.0: patches that
+    hold negative zeros (or negative values that underflow in the blur).  The shader's atan2 treats x = -0.0 as x = 0: angle 0,
+    no pi branch (atan2.glsl:29-45; `sign(-0.0)` is not -1).  The kernel takes cos's sign from gx's sign bit, so it must never
+    see the sign of a zero: its blur ends in +0.0 wherever the value is zero (round 5; the advisor's round-4 finding).  Patches:
+    a block of -0.0 beside a block of +0.0 above a textured half, the same transposed, negative values small enough to
+    underflow, and all of them scattered into random patches."""
+    from oracle import BLUR_CONTRACT, ATAN_SHADER
+    rng = np.random.default_rng(41)
+    tex = rng.random((32, 32)).astype(np.float32)
+    a = tex.copy()
+    a[:20, :16] = -0.0
+    a[:20, 16:] = 0.0
+    b = np.ascontiguousarray(a.T)
+    c = tex.copy()
+    c[:18, :14] = -1e-44          # negative denormals: the blur's products round to -0.0
+    c[:18, 14:] = 0.0
+    d = rng.random((32, 32)).astype(np.float32)
+    d[4:16, 3:12] = -0.0
+    d[4:16, 12:24] = 0.0
+    e = np.where(rng.random((32, 32)) < 0.5, np.float32(-0.0), np.float32(0.0)).astype(np.float32)
+    e[20:, :] = tex[20:, :]
+    p = np.stack([a, b, c, d, e]).astype(np.float32)
+    assert np.signbit(p).any()
+    ref = oracle.describe_patches(p, atan_mode=ATAN_SHADER | BLUR_CONTRACT)
+    for pool in (lfp.POOL_F32, lfp.POOL_F16X3):
+        got = lfp.MkdHandle(max_features=64, pool_mode=pool).describe_patches(p)
+        err = rel_l2(got, ref)
+        print(f"negative-zero patches, pool mode {pool}: relative L2 vs the oracle {err}")
+        assert err.max() < GATE, (pool, err)
+        # the same patches with every -0.0 replaced by +0.0 describe the same (zeros carry no sign into the descriptor)
+        q = np.where(p == 0, np.float32(0.0), p).astype(np.float32)
+        q[2][q[2] < 0] = 0.0
+        assert rel_l2(lfp.MkdHandle(max_features=64, pool_mode=pool).describe_patches(q)[[0, 1, 3, 4]], got[[0, 1, 3, 4]]).max() < 2e-5
+
+
 def _adversarial_keypoints(w, h):
     """Interior keypoints, keypoints on and next to the frame's borders, footprints larger than the frame's levels, sizes
     below level 0, non-finite ones."""
