@@ -76,6 +76,13 @@ struct ImageView {
     std::size_t nrows, ncols;
 };
 
+// The 8-bit luma frame the reference's callers convert from (examples/match_images/src/main.rs:44-60): same results as the
+// f32 frame v / 255, a quarter of the upload (lf_mkd_detect_u8).
+struct ImageViewU8 {
+    const std::uint8_t *data;
+    std::size_t nrows, ncols;
+};
+
 // One candidate blob as the host filter sees it (BlobLocationsView, vulkan/shaders.rs:257-319): refined position,
 // size and contrast of an extremum.
 using Blob = lf_mkd_extremum;
@@ -99,6 +106,22 @@ public:
 
     // detect_top_n (mod.rs:353-361): the n blobs of largest contrast among those with size >= min_size
     FeaturesResult detect_top_n(const ImageView &img, std::uint32_t n, float min_size) { return run(img, n, min_size); }
+    // the same from the 8-bit frame (not in the reference: its callers convert to f32 first)
+    FeaturesResult detect_top_n(const ImageViewU8 &img, std::uint32_t n, float min_size) {
+        if (!img.data || img.nrows == 0 || img.ncols == 0)
+            throw LocalFeaturesError(LocalFeaturesError::Kind::InvalidParameters, "empty image");
+        FeaturesResult r;
+        r.keypoints.resize(fixed_.max_features);
+        r.descriptors.resize(std::size_t(fixed_.max_features) * DESCRIPTOR_LEN);
+        std::uint64_t m = 0, dropped_blobs = 0, dropped_features = 0;
+        check(lf_mkd_detect_u8(h_, img.data, std::uint32_t(img.ncols), std::uint32_t(img.nrows), n, min_size, r.keypoints.data(),
+                               r.descriptors.data(), fixed_.max_features, &m, &dropped_blobs, &dropped_features));
+        r.keypoints.resize(m);
+        r.descriptors.resize(m * DESCRIPTOR_LEN);
+        r.dropped_blobs = std::uint32_t(dropped_blobs);
+        r.dropped_features = std::uint32_t(dropped_features);
+        return r;
+    }
 
     // detect (mod.rs:363-593) with a caller-supplied blob filter: the detect graph, the filter on the host, the
     // extract graph on the blobs it kept.  A null filter keeps everything (= detect_extract_all).

@@ -3,6 +3,7 @@
 // Writes OUT_PREFIX.{all,top,filt}.{kps,desc} (raw f32) and prints the counts; tests/test_gpu_cpp_api.py compares them
 // with what the Python binding returns for the same image.
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -59,6 +60,20 @@ int main(int argc, char **argv) {
         const auto matches = feats.match_features(top.descriptors, all.descriptors);
         std::printf("all %zu top %zu filt %zu matches %zu dropped %u %u\n", all.keypoints.size(), top.keypoints.size(),
                     filt.keypoints.size(), matches.size(), all.dropped_blobs, all.dropped_features);
+        // the 8-bit frame and the f32 frame made from it (u8 as f32 / 255., examples/webcam/src/main.rs:136) give the same bits
+        std::vector<std::uint8_t> img8(w * h);
+        std::vector<float> img8f(w * h);
+        for (std::size_t i = 0; i < w * h; ++i) {
+            const float v = img[i] < 0.f ? 0.f : (img[i] > 1.f ? 1.f : img[i]);
+            img8[i] = std::uint8_t(v * 255.f + 0.5f);
+            img8f[i] = float(img8[i]) / 255.f;
+        }
+        const lf::FeaturesResult from8 = feats.detect_top_n(lf::ImageViewU8{img8.data(), h, w}, 100, 0.f);
+        const lf::FeaturesResult from32 = feats.detect_top_n(lf::ImageView{img8f.data(), h, w}, 100, 0.f);
+        const bool same8 = from8.keypoints.size() == from32.keypoints.size() && from8.descriptors == from32.descriptors &&
+                           std::memcmp(from8.keypoints.data(), from32.keypoints.data(), from8.keypoints.size() * sizeof(from8.keypoints[0])) == 0;
+        std::printf("u8 %zu keypoints, same as the f32 frame: %s\n", from8.keypoints.size(), same8 ? "yes" : "NO");
+        if (!same8 || from8.keypoints.empty()) return 1;
         // error behaviour: an image larger than max_image_* is an InvalidParameters error, not a crash
         std::vector<float> big((w + 8) * h, 0.5f);
         try {

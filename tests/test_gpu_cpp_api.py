@@ -30,6 +30,7 @@ def test_cpp_api_program(tmp_path):
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
     assert lines[-1].startswith("oversize: InvalidParameters"), lines
+    assert "same as the f32 frame: yes" in lines[1], lines             # detect_top_n(ImageViewU8) == detect_top_n of u8 / 255
     counts = dict(zip(lines[0].split()[0::2], lines[0].split()[1::2]))
 
     def load(tag):

@@ -217,11 +217,23 @@ if kp_stats:
                 f"algorithmic {alg3 / 1e9:.3f} GB = {alg3 / n3:.0f} B per descriptor -> ratio {tot3 / alg3:.1f}.", ""]
         per_call["configs3_128x1080p_8192_keypoints"] = tot3
         if kp3_stats:
-            out += ["| kernel (configs[3] own form) | calls | avg us | total ms |", "|---|---|---|---|"]
+            # per-kernel bytes (counter passes, same correction) over the kernel trace's time: GB/s per kernel, and per CALL
+            # (a kernel launched three times per call -- the decimating one -- is summed)
+            out += ["| kernel (configs[3] own form) | launches per call | us per call | read GB | written GB | GB/s |", "|---|---|---|---|---|---|"]
+            pyr_us = pyr_bytes = 0.0
             for r in sorted((r for r in csv.DictReader(open(kp3_stats)) if "lfmkd" in r["Name"]), key=lambda r: -float(r["TotalDurationNs"])):
                 name = r["Name"].split("(")[0].replace("void ", "").replace("lfmkd::", "")
-                out.append(f"| `{name}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.2f} |")
-            out.append("")
+                us = float(r["TotalDurationNs"]) / 1e3 / calls
+                rb = rd3(name, f3.get(name, 0.0)) / calls * 1024
+                wb = w3.get(name, 0.0) / calls * 1024
+                out.append(f"| `{name}` | {int(r['Calls']) // calls} | {us:.1f} | {rb / 1e9:.3f} | {wb / 1e9:.3f} | {(rb + wb) / us / 1e3:.0f} |")
+                if name.startswith("pyr_"):
+                    pyr_us += us
+                    pyr_bytes += rb + wb
+            minimal = 128 * 1920 * 1080 * 4 * (1 + 1 + 1 / 3)
+            out += ["", f"Pyramid build (`lf_mkd_set_images_device`, all `pyr_*` launches of a call): {pyr_us:.0f} us for {pyr_bytes / 1e9:.2f} GB counted = "
+                    f"{pyr_bytes / pyr_us / 1e3:.0f} GB/s; on its minimal bytes (frames read once, every level written once: {minimal / 1e9:.2f} GB) "
+                    f"{minimal / pyr_us / 1e3:.0f} GB/s.", ""]
     if per_call:
         json.dump({"tag": tag, "source_sha256": stamp(("mkd_describe.hip", "mkd_pyramid.hip", "mkd_sample.h", "mkd_device.h", "lf_mkd.cpp")),
                    "git_head_at_summary": head, "hbm_bytes_per_call": per_call,
