@@ -1124,18 +1124,21 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
             LF_HIP(h, hipStreamSynchronize(s));
             (void)hipGraphExecDestroy(h->plans[old].exec);
             (void)hipGraphDestroy(h->plans[old].graph);
+            if (h->plans[old].head) (void)hipGraphExecDestroy(h->plans[old].head);
+            if (h->plans[old].head_graph) (void)hipGraphDestroy(h->plans[old].head_graph);
             h->plans.erase(h->plans.begin() + long(old));
         }
         lf_mkd::DetectPlan p;
         p.w = width; p.h = height; p.top_n = top_n; p.min_size_bits = ms_bits; p.max_out = max_out; p.u8 = u8;
         p.pd = h->pd;
-        // Frames of a megapixel and more go over PCIe in two pieces, and the pipeline's front runs on the first piece's rows
-        // while the second is on its way (RowBands).  Where to cut: the first piece's share of the front (~0.6 of the
-        // pipeline) should take as long as the second piece's upload -- an 8-bit frame uploads in about the time the front
-        // takes (cut in the middle), an f32 frame in four times that (cut at three quarters).  LF_MKD_DETECT_BANDS=0: one piece.
-        // Worth it from about 12 MB of upload (measured on the reference's houses.jpg sweep: an 8-bit frame of 7 MP gains
-        // nothing, an f32 frame of 3 MP gains 6 %, the 12.6 MP frame 8 % either way; a second copy costs ~25 us by itself).  A deep
-        // a-trous stack (n_scales 5: dilation 64, tiles of 768 rows) needs a later cut before its last layer gets any rows.
+        // Large frames go over PCIe in two pieces, and the pipeline's front runs on the first piece's rows while the second is
+        // on its way (RowBands).  Where to cut: the first piece's share of the front (~0.6 of the pipeline) should take as long
+        // as the second piece's upload -- an 8-bit frame uploads in about the time the front takes (cut in the middle), an f32
+        // frame in four times that (cut at three quarters); a deep a-trous stack (n_scales 5: dilation 64, tiles of 768 rows)
+        // needs a later cut before its last layer gets any rows.  Worth it from about 12 MB of upload (the reference's
+        // houses.jpg sweep: an 8-bit frame of 7 MP gains nothing, an f32 frame of 3 MP gains 6 %, the 12.6 MP frame 8 % either
+        // way; a second copy costs ~25 us by itself).  LF_MKD_DETECT_BANDS=0: one piece; LF_MKD_BAND_SPLIT=fraction: that cut,
+        // whatever the size (tests).
         RowBands bands{};
         const char *env_b = getenv("LF_MKD_DETECT_BANDS"), *env_f = getenv("LF_MKD_BAND_SPLIT");
         const bool want_bands = env_f || (uint64_t(width) * height * (u8 ? 1 : 4) >= 12000000ull && !(env_b && env_b[0] == '0'));

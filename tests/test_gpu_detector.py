@@ -498,7 +498,7 @@ def test_python_class_batch_call(lfp):
         assert np.array_equal(desc, one_d) and len(kps) > 40
 
 
-def test_handle_lifecycle_does_not_leak(lfp, torch):
+def test_handle_lifecycle_does_not_leak(lfp, torch, monkeypatch):
     """Create / use every family of entry points / destroy, many times: device memory returns to where it was."""
     import gc
     w, hgt = 256, 192
@@ -513,6 +513,12 @@ def test_handle_lifecycle_does_not_leak(lfp, torch):
                           pool_mode=lfp.POOL_F16X3 if rep % 2 else lfp.POOL_F32)
         kps, desc, _, _ = h.detect(img, 100 if rep % 3 else 0, 0.0)
         assert len(kps) > 20
+        if rep % 4 == 1:      # more request shapes than the handle keeps recordings for (banded ones among them), 8-bit frames too
+            monkeypatch.setenv("LF_MKD_BAND_SPLIT", "0.5")
+            u8 = np.ascontiguousarray(np.rint(img * 255).astype(np.uint8))
+            for t in range(11):
+                assert len(h.detect(u8 if t % 2 else img, 20 + t, 0.0)[0]) > 10
+            monkeypatch.delenv("LF_MKD_BAND_SPLIT")
         h.set_image(img)
         ex, _ = h.detect_extrema()
         k2, _ = h.orient_keypoints(ex)

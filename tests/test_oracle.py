@@ -90,6 +90,29 @@ def test_keypoint_mode_matches_float64_goldens(oracle):
     assert rel_l2(oracle.describe_patches(p), g["desc_shader"]).max() < 5e-5
 
 
+def test_the_two_readings_of_the_sample_position(oracle):
+    """patch_gradients.glsl:60-67 is not `precise`: `dx*ca - dy*sa` and `xx*r + x/2^L` may or may not be fused by the GLSL
+    compiler.  The oracle holds both readings (contract=False: mul then add, the default; contract=True: fma -- the reading the
+    HIP sampler implements).  Both are the float64 restatement's values to the same tolerance; they differ from each other by
+    at most one ulp of the coordinate times the frame's gradient (one of the two causes of the thinnest parity margin:
+    profiles/r05_parity_report.txt)."""
+    g = golden("keypoints_liberty.npz")
+    img = g["image"]
+    h, w = img.shape
+    pyr = oracle.build_pyramid(img)
+    a = oracle.sample_patches(pyr, w, h, g["keypoints"])
+    b = oracle.sample_patches(pyr, w, h, g["keypoints"], contract=True)
+    assert np.abs(a - g["patches"]).max() < 5e-6 and np.abs(b - g["patches"]).max() < 5e-6
+    assert 0 < np.abs(a - b).max() < 2e-5 and (a != b).mean() < 0.5
+    # a synthetic frame with large coordinates: the two readings are apart by about one coordinate ulp x the gradient
+    rng = np.random.default_rng(3)
+    big = np.ascontiguousarray(rng.random((64, 4096)).astype(np.float32))
+    k = np.array([[x, 32.0, 2.0, 37.0] for x in (40.3, 600.7, 1500.2, 2900.9, 4000.4)], np.float32)
+    pb = oracle.build_pyramid(big)
+    d = np.abs(oracle.sample_patches(pb, 4096, 64, k) - oracle.sample_patches(pb, 4096, 64, k, contract=True)).reshape(5, -1).max(1)
+    assert 0 < d.max() < 4096 * 2.0 ** -23 * 2.0          # never more than one ulp of the coordinate x the gradient (below 1 here)
+
+
 def test_properties(oracle):
     rng = np.random.default_rng(3)
     p = rng.random((8, 32, 32)).astype(np.float32)
