@@ -361,6 +361,9 @@ __device__ __forceinline__ void match_small_block(const float *__restrict__ a, l
     for (long t = wave; t < b_tiles; t += kSmallWaves) {
         const long tn = t + kSmallWaves < b_tiles ? t + kSmallWaves : t;
         const Raw nxt = load_row(b_row(tn));                // in flight while this tile is split and multiplied
+        // (the scheduler sinks these eight requests into the tile's arithmetic -- 60 VGPRs of the 128 the launch bounds allow;
+        //  fencing them here, all in flight before the tile's first instruction at 127 VGPRs, was measured in round 5 and is
+        //  SLOWER: 2000 x 2000 38 us instead of 35, 500 x 500 17 instead of 14)
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
