@@ -107,7 +107,11 @@ __global__ __launch_bounds__(256) void scan_extrema(const float *__restrict__ la
         auto at = [&](int dz, int dy, int dx) { return s_dog[c + dz * kScanPlane + dy * kScanRowLen + dx]; };
         const float val = s_dog[c];
         // a candidate needs |val| above the contrast threshold (line 95): a cube without such a voxel -- most cubes of a
-        // natural image -- is done after this one read per lane
+        // natural image -- is done after this one read per lane.  (Round 5 measured the kernel on a 12.6 MP photograph --
+        // 5.97e7 vector wave-instructions, 43 % of its LDS cycles two-way bank conflicts of this cube-shaped read -- and rebuilt
+        // the loop on that: the tile padded to a conflict-free pitch, a wave's eight centre voxels read and tested together,
+        // only the hot cubes walked.  Same extrema, no faster: 4K frame 74 us against 71, the photograph 135 against 120 in two
+        // bands.  Reverted; tools/pmc_detect_host.sh has the counters.)
         const bool hot = inside && fabsf(val) > contrast_threshold;
 #ifdef LF_SCAN_ABLATE_HOT   // timing-only build: every cube taken for cold
         if (true) {
