@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Profiling target for keypoint mode: BASELINE configs[2] as one batch (256 frames 640x480, 2000 keypoints each; default)
 or configs[1] (one 1920x1080 frame, 10 000 keypoints; argument "configs1") or configs[3] in its own form, the share of one GPU
-(128 frames 1920x1080, 8192 keypoints each; argument "configs3"), three calls of set_images + describe."""
+(128 frames 1920x1080, 8192 keypoints each; argument "configs3") or the reference's own settings on a 1080p frame (3000 keypoints:
+examples/match_images/src/main.rs:62-76; argument "refdefaults"), three calls of set_images + describe."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "local-features_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -9,7 +10,8 @@ import numpy as np, torch
 import local_features_python as lfp
 from gen_golden import random_keypoints
 which = sys.argv[1] if len(sys.argv) > 1 else "configs2"
-w, h, nk, frames, margin = {"configs1": (1920, 1080, 10000, 1, 64.0), "configs3": (1920, 1080, 8192, 128, 64.0)}.get(
+w, h, nk, frames, margin = {"configs1": (1920, 1080, 10000, 1, 64.0), "configs3": (1920, 1080, 8192, 128, 64.0),
+                            "refdefaults": (1920, 1080, 3000, 1, 64.0)}.get(
     which, (640, 480, 2000, 256, 8.0))
 n = nk * frames
 hnd = lfp.MkdHandle(max_features=n, max_image_width=w, max_image_height=h, max_frames=frames)

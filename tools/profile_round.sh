@@ -27,4 +27,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/kp1_write -- python3 $R/t
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kp3_stats -- python3 $R/tools/prof_keypoints.py configs3 > $OUT/kp3_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/kp3_fetch -- python3 $R/tools/prof_keypoints.py configs3 > $OUT/kp3_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/kp3_write -- python3 $R/tools/prof_keypoints.py configs3 > $OUT/kp3_write.log 2>&1
+# the reference's own settings on one 1080p frame (3000 keypoints): HBM traffic of the same call
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/kpr_fetch -- python3 $R/tools/prof_keypoints.py refdefaults > $OUT/kpr_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/kpr_write -- python3 $R/tools/prof_keypoints.py refdefaults > $OUT/kpr_write.log 2>&1
 tail -1 $OUT/stats.log | cut -c1-400

@@ -204,6 +204,16 @@ if kp_stats:
                 f"{tot1 / 10000:.0f} B per descriptor (same correction); algorithmic {alg1 / 1e6:.1f} MB = {alg1 / 10000:.0f} B per descriptor "
                 f"-> ratio {tot1 / alg1:.1f}.", ""]
         per_call["configs1_1080p_10k_keypoints"] = tot1
+    # the reference's own settings: one 1080p frame, 3000 keypoints
+    fr, wr = per_kernel("kpr_fetch", "FETCH_SIZE"), per_kernel("kpr_write", "WRITE_SIZE")
+    if fr and wr:
+        rdr = lambda k, v: v * (1.0 if k.startswith("mkd_pool") else 2.0)      # the same correction
+        totr = sum(rdr(k, v) for k, v in fr.items() if ours(k)) / calls * 1024 + sum(v for k, v in wr.items() if ours(k)) / calls * 1024
+        algr = 3000 * (16 + 512) + 1920 * 1080 * 4
+        out += [f"The reference's own settings (one 1920 x 1080 frame, 3000 keypoints; `prof_keypoints.py refdefaults`): {totr / 1e6:.1f} MB per call = "
+                f"{totr / 3000:.0f} B per descriptor (same correction); algorithmic {algr / 1e6:.1f} MB = {algr / 3000:.0f} B per descriptor "
+                f"-> ratio {totr / algr:.1f}.", ""]
+        per_call["reference_defaults_1080p_3000_keypoints"] = totr
     # configs[3] in its own form, one GPU's share: 128 frames 1920 x 1080, 8192 keypoints each
     f3, w3 = per_kernel("kp3_fetch", "FETCH_SIZE"), per_kernel("kp3_write", "WRITE_SIZE")
     kp3_stats = newest("kp3_stats", "*kernel_stats.csv")
