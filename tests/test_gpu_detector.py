@@ -307,6 +307,34 @@ def test_banded_upload_returns_the_unbanded_bits(lfp, oracle, monkeypatch, w, hg
     assert_same_extrema(want[0][:, [0, 1, 2, 4]], want_k[:, [0, 1, 2, 4]], "banded")
 
 
+def test_detect_recordings_survive_the_handles_other_uses(lfp, oracle):
+    """A recorded detect pipeline names the handle's scratch buffers by address; a call that has to grow one (orientation of
+    more extrema than any detect call sized it for, a larger result capacity) retires the recordings, and the next detect
+    call records anew -- same results before and after, and in between the other entry points work on the frame detect left."""
+    w, hgt = 640, 480
+    u8, f32 = _u8_frame(w, hgt, 5, 1200)
+    h = lfp.MkdHandle(max_features=300, max_image_width=w, max_image_height=hgt, max_blobs=512)
+    first = h.detect(u8, 100, 0.0, 300)
+    assert len(first[0]) > 50
+    # the frame is loaded: every extremum of it, oriented in one call -- far more than top_n = 100 sized the scratch for
+    ex, _ = h.detect_extrema(max_out=1 << 15)
+    assert len(ex) > 400
+    kps, _ = h.orient_keypoints(ex)
+    assert len(kps) >= len(ex)
+    again = h.detect(u8, 100, 0.0, 300)
+    assert again[2:] == first[2:] and np.array_equal(again[0], first[0]) and np.array_equal(again[1], first[1])
+    # a larger capacity (new result staging), then the first request once more
+    big = h.detect(f32, 0, 0.0, 5000)
+    assert len(big[0]) > len(first[0])
+    again = h.detect(f32, 100, 0.0, 300)
+    assert again[2:] == first[2:] and np.array_equal(again[0], first[0]) and np.array_equal(again[1], first[1])
+    # matching and patch description in between do not disturb it either
+    assert h.match(first[1], big[1]).shape == (len(first[1]),)
+    assert h.describe_patches(np.random.default_rng(1).random((70, 32, 32)).astype(np.float32)).shape == (70, 128)
+    again = h.detect(u8, 100, 0.0, 300)
+    assert np.array_equal(again[1], first[1])
+
+
 def test_detect_u8_errors_and_empty_frames(lfp):
     """the 8-bit entry points report what the f32 ones report; a flat frame yields no keypoints through the recorded pipeline"""
     h = lfp.MkdHandle(max_features=256, max_image_width=128, max_image_height=96)
