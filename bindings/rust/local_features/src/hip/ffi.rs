@@ -166,6 +166,9 @@ extern "C" {
     pub fn lf_mkd_comm_info(c: *const lf_mkd_comm, rccl_version: *mut i32, n_ranks: *mut i32, rank: *mut i32) -> c_int;
     pub fn lf_mkd_allgather_descriptors(h: *mut lf_mkd, c: *mut lf_mkd_comm, counts: *const u64, d_buf: *mut f32,
                                         mode: i32, stream: *mut c_void) -> c_int;
+    pub fn lf_mkd_comm_loopback(h: *mut lf_mkd, c: *mut lf_mkd_comm, d_src: *const f32, d_dst: *mut f32, n_rows: u64,
+                                stream: *mut c_void) -> c_int;
+    pub fn lf_mkd_comm_last_form(c: *const lf_mkd_comm) -> c_int;
 
     pub fn lf_mkd_get_coarse_layer(h: *mut lf_mkd, layer: u32, out: *mut f32) -> c_int;
     pub fn lf_mkd_sample_patches_device(h: *mut lf_mkd, d_kps: *const lf_mkd_keypoint, n: u64, d_patches: *mut f32,

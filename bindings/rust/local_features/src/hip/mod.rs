@@ -367,6 +367,30 @@ impl HipComm {
         Ok(counts)
     }
 
+    /// One group of ncclSend + ncclRecv from this rank to itself (`lf_mkd_comm_loopback`): `rows` descriptors go out of one
+    /// device buffer and must arrive in another.  What a job runs once per rank before its first `cross_image_match`, so that
+    /// the point-to-point branch of the gather has met the machine's librccl before the collective depends on it.
+    pub fn self_test(&self, lf: &mut LocalFeaturesHip, rows: usize) -> Result<(), Error> {
+        let src: Vec<f32> = (0..rows * DESCRIPTOR_LEN).map(|i| (i % 8191) as f32).collect();
+        let mut back = vec![0f32; src.len()];
+        // SAFETY: two distinct device buffers of `rows` rows each
+        unsafe {
+            let (d_src, d_dst) = (DeviceBuffer::from_slice(&src)?, DeviceBuffer::<f32>::new(src.len().max(1))?);
+            check(lf.h, ffi::lf_mkd_comm_loopback(lf.h, self.c, d_src.as_ptr(), d_dst.as_mut_ptr(), rows as u64,
+                                                  std::ptr::null_mut()))?;
+            check(lf.h, ffi::lf_mkd_synchronize(lf.h))?;
+            if rows > 0 { d_dst.download(&mut back)?; }
+        }
+        if back != src { return Err(Error::BadArgument("RCCL loopback: the rows that arrived are not the rows sent".into())); }
+        Ok(())
+    }
+
+    /// `LF_MKD_GATHER_DIRECT` / `LF_MKD_GATHER_RING` as the latest gather ran, -1 before the first
+    pub fn last_form(&self) -> i32 {
+        // SAFETY: plain query
+        unsafe { ffi::lf_mkd_comm_last_form(self.c) }
+    }
+
     /// (RCCL version code, ranks, this rank)
     pub fn info(&self) -> Result<(i32, i32, i32), Error> {
         let (mut v, mut n, mut r) = (0, 0, 0);

@@ -11,9 +11,15 @@
  * is shown in INTEGRATION.md.
  *
  * Threading: a handle is NOT thread-safe (the reference takes &mut self on every
- * call, mod.rs:346-367); use one handle per device/stream.  All functions return
+ * call, mod.rs:346-367); use one handle per device/stream.  Different handles may be
+ * used from different host threads at the same time (one thread per handle).  All functions return
  * LF_MKD_OK (0) or a negative lf_mkd_status; they never abort.  The message for
  * the last failure on a handle is available from lf_mkd_last_error().
+ *
+ * Current device: every entry point makes the handle's device (lf_mkd_params.device) current
+ * for its own duration and puts the calling thread's current HIP device back before it returns,
+ * on every return path -- a process that drives one handle per GPU keeps the current device it
+ * had (one hipGetDevice per call; hipSetDevice only when the two differ).
  */
 #ifndef LF_MKD_H
 #define LF_MKD_H
@@ -43,6 +49,9 @@ typedef enum { LF_MKD_PCA_LIBERTY = 0, LF_MKD_PCA_NOTREDAME = 1, LF_MKD_PCA_YOSE
 
 /* Angle path of the gradient stage.
  * SHADER  : the reference's polynomial atan2 incl. its quirks (shaders/atan2.glsl:19-46). Default.
+ *           (Domain: gx == -0.0 is gx == 0, as in the shader.  A gradient whose LARGER component is below 1e-30 in
+ *           magnitude -- pixel values of that order; frames of [0, 1] have none -- gets the direction of
+ *           min / max(larger, 1e-30) instead of min / larger: the hardware reciprocal has no denormal range.)
  * EXACT   : cos/sin of the gradient direction taken as gx/|g|, gy/|g| (what the polynomial
  *           approximates to 1e-5 rad; matches mkd_ref.rs:140, the CPU twin).
  * EXACT_ZERO : EXACT, except that a pixel with gx == 0 gets angle 0 as in the shader.  That is the one input
@@ -77,8 +86,8 @@ typedef enum { LF_MKD_POOL_DEFAULT = 0, LF_MKD_POOL_F16X3 = 1, LF_MKD_POOL_F32 =
 
 #define LF_MKD_FLAG_DETECT_STEPWISE 4u /* lf_mkd_detect / lf_mkd_detect_u8 stage by stage, every count fetched by the host before the
                                         next stage is sized (three waits): the verification form.  By default the call launches
-                                        the whole pipeline as ONE hipGraph, recorded on the first call for a (frame size, top_n,
-                                        min_size, max_out, pixel type) and kept; same bits. */
+                                        the whole pipeline as ONE hipGraph, recorded the second time a (frame size, top_n,
+                                        min_size, max_out, pixel type) is asked for and kept; same bits. */
 
 /* Mirrors BuildTimeParams (lib.rs:54-75) + FeatureDetectParams (lib.rs:34-52) for this path.
  * Zero-initialise, then set what you need; 0 means "default". */
@@ -232,9 +241,16 @@ int lf_mkd_filter_extrema_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, ui
  * image -> pyramid + a-trous stack -> extrema (at most max_blobs) -> [top_n filter if top_n > 0] ->
  * orientation -> sampling -> descriptors.  keypoints [max_out] and descriptors [max_out][128] receive
  * *n_out <= max_out results; *dropped_blobs and *dropped_features (may be NULL) as FeaturesResult
- * (lib.rs:77-83).  The whole pipeline is one hipGraph launch (recorded on the first call for these arguments' frame size, top_n,
- * min_size and max_out; up to 8 such recordings are kept per handle): the call costs the upload of the frame, the pipeline
- * and the copy of *n_out results, with one wait in between.  A frame of 12 MB or more crosses PCIe in two pieces, and the
+ * (lib.rs:77-83).  max_out beyond 18 x (top_n, or max_blobs when top_n == 0) -- more keypoints than can exist -- is treated as
+ * that bound: it sizes no buffer and no copy.  The whole pipeline is one hipGraph launch, recorded the SECOND time these
+ * arguments' frame size, top_n, min_size, max_out and pixel type are seen (up to 8 such recordings are kept per handle, the
+ * least recently used one makes room): a replayed call costs the upload of the frame, the pipeline and the copy of *n_out
+ * results, with one wait in between.  The first sighting of a request is served stage by stage (the form
+ * LF_MKD_FLAG_DETECT_STEPWISE keeps: three waits, same bits) -- the reference's match_images detects each image once, at its
+ * own size, and never pays a recording; a camera loop pays it on its second frame (LF_MKD_DETECT_RECORD_AFTER=k in the
+ * environment at lf_mkd_create: k sightings before recording, 0 = record at once; cost of the three kinds of call:
+ * INTEGRATION.md section 2).  Handles whose keypoint mode takes the two-launch form (LF_MKD_POOL_F32, LF_MKD_POOL_F16_FP6,
+ * LF_MKD_FLAG_UNFUSED_KEYPOINTS) always take the stage-by-stage form here.  A frame of 12 MB or more crosses PCIe in two pieces, and the
  * pipeline's front (level 0, the a-trous layers, the extremum scan) runs on the rows the first piece allows while the second
  * is on its way (LF_MKD_DETECT_BANDS=0 in the environment: one piece); same results bit for bit.  Afterwards the handle holds
  * the frame like lf_mkd_set_image.  (benches/bench.rs on houses.jpg, 4096 x 3072, top 2000: 1.29 ms, 0.94 of it the 50 MB
@@ -311,7 +327,8 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
  * image 2 and image 2 against image 1): d_match_ab [na] as lf_mkd_match_device(a, b) gives it, d_match_ba [nb] as
  * lf_mkd_match_device(b, a) does -- decision for decision.  Where both directions fit the one-launch form (the example's own
  * 2000 x 2000) they ARE one launch: the second direction costs no second launch.  Device pointers (16-byte aligned),
- * asynchronous on `stream`; na, nb >= 2. */
+ * asynchronous on `stream`.  An empty side (na == 0 or nb == 0) is LF_MKD_OK and writes nothing, as lf_mkd_match_device with
+ * na == 0; otherwise na, nb >= 2.  lf_mkd_match_overflowed afterwards reports the rows redone over BOTH directions. */
 int lf_mkd_match_both_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d_b, uint64_t nb, float ratio,
                              int32_t *d_match_ab, int32_t *d_match_ba, void *stream);
 /* Host pointers, synchronous. */
@@ -351,6 +368,16 @@ int lf_mkd_comm_destroy(lf_mkd_comm *c);
 int lf_mkd_comm_info(const lf_mkd_comm *c, int32_t *rccl_version, int32_t *n_ranks, int32_t *rank);
 int lf_mkd_allgather_descriptors(lf_mkd *h, lf_mkd_comm *c, const uint64_t *counts, float *d_buf, int32_t mode,
                                  void *stream);
+/* Diagnostics of the gather.
+ * lf_mkd_comm_loopback: one group with a send of n_rows rows of 128 f32 from d_src to THIS rank and the matching receive into
+ *     d_dst (ncclGroupStart, ncclSend, ncclRecv, ncclGroupEnd; n_rows == 0 posts the empty group) -- through the same binding
+ *     and the same posting routine as the DIRECT form, whose loop is empty on a one-rank communicator: what lets one process
+ *     check that the point-to-point branch works against the librccl it finds, before a multi-rank job depends on it.
+ *     d_src and d_dst are DEVICE arrays that must not overlap.  Asynchronous on `stream` (NULL: the handle's own).
+ * lf_mkd_comm_last_form: LF_MKD_GATHER_DIRECT or LF_MKD_GATHER_RING, whichever the communicator's latest
+ *     lf_mkd_allgather_descriptors took (RING falls back to DIRECT on unequal shards); -1 before the first gather. */
+int lf_mkd_comm_loopback(lf_mkd *h, lf_mkd_comm *c, const float *d_src, float *d_dst, uint64_t n_rows, void *stream);
+int lf_mkd_comm_last_form(const lf_mkd_comm *c);
 
 /* The same stage on the reference's own buffer formats, for a caller that keeps the reference's detect graph and host
  * filter and swaps only the extract graph.  Host pointers; synchronous.
@@ -393,7 +420,9 @@ int lf_mkd_build_constants(const float *mean, const float *eigvals, const float 
 /* With LF_MKD_FLAG_KERNEL_TIMING: waits for the recorded launches, returns the summed device time
  * (ms) of the describe kernel (pool_ms; whiten_ms is 0 since the whitening stage was fused into it)
  * and the number of batches since the previous call, then resets the sums.  Any output pointer may
- * be NULL. */
+ * be NULL.  Covers the describe launches the patch and keypoint entry points make (and a stage-by-stage
+ * lf_mkd_detect); a REPLAYED lf_mkd_detect / lf_mkd_stream_frame launches its describe node inside the
+ * hipGraph, without events: lf_mkd_detect_times covers those. */
 int lf_mkd_kernel_times(lf_mkd *h, double *pool_ms, double *whiten_ms, uint64_t *launches);
 
 /* With LF_MKD_FLAG_KERNEL_TIMING: where the handle's latest lf_mkd_detect / lf_mkd_detect_u8 call spent its time -- the upload of

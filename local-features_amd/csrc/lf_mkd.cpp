@@ -80,6 +80,18 @@ struct lf_mkd {
     };
     std::vector<DetectPlan> plans;
     uint64_t plan_clock = 0;
+    // Requests seen but not recorded yet.  Recording costs a capture and an instantiation (two when the upload is banded) --
+    // several times the call itself -- so a request is served stage by stage until it has been seen record_after times
+    // (default 1: the reference's match_images detects each image once, at its own size, and never pays a recording; a
+    // camera loop records on its second frame and replays from the third).  LF_MKD_DETECT_RECORD_AFTER in the environment,
+    // read at creation: 0 records on the first sighting.
+    struct Sighting {
+        uint32_t w, h, top_n, min_size_bits;
+        uint64_t max_out, count, stamp;
+        bool u8;
+    };
+    std::vector<Sighting> sightings;
+    uint64_t record_after = 1;
     unsigned char *d_image_u8 = nullptr;              // 8-bit frame(s) on their way to level 0, allocated on first use
     unsigned long long *d_det_counts = nullptr;       // [8] the recorded detect pipeline's counts (as lf_mkd_stream_create's d_counts)
     unsigned long long *h_det_counts = nullptr;       // the same in pinned host memory: the last node of a plan copies them here
@@ -125,6 +137,12 @@ thread_local std::string g_create_error;
             return LF_MKD_ERR_HIP;                                                          \
         }                                                                                   \
     } while (0)
+
+// Every entry point makes the handle's device current for its own duration and puts the caller's device back on EVERY return
+// path (a one-process / one-handle-per-GPU caller -- INTEGRATION.md section 3 -- keeps the current device it had).
+#define LF_ENTER(h)              \
+    lfmkd::DeviceScope scope_;   \
+    LF_HIP(h, scope_.enter((h)->params.device))
 
 int fail(lf_mkd *h, int code, const std::string &msg) {
     if (h) h->err = msg;
@@ -201,6 +219,7 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
         return LF_MKD_ERR_BAD_ARG;
     }
     h->max_extrema = 256 * ((uint64_t(params->max_blobs ? params->max_blobs : 8000) + 255) / 256);  // mod.rs:279-286
+    if (const char *e = getenv("LF_MKD_DETECT_RECORD_AFTER")) h->record_after = uint64_t(std::max(0, atoi(e)));
     h->batch = (mf + 63) / 64 * 64;
     auto bail = [&](int code) {
         g_create_error = h->err;
@@ -215,7 +234,8 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
             return bail(LF_MKD_ERR_HIP);                                      \
         }                                                                     \
     } while (0)
-    LF_CREATE_HIP(hipSetDevice(params->device));
+    lfmkd::DeviceScope scope_;
+    LF_CREATE_HIP(scope_.enter(params->device));
     LF_CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     {
         hipDeviceProp_t prop;
@@ -435,10 +455,15 @@ int detect_extrema_device(lf_mkd *h, float *d_out, uint32_t *d_frame_of, uint64_
     return LF_MKD_OK;
 }
 
+// recorded: the buffer is one a recorded pipeline names by address (record_pipeline: the detector's extrema and selection, the
+// top-n scratch, the staging patches; the orientation scratch, d_kps_out, d_det_desc and h_res_kps have their own sites) --
+// moving it retires every recording.  The matcher's and the multi-frame detect's scratch is named by no recording: growing it
+// leaves the recordings alone (and does not wait for the device).
+enum Recorded { kNotRecorded = 0, kRecorded = 1 };
 template <typename T>
-int grow(lf_mkd *h, T **p, uint64_t *cap, uint64_t want, size_t elem_bytes) {
+int grow(lf_mkd *h, T **p, uint64_t *cap, uint64_t want, size_t elem_bytes, Recorded recorded = kNotRecorded) {
     if (want <= *cap && *p) return LF_MKD_OK;
-    retire_graph(h);
+    if (recorded == kRecorded) retire_graph(h);
     if (*p) (void)hipFree(*p);
     *p = nullptr;
     *cap = 0;
@@ -453,8 +478,18 @@ int grow(lf_mkd *h, T **p, uint64_t *cap, uint64_t want, size_t elem_bytes) {
 // ordered with the null stream)
 int grow_topk_work(lf_mkd *h, uint64_t n_cap, hipStream_t s) {
     const uint64_t before = h->topk_work_cap;
-    if (int rc = grow(h, &h->d_topk_work, &h->topk_work_cap, topk_work_words(n_cap), 4)) return rc;
+    if (int rc = grow(h, &h->d_topk_work, &h->topk_work_cap, topk_work_words(n_cap), 4, kRecorded)) return rc;
     if (h->topk_work_cap != before) LF_HIP(h, hipMemsetAsync(h->d_topk_work, 0, topk_work_words(n_cap) * 4, s));
+    return LF_MKD_OK;
+}
+
+// the matcher's three words -- [0] largest |b| (float bits), [1] rows of the current chunk whose candidate records
+// overflowed, [2] the same over the call (lf_mkd_match_overflowed) -- allocated on first use and zeroed once, on the stream
+// the match will run on (so that a form that does not reset [2] adds to a defined value)
+int ensure_match_misc(lf_mkd *h, hipStream_t s) {
+    if (h->d_match_misc) return LF_MKD_OK;
+    if (int rc = grow(h, &h->d_match_misc, &h->match_misc_cap, 3, sizeof(unsigned))) return rc;
+    LF_HIP(h, hipMemsetAsync(h->d_match_misc, 0, 3 * sizeof(unsigned), s));
     return LF_MKD_OK;
 }
 
@@ -526,7 +561,8 @@ int lf_mkd_create_from_file(const lf_mkd_params *params, const char *path, lf_mk
 
 void lf_mkd_destroy(lf_mkd *h) {
     if (!h) return;
-    (void)hipSetDevice(h->params.device);
+    lfmkd::DeviceScope scope_;
+    (void)scope_.enter(h->params.device);
     (void)hipDeviceSynchronize();   // work of this handle may be in flight on the caller's streams too
     void *ptrs[] = {h->dc.colmap,     h->dc.pool_b_f32, h->dc.pool_b_f16, h->dc.pool_b_fp6, h->dc.white_a_f16,
                     h->dc.white_a_f32, h->dc.white_bias, h->d_patches,     h->d_out,         h->d_kps,
@@ -571,7 +607,7 @@ const char *lf_mkd_last_error(const lf_mkd *h) { return h ? h->err.c_str() : g_c
 
 int lf_mkd_kernel_times(lf_mkd *h, double *pool_ms, double *whiten_ms, uint64_t *launches) {
     if (!h) return LF_MKD_ERR_BAD_ARG;
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     double tp = 0, tw = 0;
     const size_t nb = h->ev_pending.size() / 2;
     for (size_t i = 0; i < nb; ++i) {
@@ -593,7 +629,7 @@ int lf_mkd_kernel_clock(lf_mkd *h, void *stream, double *shader_mhz, double *ker
     if (shader_mhz) *shader_mhz = 0;
     if (kernel_ms) *kernel_ms = 0;
     if (!h->d_clk) return fail(h, LF_MKD_ERR_BAD_ARG, "kernel_clock: the handle was not created with LF_MKD_FLAG_KERNEL_TIMING");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     unsigned long long c[4] = {0, 0, 0, 0};
     LF_HIP(h, hipMemcpyAsync(c, h->d_clk, sizeof(c), hipMemcpyDeviceToHost, s));
@@ -608,7 +644,7 @@ int lf_mkd_kernel_clock(lf_mkd *h, void *stream, double *shader_mhz, double *ker
 
 int lf_mkd_synchronize(lf_mkd *h) {
     if (!h) return LF_MKD_ERR_BAD_ARG;
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     LF_HIP(h, hipStreamSynchronize(h->stream));
     return LF_MKD_OK;
 }
@@ -617,7 +653,7 @@ int lf_mkd_describe_patches_device(lf_mkd *h, const float *d_patches, uint64_t n
     if (!h) return LF_MKD_ERR_BAD_ARG;
     if (n == 0) return LF_MKD_OK;
     if (!d_patches || !d_out) return fail(h, LF_MKD_ERR_BAD_ARG, "describe_patches_device: null pointer");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     for (uint64_t off = 0; off < n; off += h->batch) {
         const uint64_t m = std::min<uint64_t>(h->batch, n - off);
@@ -631,7 +667,7 @@ int lf_mkd_raw_descriptors_device(lf_mkd *h, const float *d_patches, uint64_t n,
     if (!h) return LF_MKD_ERR_BAD_ARG;
     if (n == 0) return LF_MKD_OK;
     if (!d_patches || !d_raw) return fail(h, LF_MKD_ERR_BAD_ARG, "raw_descriptors_device: null pointer");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     if (int rc = ensure_staging(h)) return rc;   // the kernel also writes the whitened descriptors: into the staging buffer
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     for (uint64_t off = 0; off < n; off += h->batch) {
@@ -646,7 +682,7 @@ int lf_mkd_describe_patches(lf_mkd *h, const float *patches, uint64_t n, float *
     if (!h) return LF_MKD_ERR_BAD_ARG;
     if (n == 0) return LF_MKD_OK;
     if (!patches || !out) return fail(h, LF_MKD_ERR_BAD_ARG, "describe_patches: null pointer");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     if (int rc = ensure_staging(h)) return rc;
     for (uint64_t off = 0; off < n; off += h->batch) {
         const uint64_t m = std::min<uint64_t>(h->batch, n - off);
@@ -672,7 +708,7 @@ static int set_images_impl(lf_mkd *h, const float *d_images, const unsigned char
     if (n_frames > h->max_frames)
         return fail(h, LF_MKD_ERR_BAD_ARG, "set_images: " + std::to_string(n_frames) + " frames exceed max_frames = " +
                                                std::to_string(h->max_frames) + " given at creation");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     describe_pyramid(width, height, h->pd);
     // once the a-trous stack exists (orientation or the detector have been used on this handle) the pyramid's
@@ -719,7 +755,7 @@ int lf_mkd_set_image(lf_mkd *h, const float *image, uint32_t width, uint32_t hei
     if (!image) return fail(h, LF_MKD_ERR_BAD_ARG, "set_image: null image");
     if (!h->d_image || width > h->params.max_image_width || height > h->params.max_image_height)
         return fail(h, LF_MKD_ERR_BAD_ARG, "set_image: image exceeds max_image_width/height given at creation");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     LF_HIP(h, hipMemcpyAsync(h->d_image, image, size_t(width) * height * 4, hipMemcpyHostToDevice, h->stream));
     const int rc = lf_mkd_set_image_device(h, h->d_image, width, height, h->stream);
     if (rc) return rc;
@@ -732,7 +768,7 @@ int lf_mkd_set_image_u8(lf_mkd *h, const uint8_t *image, uint32_t width, uint32_
     if (!image) return fail(h, LF_MKD_ERR_BAD_ARG, "set_image_u8: null image");
     if (!h->d_image || width > h->params.max_image_width || height > h->params.max_image_height)
         return fail(h, LF_MKD_ERR_BAD_ARG, "set_image_u8: image exceeds max_image_width/height given at creation");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     if (int rc = ensure_u8_staging(h)) return rc;
     LF_HIP(h, hipMemcpyAsync(h->d_image_u8, image, size_t(width) * height, hipMemcpyHostToDevice, h->stream));
     const int rc = lf_mkd_set_images_u8_device(h, h->d_image_u8, 1, width, height, h->stream);
@@ -747,7 +783,7 @@ int lf_mkd_sample_patches_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64
     if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "sample_patches: call lf_mkd_set_image first");
     if (n == 0) return LF_MKD_OK;
     if (!d_kps || !d_patches) return fail(h, LF_MKD_ERR_BAD_ARG, "sample_patches: null pointer");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_kps), nullptr, 1, long(n),
                           nullptr, h->params.patch_scale_factor, d_patches, s);
@@ -761,7 +797,7 @@ int lf_mkd_describe_keypoints_frames_device(lf_mkd *h, const lf_mkd_keypoint *d_
     if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "describe_keypoints: call lf_mkd_set_image first");
     if (n == 0) return LF_MKD_OK;
     if (!d_kps || !d_out) return fail(h, LF_MKD_ERR_BAD_ARG, "describe_keypoints_device: null pointer");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     return describe_keypoints_on_device(h, reinterpret_cast<const float *>(d_kps), d_frame_of_kp, n, d_out, s);
 }
@@ -776,7 +812,7 @@ int lf_mkd_describe_keypoints(lf_mkd *h, const lf_mkd_keypoint *kps, uint64_t n,
     if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "describe_keypoints: call lf_mkd_set_image first");
     if (n == 0) return LF_MKD_OK;
     if (!kps || !out) return fail(h, LF_MKD_ERR_BAD_ARG, "describe_keypoints: null pointer");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     if (int rc = ensure_io_staging(h)) return rc;
     for (uint64_t off = 0; off < n; off += h->batch) {
         const uint64_t m = std::min<uint64_t>(h->batch, n - off);
@@ -798,7 +834,7 @@ int lf_mkd_orient_keypoints_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, 
     if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "orient_keypoints: call lf_mkd_set_image first");
     if (n == 0) return LF_MKD_OK;
     if (!d_extrema || (!d_out && max_out)) return fail(h, LF_MKD_ERR_BAD_ARG, "orient_keypoints_device: null pointer");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     if (int rc = ensure_orient_scratch(h, n, false, 0)) return rc;
     return orient_device(h, reinterpret_cast<const float *>(d_extrema), d_frame_of_extremum, n,
@@ -814,7 +850,7 @@ int lf_mkd_orient_keypoints(lf_mkd *h, const lf_mkd_extremum *extrema, uint64_t 
     if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "orient_keypoints: call lf_mkd_set_image first");
     if (n == 0) return LF_MKD_OK;
     if (!extrema || (!out && max_out)) return fail(h, LF_MKD_ERR_BAD_ARG, "orient_keypoints: null pointer");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     if (int rc = ensure_orient_scratch(h, n, true, std::max<uint64_t>(max_out, 1))) return rc;
     LF_HIP(h, hipMemcpyAsync(h->d_extrema, extrema, n * sizeof(lf_mkd_extremum), hipMemcpyHostToDevice, h->stream));
     if (int rc = orient_device(h, h->d_extrema, nullptr, n, h->d_kps_out, nullptr, max_out, n_out, n_dropped, h->stream))
@@ -831,7 +867,7 @@ int lf_mkd_detect_extrema_device(lf_mkd *h, lf_mkd_extremum *d_out, uint32_t *d_
     if (n_dropped) *n_dropped = 0;
     if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "detect_extrema: call lf_mkd_set_image first");
     if (!d_out && max_out) return fail(h, LF_MKD_ERR_BAD_ARG, "detect_extrema_device: null pointer");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     return detect_extrema_device(h, reinterpret_cast<float *>(d_out), d_frame_of, max_out, n_out, n_dropped, s);
 }
@@ -843,8 +879,8 @@ int lf_mkd_detect_extrema(lf_mkd *h, lf_mkd_extremum *out, uint64_t max_out, uin
     if (n_dropped) *n_dropped = 0;
     if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "detect_extrema: call lf_mkd_set_image first");
     if (!out && max_out) return fail(h, LF_MKD_ERR_BAD_ARG, "detect_extrema: null pointer");
-    LF_HIP(h, hipSetDevice(h->params.device));
-    if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, max_out, sizeof(lf_mkd_extremum))) return rc;
+    LF_ENTER(h);
+    if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, max_out, sizeof(lf_mkd_extremum), kRecorded)) return rc;
     if (int rc = detect_extrema_device(h, h->d_det_extrema, nullptr, max_out, n_out, n_dropped, h->stream)) return rc;
     if (*n_out) LF_HIP(h, hipMemcpy(out, h->d_det_extrema, *n_out * sizeof(lf_mkd_extremum), hipMemcpyDeviceToHost));
     return LF_MKD_OK;
@@ -858,7 +894,7 @@ int lf_mkd_filter_extrema_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, ui
     if (n == 0 || top_n == 0) return LF_MKD_OK;
     if (!d_extrema || !d_out) return fail(h, LF_MKD_ERR_BAD_ARG, "filter_extrema_device: null pointer");
     if (n > 0xFFFFFFFFull) return fail(h, LF_MKD_ERR_BAD_ARG, "filter_extrema_device: more than 2^32 extrema");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     if (!h->d_sel_count) LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_sel_count), 4 * h->max_frames));
     if (int rc = grow_topk_work(h, n, s)) return rc;
@@ -904,7 +940,7 @@ static int detect_stepwise(lf_mkd *h, bool u8, uint32_t width, uint32_t height, 
     h->coarse_valid = stack_queued;
     h->n_frames = 1;
     // detect graph: extrema, at most max_extrema of them (mod.rs:625-633)
-    if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, h->max_extrema, sizeof(lf_mkd_extremum))) return rc;
+    if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, h->max_extrema, sizeof(lf_mkd_extremum), kRecorded)) return rc;
     uint64_t n_ext = 0;
     const int rc_ext = detect_extrema_device(h, h->d_det_extrema, nullptr, h->max_extrema, &n_ext, dropped_blobs, s);
     if (share) LF_HIP(h, hipStreamWaitEvent(s, h->side_events[1], 0));   // whatever follows on s sees the whole pyramid
@@ -912,7 +948,7 @@ static int detect_stepwise(lf_mkd *h, bool u8, uint32_t width, uint32_t height, 
     // host blob filter of detect_top_n, on the device
     const float *d_sel = h->d_det_extrema;
     if (top_n && n_ext) {
-        if (int rc = grow(h, &h->d_det_selected, &h->det_sel_cap, top_n, sizeof(lf_mkd_extremum))) return rc;
+        if (int rc = grow(h, &h->d_det_selected, &h->det_sel_cap, top_n, sizeof(lf_mkd_extremum), kRecorded)) return rc;
         uint64_t n_sel = 0;
         if (int rc = lf_mkd_filter_extrema_device(h, reinterpret_cast<const lf_mkd_extremum *>(h->d_det_extrema), n_ext,
                                                   top_n, min_size, reinterpret_cast<lf_mkd_extremum *>(h->d_det_selected),
@@ -949,9 +985,9 @@ static int prepare_pipeline(lf_mkd *h, uint32_t top_n, uint64_t cap) {
         LF_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->d_coarse), size_t(h->coarse_stride) * h->max_frames * 4));
     }
     if (int rc = ensure_detect_scratch(h)) return rc;
-    if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, h->max_extrema, sizeof(lf_mkd_extremum))) return rc;
+    if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, h->max_extrema, sizeof(lf_mkd_extremum), kRecorded)) return rc;
     if (top_n) {
-        if (int rc = grow(h, &h->d_det_selected, &h->det_sel_cap, top_n, sizeof(lf_mkd_extremum))) return rc;
+        if (int rc = grow(h, &h->d_det_selected, &h->det_sel_cap, top_n, sizeof(lf_mkd_extremum), kRecorded)) return rc;
         if (int rc = grow_topk_work(h, h->max_extrema, h->stream)) return rc;
     }
     return ensure_orient_scratch(h, cap, false, 0);
@@ -1065,19 +1101,54 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
     if (!h->d_image || !h->d_pyr || width < 2 || height < 2 || width > h->params.max_image_width ||
         height > h->params.max_image_height)
         return fail(h, LF_MKD_ERR_BAD_ARG, "detect: image exceeds max_image_width/height given at creation");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     hipStream_t s = h->stream;
     const bool u8 = image_u8 != nullptr;
     if (u8)
         if (int rc = ensure_u8_staging(h)) return rc;
-    const bool stepwise = (h->params.flags & LF_MKD_FLAG_DETECT_STEPWISE) || max_out == 0;
+    // An extremum yields at most 18 keypoints: a capacity beyond that bound sizes nothing -- not the result staging, not
+    // the pinned keypoint rows a recording copies on every call, not the key of a recording.
+    max_out = std::min<uint64_t>(max_out, std::min<uint64_t>(top_n ? top_n : h->max_extrema, h->max_extrema) *
+                                              LF_MKD_MAX_ANGLES_PER_EXTREMUM);
+    uint32_t ms_bits;
+    std::memcpy(&ms_bits, &min_size, 4);
+    // Stage by stage: when asked for (the verification flag), when only the counts are wanted, and on handles whose keypoint
+    // mode takes the two-launch form (POOL_F32, F16_FP6, FLAG_UNFUSED_KEYPOINTS: verification forms whose staging patches
+    // are sized by the internal batch there, by max_out x 4 KiB in a recording) ...
+    bool stepwise = (h->params.flags & LF_MKD_FLAG_DETECT_STEPWISE) || max_out == 0 || !fused_keypoints(h);
+    lf_mkd::DetectPlan *plan = nullptr;
+    if (!stepwise) {
+        for (auto &p : h->plans)
+            if (p.w == width && p.h == height && p.top_n == top_n && p.min_size_bits == ms_bits && p.max_out == max_out && p.u8 == u8)
+                plan = &p;
+        // ... and while a request has not been seen record_after times (see lf_mkd::Sighting)
+        if (!plan && h->record_after) {
+            lf_mkd::Sighting *seen = nullptr;
+            for (auto &g : h->sightings)
+                if (g.w == width && g.h == height && g.top_n == top_n && g.min_size_bits == ms_bits && g.max_out == max_out && g.u8 == u8)
+                    seen = &g;
+            if (!seen) {
+                if (h->sightings.size() >= 64) {     // the least recently seen request is forgotten
+                    size_t old = 0;
+                    for (size_t i = 1; i < h->sightings.size(); ++i)
+                        if (h->sightings[i].stamp < h->sightings[old].stamp) old = i;
+                    h->sightings.erase(h->sightings.begin() + long(old));
+                }
+                h->sightings.push_back(lf_mkd::Sighting{width, height, top_n, ms_bits, max_out, 0, 0, u8});
+                seen = &h->sightings.back();
+            }
+            seen->stamp = ++h->plan_clock;
+            if (seen->count < h->record_after) {
+                ++seen->count;
+                stepwise = true;
+            }
+        }
+    }
     if (!stepwise) {
         // every buffer the recording names, before the upload is queued (growing one waits for the device)
         const uint64_t cap = top_n ? top_n : h->max_extrema;
         if (int rc = prepare_pipeline(h, top_n, cap)) return rc;
         if (int rc = ensure_orient_scratch(h, cap, true, max_out)) return rc;     // d_kps_out, d_det_desc [max_out]
-        if (!fused_keypoints(h))
-            if (int rc = grow(h, &h->d_stream_patches, &h->stream_patch_cap, max_out * kPx, sizeof(float))) return rc;
         if (max_out > h->h_res_cap) {          // the recordings store into it by address
             retire_graph(h);
             if (h->h_res_kps) (void)hipHostFree(h->h_res_kps);
@@ -1105,14 +1176,14 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
         return LF_MKD_OK;
     };
     if (stepwise) {
+        h->det_upload_ms = h->det_pipeline_ms = h->det_readback_ms = 0;    // lf_mkd_detect_times covers recorded calls only
         if (int rc = upload_whole()) return rc;
         return detect_stepwise(h, u8, width, height, top_n, min_size, keypoints, descriptors, max_out, n_out, dropped_blobs,
                                dropped_features);
     }
     describe_pyramid(width, height, h->pd);
-    uint32_t ms_bits;
-    std::memcpy(&ms_bits, &min_size, 4);
-    lf_mkd::DetectPlan *plan = nullptr;
+    // (the buffers above may have moved and retired every recording, `plan` among them: look again)
+    plan = nullptr;
     for (auto &p : h->plans)
         if (p.w == width && p.h == height && p.top_n == top_n && p.min_size_bits == ms_bits && p.max_out == max_out && p.u8 == u8)
             plan = &p;
@@ -1260,6 +1331,7 @@ int lf_mkd_detect_frames_device(lf_mkd *h, const float *d_images, uint32_t n_fra
     if (dropped_features) *dropped_features = 0;
     if (max_out && (!d_keypoints || !d_descriptors || !d_frame_of_kp))
         return fail(h, LF_MKD_ERR_BAD_ARG, "detect_frames: null output pointer");
+    LF_ENTER(h);
     if (int rc = lf_mkd_set_images_device(h, d_images, n_frames, width, height, stream)) return rc;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     const uint64_t cap_f = h->max_extrema;                       // extrema kept per frame (mod.rs:625-633)
@@ -1267,7 +1339,7 @@ int lf_mkd_detect_frames_device(lf_mkd *h, const float *d_images, uint32_t n_fra
     const uint64_t all_cap = cap_f * n_frames * 2;               // room for frames that exceed their share
     if (int rc = ensure_coarse_stack(h, s)) return rc;
     if (int rc = ensure_detect_scratch(h)) return rc;
-    if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, all_cap, sizeof(lf_mkd_extremum))) return rc;
+    if (int rc = grow(h, &h->d_det_extrema, &h->det_out_cap, all_cap, sizeof(lf_mkd_extremum), kRecorded)) return rc;
     if (int rc = grow(h, &h->d_mf_frame_start, &h->mf_start_cap, n_frames, 4)) return rc;
     if (int rc = grow(h, &h->d_mf_offsets, &h->mf_off_cap, n_frames, 4)) return rc;
     if (int rc = grow(h, &h->d_mf_padded, &h->mf_padded_cap, keep * n_frames, sizeof(lf_mkd_extremum))) return rc;
@@ -1309,7 +1381,7 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
         return fail(h, LF_MKD_ERR_BAD_ARG, "stream_create: bad argument");
     if (!h->d_pyr || width > h->params.max_image_width || height > h->params.max_image_height)
         return fail(h, LF_MKD_ERR_BAD_ARG, "stream_create: frame exceeds max_image_width/height given at creation");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     LF_HIP(h, hipStreamSynchronize(h->stream));
     // an earlier recording may still be running on a caller's stream
     if (h->graph_exec) {
@@ -1329,7 +1401,7 @@ int lf_mkd_stream_create(lf_mkd *h, uint32_t width, uint32_t height, uint32_t to
     const uint64_t cap = top_n ? top_n : h->max_extrema;   // extrema that can reach orientation
     if (int rc = prepare_pipeline(h, top_n, cap)) return rc;
     if (!fused_keypoints(h))
-        if (int rc = grow(h, &h->d_stream_patches, &h->stream_patch_cap, max_out * kPx, sizeof(float))) return rc;
+        if (int rc = grow(h, &h->d_stream_patches, &h->stream_patch_cap, max_out * kPx, sizeof(float), kRecorded)) return rc;
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(d_counts);
     LF_HIP(h, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), h->stream));
     LF_HIP(h, hipStreamSynchronize(h->stream));
@@ -1345,7 +1417,7 @@ int lf_mkd_stream_frame(lf_mkd *h, void *stream) {
     if (!h->graph_exec)
         return fail(h, LF_MKD_ERR_BAD_ARG, "stream_frame: no recorded pipeline (call lf_mkd_stream_create; a call that "
                                            "grew the handle's scratch buffers retires an earlier recording)");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     LF_HIP(h, hipGraphLaunch(h->graph_exec, stream ? static_cast<hipStream_t>(stream) : h->stream));
     // every launch rebuilds the pyramid and the a-trous stack of the frame in d_image: work enqueued behind it on the same
     // stream (describe_keypoints, orientation, the verification taps) sees that frame
@@ -1355,9 +1427,10 @@ int lf_mkd_stream_frame(lf_mkd *h, void *stream) {
     return LF_MKD_OK;
 }
 
-int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d_b, uint64_t nb,
-                        const uint32_t *d_exclude_lo, const uint32_t *d_exclude_hi, float ratio, int32_t *d_match,
-                        float *d_best, float *d_second, void *stream) {
+// keep_overflow: the word lf_mkd_match_overflowed reads is added to, not reset (the second direction of lf_mkd_match_both_device)
+static int match_device_impl(lf_mkd *h, const float *d_a, uint64_t na, const float *d_b, uint64_t nb,
+                             const uint32_t *d_exclude_lo, const uint32_t *d_exclude_hi, float ratio, int32_t *d_match,
+                             float *d_best, float *d_second, void *stream, bool keep_overflow) {
     if (!h) return LF_MKD_ERR_BAD_ARG;
     if (na == 0) return LF_MKD_OK;
     if (!d_a || !d_b || !d_match) return fail(h, LF_MKD_ERR_BAD_ARG, "match_device: null pointer");
@@ -1367,7 +1440,7 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
     if (na > 0x7FFFFFFFull || nb > 0x7FFFFFFFull) return fail(h, LF_MKD_ERR_BAD_ARG, "match: more than 2^31 rows");
     if ((reinterpret_cast<uintptr_t>(d_a) | reinterpret_cast<uintptr_t>(d_b)) & 15)
         return fail(h, LF_MKD_ERR_BAD_ARG, "match_device: d_a and d_b must be 16-byte aligned");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     // Which form: the two passes win once the scan would take about a millisecond and a has enough rows to fill the chip
     // without splitting b many ways (every b split starts its candidate lists from nothing); below that -- the reference's
@@ -1380,7 +1453,7 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
     const bool want_small = form ? (form[0] == 's' && form[1] == 'm') : true;
     if (want_small && match_small_fits(long(na), long(nb))) {
         launch_match_small(d_a, long(na), d_b, long(nb), d_exclude_lo, d_exclude_hi, ratio, d_match, d_best, d_second,
-                           h->d_match_misc ? h->d_match_misc + 2 : nullptr, s);
+                           h->d_match_misc && !keep_overflow ? h->d_match_misc + 2 : nullptr, s);
         LF_HIP(h, hipGetLastError());
         return LF_MKD_OK;
     }
@@ -1398,7 +1471,7 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
     int *p_index = reinterpret_cast<int *>(p_second + uint64_t(splits) * chunk);
     if (three_term_only) {
         // lf_mkd_match_overflowed reports on the LATEST call: this form redoes nothing
-        if (h->d_match_misc) LF_HIP(h, hipMemsetAsync(h->d_match_misc + 2, 0, sizeof(unsigned), s));
+        if (h->d_match_misc && !keep_overflow) LF_HIP(h, hipMemsetAsync(h->d_match_misc + 2, 0, sizeof(unsigned), s));
         launch_match_split(d_a, long(na), h->d_match_a, nullptr, nullptr, s);
         launch_match_split(d_b, long(nb), h->d_match_b, nullptr, nullptr, s);
         launch_match(h->d_match_a, long(na), h->d_match_b, long(nb), d_exclude_lo, d_exclude_hi, ratio, splits, p_best,
@@ -1409,11 +1482,11 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
     if (int rc = grow(h, &h->d_match_rec, &h->match_rec_cap, match_record_bytes(long(chunk), splits), 1)) return rc;
     if (int rc = grow(h, &h->d_match_cnt, &h->match_cnt_cap, match_count_bytes(long(chunk), splits), 1)) return rc;
     if (int rc = grow(h, &h->d_match_norm, &h->match_norm_cap, chunk, sizeof(float))) return rc;
-    if (int rc = grow(h, &h->d_match_misc, &h->match_misc_cap, 3, sizeof(unsigned))) return rc;
+    if (int rc = ensure_match_misc(h, s)) return rc;
     if (int rc = grow(h, &h->d_match_few_tiles, &h->match_few_tiles_cap, match_few_tiles_bytes(), 1)) return rc;
     if (int rc = grow(h, &h->d_match_few, &h->match_few_cap, match_few_words(), sizeof(unsigned))) return rc;
     // misc: [0] largest |b| (float bits), [1] rows of the current chunk whose records overflowed, [2] the same over the call
-    LF_HIP(h, hipMemsetAsync(h->d_match_misc, 0, 3 * sizeof(unsigned), s));
+    LF_HIP(h, hipMemsetAsync(h->d_match_misc, 0, (keep_overflow ? 2 : 3) * sizeof(unsigned), s));
     unsigned *b_max = h->d_match_misc;
     int *n_over = reinterpret_cast<int *>(h->d_match_misc + 1);
     launch_match_split(d_b, long(nb), h->d_match_b, nullptr, b_max, s);
@@ -1440,15 +1513,22 @@ int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d
     return LF_MKD_OK;
 }
 
+int lf_mkd_match_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d_b, uint64_t nb,
+                        const uint32_t *d_exclude_lo, const uint32_t *d_exclude_hi, float ratio, int32_t *d_match,
+                        float *d_best, float *d_second, void *stream) {
+    return match_device_impl(h, d_a, na, d_b, nb, d_exclude_lo, d_exclude_hi, ratio, d_match, d_best, d_second, stream, false);
+}
+
 int lf_mkd_match_both_device(lf_mkd *h, const float *d_a, uint64_t na, const float *d_b, uint64_t nb, float ratio,
                              int32_t *d_match_ab, int32_t *d_match_ba, void *stream) {
     if (!h) return LF_MKD_ERR_BAD_ARG;
-    if (na == 0 && nb == 0) return LF_MKD_OK;
+    // an empty side: nothing to match in either direction, nothing is written (as lf_mkd_match_device with na == 0)
+    if (na == 0 || nb == 0) return LF_MKD_OK;
     if (!d_a || !d_b || !d_match_ab || !d_match_ba) return fail(h, LF_MKD_ERR_BAD_ARG, "match_both_device: null pointer");
     if (na < 2 || nb < 2) return fail(h, LF_MKD_ERR_BAD_ARG, "match_both: needs at least two rows on either side (main.rs:20)");
     if ((reinterpret_cast<uintptr_t>(d_a) | reinterpret_cast<uintptr_t>(d_b)) & 15)
         return fail(h, LF_MKD_ERR_BAD_ARG, "match_both_device: d_a and d_b must be 16-byte aligned");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     const char *form = getenv("LF_MKD_MATCH");
     if (!form && match_small_fits(long(na), long(nb)) && match_small_fits(long(nb), long(na))) {
@@ -1457,9 +1537,11 @@ int lf_mkd_match_both_device(lf_mkd *h, const float *d_a, uint64_t na, const flo
         LF_HIP(h, hipGetLastError());
         return LF_MKD_OK;
     }
-    // larger problems (or a forced form): one call per direction, each in the form its size takes
-    if (int rc = lf_mkd_match_device(h, d_a, na, d_b, nb, nullptr, nullptr, ratio, d_match_ab, nullptr, nullptr, s)) return rc;
-    return lf_mkd_match_device(h, d_b, nb, d_a, na, nullptr, nullptr, ratio, d_match_ba, nullptr, nullptr, s);
+    // larger problems (or a forced form): one call per direction, each in the form its size takes; the second adds its
+    // redone rows to the first's, so that lf_mkd_match_overflowed reports on the whole call
+    if (int rc = ensure_match_misc(h, s)) return rc;
+    if (int rc = match_device_impl(h, d_a, na, d_b, nb, nullptr, nullptr, ratio, d_match_ab, nullptr, nullptr, s, false)) return rc;
+    return match_device_impl(h, d_b, nb, d_a, na, nullptr, nullptr, ratio, d_match_ba, nullptr, nullptr, s, true);
 }
 
 int lf_mkd_match_overflowed(lf_mkd *h, void *stream, uint64_t *n_rows) {
@@ -1467,7 +1549,7 @@ int lf_mkd_match_overflowed(lf_mkd *h, void *stream, uint64_t *n_rows) {
     if (!n_rows) return fail(h, LF_MKD_ERR_BAD_ARG, "match_overflowed: null pointer");
     *n_rows = 0;
     if (!h->d_match_misc) return LF_MKD_OK;           // no two-pass match yet
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     int n = 0;
     LF_HIP(h, hipMemcpyAsync(&n, h->d_match_misc + 2, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1481,7 +1563,7 @@ int lf_mkd_match(lf_mkd *h, const float *a, uint64_t na, const float *b, uint64_
     if (na == 0) return LF_MKD_OK;
     if (!a || !b || !match) return fail(h, LF_MKD_ERR_BAD_ARG, "match: null pointer");
     if (nb < 2) return fail(h, LF_MKD_ERR_BAD_ARG, "match: needs at least two candidates in b (main.rs:20)");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     if (int rc = grow(h, &h->d_match_in, &h->match_in_cap, (na + nb) * kOut, sizeof(float))) return rc;
     if (int rc = grow(h, &h->d_match_out, &h->match_out_cap, na, sizeof(int))) return rc;
     LF_HIP(h, hipMemcpyAsync(h->d_match_in, a, na * kOut * 4, hipMemcpyHostToDevice, h->stream));
@@ -1534,7 +1616,7 @@ int lf_mkd_get_coarse_layer(lf_mkd *h, uint32_t layer, float *out) {
     if (!h) return LF_MKD_ERR_BAD_ARG;
     if (!h->have_image) return fail(h, LF_MKD_ERR_NO_IMAGE, "get_coarse_layer: call lf_mkd_set_image first");
     if (layer >= uint32_t(h->n_layers) || !out) return fail(h, LF_MKD_ERR_BAD_ARG, "get_coarse_layer: bad layer");
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     if (int rc = ensure_coarse_stack(h, h->stream)) return rc;
     LF_HIP(h, hipStreamSynchronize(h->stream));
     const float *src = layer == 0 ? h->d_pyr + h->pd.offset[0] : h->d_coarse + long(layer - 1) * h->layer_stride;
@@ -1551,7 +1633,7 @@ int lf_mkd_get_pyramid_level(lf_mkd *h, uint32_t level, float *out, uint32_t *w,
     if (w) *w = uint32_t(h->pd.w[level]);
     if (hgt) *hgt = uint32_t(h->pd.h[level]);
     if (!out) return LF_MKD_OK;
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     LF_HIP(h, hipStreamSynchronize(h->stream));
     LF_HIP(h, hipMemcpy2D(out, size_t(h->pd.w[level]) * 4, h->d_pyr + h->pd.offset[level], size_t(h->pd.pitch[level]) * 4,
                           size_t(h->pd.w[level]) * 4, size_t(h->pd.h[level]), hipMemcpyDeviceToHost));
@@ -1567,7 +1649,7 @@ int lf_mkd_get_pyramid_level_apron(lf_mkd *h, uint32_t level, float *out, uint32
     if (hgt) *hgt = uint32_t(h->pd.h[level]);
     if (apron) *apron = uint32_t(a);
     if (!out) return LF_MKD_OK;
-    LF_HIP(h, hipSetDevice(h->params.device));
+    LF_ENTER(h);
     LF_HIP(h, hipStreamSynchronize(h->stream));
     const float *src = h->d_pyr + h->pd.offset[level] - long(a) * h->pd.pitch[level] - a;
     LF_HIP(h, hipMemcpy2D(out, size_t(pw) * 4, src, size_t(h->pd.pitch[level]) * 4, size_t(pw) * 4, size_t(ph),

@@ -15,6 +15,7 @@
 struct lf_mkd_comm {
     ncclComm_t comm = nullptr;
     int n_ranks = 0, rank = 0, device = 0;
+    int last_form = -1;   // LF_MKD_GATHER_* the latest lf_mkd_allgather_descriptors took (RING falls back to DIRECT on unequal shards)
 };
 
 namespace {
@@ -73,6 +74,35 @@ Rccl &state() {
 const Rccl *rccl() { return state().lib ? &state() : nullptr; }
 const std::string &rccl_error() { return state().error; }
 
+// One group of point-to-point transfers, rows of 128 f32: ncclGroupStart, a Send and / or a Recv per entry (empty ones are not
+// posted), ncclGroupEnd -- always closed, also after a failed post.  The direct form of the gather and the loopback
+// diagnostic both go through here.
+struct Transfer {
+    const float *send;
+    uint64_t send_rows;
+    int dst;
+    float *recv;
+    uint64_t recv_rows;
+    int src;
+};
+int post_group(lf_mkd *h, const Rccl *r, lf_mkd_comm *c, const std::vector<Transfer> &ts, hipStream_t s) {
+    constexpr uint64_t kW = LF_MKD_DESC_LEN;
+    auto check = [&](ncclResult_t rc, const char *what) -> int {
+        if (rc == ncclSuccess) return LF_MKD_OK;
+        return lf_mkd_internal_fail(h, LF_MKD_ERR_COMM, std::string(what) + ": " + r->GetErrorString(rc));
+    };
+    if (int rc = check(r->GroupStart(), "ncclGroupStart")) return rc;
+    int first = LF_MKD_OK;
+    for (const Transfer &t : ts) {
+        if (t.send_rows && first == LF_MKD_OK)
+            first = check(r->Send(t.send, t.send_rows * kW, ncclFloat, t.dst, c->comm, s), "ncclSend");
+        if (t.recv_rows && first == LF_MKD_OK)
+            first = check(r->Recv(t.recv, t.recv_rows * kW, ncclFloat, t.src, c->comm, s), "ncclRecv");
+    }
+    const int end = check(r->GroupEnd(), "ncclGroupEnd");
+    return first != LF_MKD_OK ? first : end;
+}
+
 }  // namespace
 
 extern "C" {
@@ -95,7 +125,8 @@ int lf_mkd_comm_create(lf_mkd *h, const uint8_t *id, int32_t n_ranks, int32_t ra
         return lf_mkd_internal_fail(h, LF_MKD_ERR_BAD_ARG, "comm_create: bad identifier / rank / n_ranks");
     const Rccl *r = rccl();
     if (!r) return lf_mkd_internal_fail(h, LF_MKD_ERR_COMM, rccl_error());
-    if (hipSetDevice(lf_mkd_internal_device(h)) != hipSuccess) return lf_mkd_internal_fail(h, LF_MKD_ERR_HIP, "hipSetDevice");
+    lfmkd::DeviceScope scope;
+    if (scope.enter(lf_mkd_internal_device(h)) != hipSuccess) return lf_mkd_internal_fail(h, LF_MKD_ERR_HIP, "hipSetDevice");
     lf_mkd_comm *c = new (std::nothrow) lf_mkd_comm;
     if (!c) return LF_MKD_ERR_BAD_ARG;
     ncclUniqueId u;
@@ -117,7 +148,8 @@ int lf_mkd_comm_destroy(lf_mkd_comm *c) {
     const Rccl *r = rccl();
     int rc = LF_MKD_OK;
     if (r && c->comm) {
-        (void)hipSetDevice(c->device);
+        lfmkd::DeviceScope scope;
+        (void)scope.enter(c->device);
         if (r->CommDestroy(c->comm) != ncclSuccess) rc = LF_MKD_ERR_COMM;
     }
     delete c;
@@ -156,28 +188,42 @@ int lf_mkd_allgather_descriptors(lf_mkd *h, lf_mkd_comm *c, const uint64_t *coun
     total = off[c->n_ranks];
     if (total == 0) return LF_MKD_OK;
     if (!d_buf) return lf_mkd_internal_fail(h, LF_MKD_ERR_BAD_ARG, "allgather_descriptors: null buffer");
-    if (hipSetDevice(lf_mkd_internal_device(h)) != hipSuccess) return lf_mkd_internal_fail(h, LF_MKD_ERR_HIP, "hipSetDevice");
+    lfmkd::DeviceScope scope;
+    if (scope.enter(lf_mkd_internal_device(h)) != hipSuccess) return lf_mkd_internal_fail(h, LF_MKD_ERR_HIP, "hipSetDevice");
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : lf_mkd_internal_stream(h);
     constexpr uint64_t kW = LF_MKD_DESC_LEN;
-    auto check = [&](ncclResult_t rc, const char *what) -> int {
-        if (rc == ncclSuccess) return LF_MKD_OK;
-        return lf_mkd_internal_fail(h, LF_MKD_ERR_COMM, std::string(what) + ": " + r->GetErrorString(rc));
-    };
-    if (mode == LF_MKD_GATHER_RING && equal && counts[0] > 0)   // in place: the shard already sits at its offset
-        return check(r->AllGather(d_buf + off[c->rank] * kW, d_buf, counts[0] * kW, ncclFloat, c->comm, s), "ncclAllGather");
+    if (mode == LF_MKD_GATHER_RING && equal && counts[0] > 0) {   // in place: the shard already sits at its offset
+        const ncclResult_t rc = r->AllGather(d_buf + off[c->rank] * kW, d_buf, counts[0] * kW, ncclFloat, c->comm, s);
+        if (rc != ncclSuccess)
+            return lf_mkd_internal_fail(h, LF_MKD_ERR_COMM, std::string("ncclAllGather: ") + r->GetErrorString(rc));
+        c->last_form = LF_MKD_GATHER_RING;
+        return LF_MKD_OK;
+    }
     // direct: this rank's shard to every peer, every peer's shard from it, as one group (peer order staggered by rank so
     // that at any position of the group the pairs are disjoint)
-    if (int rc = check(r->GroupStart(), "ncclGroupStart")) return rc;
-    int first = LF_MKD_OK;
+    std::vector<Transfer> ts;
     for (int step = 1; step < c->n_ranks; ++step) {
         const int dst = (c->rank + step) % c->n_ranks, src = (c->rank - step + c->n_ranks) % c->n_ranks;
-        if (counts[c->rank] && first == LF_MKD_OK)
-            first = check(r->Send(d_buf + off[c->rank] * kW, counts[c->rank] * kW, ncclFloat, dst, c->comm, s), "ncclSend");
-        if (counts[src] && first == LF_MKD_OK)
-            first = check(r->Recv(d_buf + off[src] * kW, counts[src] * kW, ncclFloat, src, c->comm, s), "ncclRecv");
+        ts.push_back(Transfer{d_buf + off[c->rank] * kW, counts[c->rank], dst, d_buf + off[src] * kW, counts[src], src});
     }
-    const int end = check(r->GroupEnd(), "ncclGroupEnd");   // always closed, also after a failed post
-    return first != LF_MKD_OK ? first : end;
+    c->last_form = LF_MKD_GATHER_DIRECT;
+    return post_group(h, r, c, ts, s);
 }
+
+int lf_mkd_comm_loopback(lf_mkd *h, lf_mkd_comm *c, const float *d_src, float *d_dst, uint64_t n_rows, void *stream) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    if (!c) return lf_mkd_internal_fail(h, LF_MKD_ERR_BAD_ARG, "comm_loopback: null communicator");
+    if (n_rows && (!d_src || !d_dst)) return lf_mkd_internal_fail(h, LF_MKD_ERR_BAD_ARG, "comm_loopback: null buffer");
+    if (n_rows && d_src == d_dst) return lf_mkd_internal_fail(h, LF_MKD_ERR_BAD_ARG, "comm_loopback: source and destination must differ");
+    const Rccl *r = rccl();
+    if (!r) return lf_mkd_internal_fail(h, LF_MKD_ERR_COMM, rccl_error());
+    lfmkd::DeviceScope scope;
+    if (scope.enter(lf_mkd_internal_device(h)) != hipSuccess) return lf_mkd_internal_fail(h, LF_MKD_ERR_HIP, "hipSetDevice");
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : lf_mkd_internal_stream(h);
+    // (n_rows == 0: an empty group, as the gather posts for a rank whose peers all hold nothing)
+    return post_group(h, r, c, {Transfer{d_src, n_rows, c->rank, d_dst, n_rows, c->rank}}, s);
+}
+
+int lf_mkd_comm_last_form(const lf_mkd_comm *c) { return c ? c->last_form : -1; }
 
 }  // extern "C"

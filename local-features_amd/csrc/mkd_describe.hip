@@ -433,9 +433,8 @@ __device__ __forceinline__ void blur_row_impl(const unsigned char *ring_lane, Sl
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
         // (the first tap as an fma onto +0.0: the same bits as the product for every non-zero result, and +0.0 where the
-        //  product would be -0.0 -- a blurred value is then never -0.0, so neither is gx = left - right, and the sign bit
-        //  gradient_direction takes from gx is never the sign of a zero: the shader's (cos, sin) = (1, 0) at gx == -0.0,
-        //  atan2.glsl:29-45, at no instruction's cost)
+        //  factor is -0.0.  A product of a negative denormal that underflows still rounds to -0.0 -- the caller normalises
+        //  gx itself, see "left - right" in the row loop)
         float s = ablate::kMulFirstTap ? kB0 * ext[x] : fmaf(kB0, ext[x], 0.0f);
         s = fmaf(kB1, ext[x + 1], s);
         s = fmaf(kB2, ext[x + 2], s);
@@ -1237,7 +1236,10 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
                     const int x = 2 * e;
                     const f32x2 left = {x == 0 ? cur_l : cur[x - 1], cur[x]};
                     const f32x2 right = {cur[x + 1], x == 6 ? cur_r : cur[x + 2]};
-                    gx[e] = left - right;                                               // left - right
+                    // left - right, plus +0.0: the value unchanged, but -0.0 (a blurred -0.0 on the left of a +0.0 -- the blur of
+                    // negative denormals underflows to it, fma or not) becomes +0.0, so that the sign bit gradient_direction
+                    // takes from gx is never the sign of a zero: the shader's (cos, sin) = (1, 0) at gx == -0.0, atan2.glsl:29-45
+                    gx[e] = (left - right) + pk_set(0.0f);
                     gy[e] = f32x2{nxt[x], nxt[x + 1]} - f32x2{prv[x], prv[x + 1]};      // down - up
                     r2n[e] = pk_fma(gy[e], gy[e], gx[e] * gx[e]);
                     const f32x2 r2 = r2n[e] + pk_set(1e-8f);

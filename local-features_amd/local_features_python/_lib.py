@@ -32,6 +32,7 @@ SYMBOLS = (
     "lf_mkd_match", "lf_mkd_match_device", "lf_mkd_match_both_device", "lf_mkd_match_overflowed", "lf_mkd_stream_create", "lf_mkd_stream_frame",
     "lf_mkd_detect_frames_device", "lf_mkd_orient_keypoints_blocked",
     "lf_mkd_comm_unique_id", "lf_mkd_comm_create", "lf_mkd_comm_destroy", "lf_mkd_comm_info", "lf_mkd_allgather_descriptors",
+    "lf_mkd_comm_loopback", "lf_mkd_comm_last_form",
 )
 COMM_ID_BYTES = 128
 GATHER_DIRECT, GATHER_RING = 0, 1
@@ -126,6 +127,8 @@ def load_library():
     L.lf_mkd_comm_destroy.argtypes = [vp]
     L.lf_mkd_comm_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.lf_mkd_allgather_descriptors.argtypes = [vp, vp, vp, vp, i32, vp]
+    L.lf_mkd_comm_loopback.argtypes = [vp, vp, vp, vp, u64, vp]
+    L.lf_mkd_comm_last_form.argtypes = [vp]
     L.lf_mkd_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(u64)]
     _lib = L
@@ -167,6 +170,16 @@ class Comm:
         self.calls += 1
         self.handle._device_call(stream, lambda s: self.handle.L.lf_mkd_allgather_descriptors(
             self.handle._h, self._c, arr, d_buf, mode, s), "lf_mkd_allgather_descriptors")
+
+    def loopback(self, d_src, d_dst, n_rows, stream=None):
+        """n_rows descriptors from d_src to this very rank and back into d_dst: one group of ncclSend + ncclRecv through
+        the posting routine of the direct gather (lf_mkd_comm_loopback)."""
+        self.handle._device_call(stream, lambda s: self.handle.L.lf_mkd_comm_loopback(
+            self.handle._h, self._c, d_src, d_dst, n_rows, s), "lf_mkd_comm_loopback")
+
+    def last_form(self):
+        """GATHER_DIRECT / GATHER_RING as the latest gather ran (-1: none yet)"""
+        return self.handle.L.lf_mkd_comm_last_form(self._c)
 
     def close(self):
         if self._c is not None:

@@ -144,8 +144,10 @@ def assert_patch_parity(oracle, patches, desc, atan_mode, gate=GATE, what="", mi
     return worst
 
 
-def assert_keypoint_parity(oracle, handle, img, kps5, desc, gate=GATE, what="", patch_tol=1e-5, min_settled=0.97):
-    """desc = the library's descriptors of keypoints kps5 [n,5] on img (already set on `handle`).
+def assert_keypoint_parity(oracle, handle, img, kps5, desc, gate=GATE, what="", patch_tol=1e-5, min_settled=0.97,
+                           patch_scale_factor=24.0):
+    """desc = the library's descriptors of keypoints kps5 [n,5] on img (already set on `handle`, which was created with
+    this patch_scale_factor).
     patch_tol: the sampling positions of the two sides differ by ~1e-5 texel (different libm sin/cos/exp2); on smooth
     test frames that is 1e-6 in the sampled values, on a sharp photograph up to the local gradient times that."""
     import torch
@@ -161,7 +163,7 @@ def assert_keypoint_parity(oracle, handle, img, kps5, desc, gate=GATE, what="", 
     handle.sample_patches_device(d_k.data_ptr(), n, d_p.data_ptr())
     handle.synchronize()
     got_p = d_p.cpu().numpy()
-    ref_p = oracle.sample_patches(oracle.build_pyramid(img), w, hgt, kps5[:, :4])
+    ref_p = oracle.sample_patches(oracle.build_pyramid(img), w, hgt, kps5[:, :4], patch_scale_factor)
     assert np.abs(got_p - ref_p).max(initial=0.0) < patch_tol, (what, "sampled patches", np.abs(got_p - ref_p).max())
     assert_patch_parity(oracle, got_p, desc, ATAN_SHADER, gate, what + " (describe stage, GPU-sampled bits)", min_settled)
     clean_ref, _, ref_s, q_ref, r_ref = settled_detail(oracle, ref_p, ATAN_SHADER, gate)

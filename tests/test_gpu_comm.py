@@ -50,6 +50,40 @@ def test_one_rank_communicator_both_gather_forms(lfp, torch):
     comm.close()
 
 
+def test_loopback_drives_the_grouped_send_recv_branch_on_one_rank(lfp, torch):
+    """The DIRECT form of the gather is one group of ncclSend / ncclRecv per peer -- a loop that is empty on a one-rank
+    communicator, so that before round 6 those four bound symbols, their argument order and units had never met a real
+    librccl.  lf_mkd_comm_loopback posts the same group through the same routine with this rank as its own peer (a self
+    send/recv inside a group is legal): the rows must arrive, for no rows (the empty group), one row and the per-GPU share of
+    BASELINE configs[3] (2^20 rows = 512 MiB), on the handle's own stream and on a caller's, repeatedly on one communicator,
+    and with the gather itself before and after."""
+    h = lfp.MkdHandle(max_features=64)
+    comm = lfp.Comm(h, lfp.comm_unique_id(), 1, 0)
+    assert comm.last_form() == -1
+    g = torch.Generator(device="cuda").manual_seed(11)
+    side = torch.cuda.Stream()
+    for rnd, n in enumerate((0, 1, 1 << 20, 777, 1)):
+        src = torch.randn((max(n, 1), 128), device="cuda", generator=g)
+        dst = torch.full((max(n, 1) + 2, 128), -7.0, device="cuda")            # guard rows before and after
+        torch.cuda.synchronize()
+        stream = side.cuda_stream if rnd % 2 else None
+        comm.loopback(src.data_ptr(), dst[1:].data_ptr(), n, stream)
+        if stream:
+            side.synchronize()
+        assert torch.equal(dst[1:1 + n], src[:n]), n
+        assert bool((dst[0] == -7.0).all()) and bool((dst[1 + n:] == -7.0).all()), n      # exactly n rows were written
+        if n == 777:      # a gather on the same communicator in between leaves it usable
+            comm.allgather_descriptors(src.data_ptr(), [n], lfp.GATHER_DIRECT)
+            assert comm.last_form() == lfp.GATHER_DIRECT
+            comm.allgather_descriptors(src.data_ptr(), [n], lfp.GATHER_RING)
+            assert comm.last_form() == lfp.GATHER_RING
+    with pytest.raises(RuntimeError, match="differ"):
+        comm.loopback(src.data_ptr(), src.data_ptr(), 1)
+    with pytest.raises(RuntimeError, match="null buffer"):
+        comm.loopback(0, 0, 5)
+    comm.close()
+
+
 def test_cross_image_match_over_the_boundary_transport(lfp, torch):
     """sharding.cross_image_match with a communicator of the C boundary (world of one): torch.distributed carries the
     identifier only, the gather is lf_mkd_allgather_descriptors, the result the plain match with own-image exclusion."""

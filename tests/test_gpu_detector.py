@@ -220,7 +220,8 @@ def test_detect_recorded_stepwise_and_u8_return_the_same_bits(lfp, torch, oracle
     """Round 5: lf_mkd_detect is one upload + ONE hipGraph launch recorded per (frame size, top_n, min_size, max_out, pixel
     type), and lf_mkd_detect_u8 takes the 8-bit frame (1 B/px over PCIe, (float)v / 255.0f on the device).  All of them must
     return the bits of the stage-by-stage form the call had before (LF_MKD_FLAG_DETECT_STEPWISE keeps it): keypoints,
-    descriptors and both dropped counters, on the first call (recording) and on later ones (replay), for aligned frames (the
+    descriptors and both dropped counters, on the first call (served stage by stage since round 6), the second (recording)
+    and on later ones (replay), for aligned frames (the
     staged level-0 kernel) and odd ones (the unaligned kernel), with and without the top-n filter, with an output capacity
     that cuts the list, and with more distinct requests than the handle keeps recordings for."""
     u8, f32 = _u8_frame(w, hgt, 11, blobs)
@@ -233,7 +234,7 @@ def test_detect_recorded_stepwise_and_u8_return_the_same_bits(lfp, torch, oracle
         for top_n, min_size, cap in requests:
             want = ref.detect(f32, top_n, min_size, cap)
             assert len(want[0]) > 0
-            for img in (f32, u8, f32):
+            for img in (f32, u8, f32, u8, f32):           # per pixel type: first sighting, recording, [replay]
                 got = rec.detect(img, top_n, min_size, cap)
                 assert got[2:] == want[2:], (top_n, min_size, cap, got[2:], want[2:])
                 assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (rnd, top_n, min_size, cap, img.dtype)
@@ -295,7 +296,7 @@ def test_banded_upload_returns_the_unbanded_bits(lfp, oracle, monkeypatch, w, hg
         else:
             monkeypatch.setenv("LF_MKD_BAND_SPLIT", frac)
         h = lfp.MkdHandle(**kw)                                  # (the cut is fixed when a request is first recorded)
-        for img in (f32, u8, f32):
+        for img in (f32, u8, f32, u8, f32):                      # per pixel type: first sighting (stage by stage), recording, [replay]
             for top_n in (0, 700):
                 got = h.detect(img, top_n, 0.0, 20000)
                 exp = want if top_n == 0 else ref.detect(f32, top_n, 0.0, 20000)
@@ -314,7 +315,10 @@ def test_detect_recordings_survive_the_handles_other_uses(lfp, oracle):
     w, hgt = 640, 480
     u8, f32 = _u8_frame(w, hgt, 5, 1200)
     h = lfp.MkdHandle(max_features=300, max_image_width=w, max_image_height=hgt, max_blobs=512)
-    first = h.detect(u8, 100, 0.0, 300)
+    first = h.detect(u8, 100, 0.0, 300)            # first sighting: stage by stage
+    for _ in range(2):                             # recording, replay
+        again = h.detect(u8, 100, 0.0, 300)
+        assert again[2:] == first[2:] and np.array_equal(again[0], first[0]) and np.array_equal(again[1], first[1])
     assert len(first[0]) > 50
     # the frame is loaded: every extremum of it, oriented in one call -- far more than top_n = 100 sized the scratch for
     ex, _ = h.detect_extrema(max_out=1 << 15)
@@ -326,8 +330,11 @@ def test_detect_recordings_survive_the_handles_other_uses(lfp, oracle):
     # a larger capacity (new result staging), then the first request once more
     big = h.detect(f32, 0, 0.0, 5000)
     assert len(big[0]) > len(first[0])
-    again = h.detect(f32, 100, 0.0, 300)
-    assert again[2:] == first[2:] and np.array_equal(again[0], first[0]) and np.array_equal(again[1], first[1])
+    big2 = h.detect(f32, 0, 0.0, 5000)             # (recorded now)
+    assert np.array_equal(big2[0], big[0]) and np.array_equal(big2[1], big[1])
+    for _ in range(3):
+        again = h.detect(f32, 100, 0.0, 300)
+        assert again[2:] == first[2:] and np.array_equal(again[0], first[0]) and np.array_equal(again[1], first[1])
     # matching and patch description in between do not disturb it either
     assert h.match(first[1], big[1]).shape == (len(first[1]),)
     assert h.describe_patches(np.random.default_rng(1).random((70, 32, 32)).astype(np.float32)).shape == (70, 128)
@@ -539,13 +546,14 @@ def test_handle_lifecycle_does_not_leak(lfp, torch, monkeypatch):
             free0 = torch.cuda.mem_get_info()[0]
         h = lfp.MkdHandle(max_features=512, max_image_width=w, max_image_height=hgt, max_blobs=512, max_frames=2,
                           pool_mode=lfp.POOL_F16X3 if rep % 2 else lfp.POOL_F32)
-        kps, desc, _, _ = h.detect(img, 100 if rep % 3 else 0, 0.0)
+        for _ in range(3):       # first sighting (stage by stage), recording, replay
+            kps, desc, _, _ = h.detect(img, 100 if rep % 3 else 0, 0.0)
         assert len(kps) > 20
         if rep % 4 == 1:      # more request shapes than the handle keeps recordings for (banded ones among them), 8-bit frames too
             monkeypatch.setenv("LF_MKD_BAND_SPLIT", "0.5")
             u8 = np.ascontiguousarray(np.rint(img * 255).astype(np.uint8))
-            for t in range(11):
-                assert len(h.detect(u8 if t % 2 else img, 20 + t, 0.0)[0]) > 10
+            for t in range(22):
+                assert len(h.detect(u8 if (t // 2) % 2 else img, 20 + t // 2, 0.0)[0]) > 10
             monkeypatch.delenv("LF_MKD_BAND_SPLIT")
         h.set_image(img)
         ex, _ = h.detect_extrema()

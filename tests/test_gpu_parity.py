@@ -505,7 +505,24 @@ def test_negative_zero_pixels_take_the_shaders_angle(lfp, oracle):
     d[4:16, 12:24] = 0.0
     e = np.where(rng.random((32, 32)) < 0.5, np.float32(-0.0), np.float32(0.0)).astype(np.float32)
     e[20:, :] = tex[20:, :]
-    p = np.stack([a, b, c, d, e]).astype(np.float32)
+    # The advisor's round-5 case: negative denormals whose products underflow to -0.0 whether the tap is a multiply or an fma.
+    # With the kernel's arithmetic (worked through in an f64 emulation of its two passes) these three column patterns leave
+    # out[x-1] = -0.0 beside out[x+1] = +0.0, i.e. gx = -0.0, on every row of the zeroed block, at x = 0, 10 and 20:
+    #   column 2 = -1.4e-45 (the left border: taps 0..2 of x = 0 sit on the replicated column 0);
+    #   column 10 = -1.4e-45 beside column 11 = -0.0;  column 20 = -2.8e-45 beside column 21 = -0.0
+    # (the vertical pass keeps a column of -0.0 as -0.0 -- its first tap is a multiply -- where the oracle's fma onto +0.0 gives
+    # +0.0: zeros of either sign must describe the same).
+    f = tex.copy()
+    f[:22, :] = 0.0
+    f[:22, 2] = -1.4e-45
+    f[:22, 10], f[:22, 11] = -1.4e-45, -0.0
+    f[:22, 20], f[:22, 21] = -2.8e-45, -0.0
+    g = np.ascontiguousarray(f.T)
+    p = np.stack([a, b, c, d, e, f, g]).astype(np.float32)
+    assert (p[5:] < 0).any() and np.float32(0.2054) * p[5:].min() == 0      # (and numpy kept the denormals)
+    # (Not covered, by design: gradients whose larger component is a DENORMAL below 1e-30 -- the kernel's direction is then
+    #  a = min / max(larger, 1e-30), the shader's min / larger; such pixels need pixel values of ~1e-30 and do not occur in
+    #  frames of [0, 1]; lf_mkd.h states the domain.)
     assert np.signbit(p).any()
     ref = oracle.describe_patches(p, atan_mode=ATAN_SHADER | BLUR_CONTRACT)
     for pool in (lfp.POOL_F32, lfp.POOL_F16X3):
