@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -46,6 +47,9 @@ struct lf_mkd {
     uint64_t kps_out_cap = 0;
     unsigned long long *d_totals = nullptr;
     unsigned long long *d_clk = nullptr;       // LF_MKD_FLAG_KERNEL_TIMING: clock stamps of the latest describe launch
+    // the row-split form of the keypoint kernel (requests of at most 16 x CUs keypoints): partial sums and their counters
+    float *d_kp_xchg = nullptr;
+    unsigned *d_kp_words = nullptr;
     // detector scratch (allocated on first use): per-cube slots and counts for max_frames frames of the maximum size
     uint64_t max_extrema = 8192;
     float *d_slots = nullptr, *d_det_extrema = nullptr, *d_det_selected = nullptr, *d_det_desc = nullptr;
@@ -70,12 +74,13 @@ struct lf_mkd {
         bool u8 = false;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-        // banded form (frames large enough to be worth it): the frame is uploaded in two pieces, rows [0, band_rows) first;
-        // `head` is the share of the pipeline's front those rows allow (RowBands part 0) and runs while the second piece is on
-        // its way, `graph` is then part 1 + everything else
-        uint32_t band_rows = 0;
-        hipGraph_t head_graph = nullptr;
-        hipGraphExec_t head = nullptr;
+        // banded form (frames large enough to be worth it): the frame is uploaded in pieces, rows [0, cuts[0]) first, then
+        // [cuts[0], cuts[1]) ...; heads[p] is the share of the pipeline's front the frame's first cuts[p] rows allow beyond
+        // heads[p - 1]'s (RowBands) and runs while piece p + 1 is on its way, `graph` is then the last piece's share +
+        // everything else
+        std::vector<uint32_t> cuts;
+        std::vector<hipGraph_t> head_graphs;
+        std::vector<hipGraphExec_t> heads;
         PyramidDesc pd{};
     };
     std::vector<DetectPlan> plans;
@@ -103,7 +108,7 @@ struct lf_mkd {
     lf_mkd_keypoint *h_res_kps = nullptr;
     uint64_t h_res_cap = 0;
     hipStream_t copy_stream = nullptr;                    // the banded upload: pieces are copied here, the pipeline's parts wait for them
-    hipEvent_t copy_ev[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> copy_ev;
     hipEvent_t det_ev[3] = {nullptr, nullptr, nullptr};   // LF_MKD_FLAG_KERNEL_TIMING: before the upload, after it, after the pipeline
     double det_upload_ms = 0, det_pipeline_ms = 0, det_readback_ms = 0;
     // matcher scratch
@@ -271,6 +276,11 @@ int create_impl(const lf_mkd_params *params, const PcaModel &pca, lf_mkd **out) 
         LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_tmp_a), px * 4));
         LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_tmp_b), px * 4));
         LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_pyr), size_t(h->pyr_stride) * h->max_frames * 4));
+        if (h->params.pool_mode == LF_MKD_POOL_F16X3 && !(h->params.flags & LF_MKD_FLAG_UNFUSED_KEYPOINTS)) {
+            LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_kp_xchg), kp_split_exchange_bytes(h->num_cus)));
+            LF_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_kp_words), kp_split_counter_words(h->num_cus) * 4));
+            LF_CREATE_HIP(hipMemset(h->d_kp_words, 0, kp_split_counter_words(h->num_cus) * 4));
+        }
     }
 #undef LF_CREATE_HIP
     *out = h;
@@ -342,7 +352,8 @@ int describe_keypoints_on_device(lf_mkd *h, const float *d_kps, const uint32_t *
     if (fused_keypoints(h)) {
         if (int rc = mark(h, s)) return rc;
         launch_describe_keypoints(h->d_pyr, h->pyr_stride, h->pd, d_kps, d_frame_of, h->n_frames, long(n), nullptr,
-                                  h->params.patch_scale_factor, h->dc, h->params.angle_mode, d_out, h->num_cus, s, h->d_clk);
+                                  h->params.patch_scale_factor, h->dc, h->params.angle_mode, d_out, h->num_cus, s, h->d_clk,
+                                  h->d_kp_xchg, h->d_kp_words);
         LF_HIP(h, hipGetLastError());
         return mark(h, s);
     }
@@ -357,6 +368,17 @@ int describe_keypoints_on_device(lf_mkd *h, const float *d_kps, const uint32_t *
     return LF_MKD_OK;
 }
 
+void destroy_plan(lf_mkd::DetectPlan &p) {
+    if (p.exec) (void)hipGraphExecDestroy(p.exec);
+    if (p.graph) (void)hipGraphDestroy(p.graph);
+    for (hipGraphExec_t e : p.heads) (void)hipGraphExecDestroy(e);
+    for (hipGraph_t g : p.head_graphs) (void)hipGraphDestroy(g);
+    p.exec = nullptr;
+    p.graph = nullptr;
+    p.heads.clear();
+    p.head_graphs.clear();
+}
+
 // A recorded stream pipeline holds raw pointers into the scratch buffers: re-allocating one of them retires the graph
 // (lf_mkd_stream_frame then asks for a new lf_mkd_stream_create instead of touching freed memory).
 void retire_graph(lf_mkd *h) {
@@ -365,12 +387,7 @@ void retire_graph(lf_mkd *h) {
     if (h->graph) (void)hipGraphDestroy(h->graph);
     h->graph_exec = nullptr;
     h->graph = nullptr;
-    for (auto &p : h->plans) {       // lf_mkd_detect's recordings hold the same raw pointers: the next call records anew
-        if (p.exec) (void)hipGraphExecDestroy(p.exec);
-        if (p.graph) (void)hipGraphDestroy(p.graph);
-        if (p.head) (void)hipGraphExecDestroy(p.head);
-        if (p.head_graph) (void)hipGraphDestroy(p.head_graph);
-    }
+    for (auto &p : h->plans) destroy_plan(p);   // lf_mkd_detect's recordings hold the same raw pointers: the next call records anew
     h->plans.clear();
 }
 
@@ -508,6 +525,131 @@ int orient_device(lf_mkd *h, const float *d_extrema, const uint32_t *d_frame_of,
     return LF_MKD_OK;
 }
 
+// ---- the banded upload's plan (lf_mkd_detect / lf_mkd_detect_u8 on large frames) --------------------------------------
+// Stage rows [lo, hi) of piece p of a frame cut at raw rows cuts[0] < cuts[1] < ... < h (the last piece ends at h).
+bool piece_bands(const std::vector<uint32_t> &cuts, size_t p, int w, int hgt, int n_layers, RowBands &b) {
+    RowBands lo{}, hi{};
+    if (p > 0 && !plan_row_bands(int(cuts[p - 1]), w, hgt, n_layers, kBorder, lo)) return false;
+    const bool last = p == cuts.size();
+    if (!last && !plan_row_bands(int(cuts[p]), w, hgt, n_layers, kBorder, hi)) return false;
+    b = RowBands{};
+    b.last = last ? 1 : 0;
+    b.level0_lo = lo.level0_hi;
+    b.level0_hi = last ? hgt : hi.level0_hi;
+    for (int l = 0; l < 8; ++l) {
+        b.layer_lo[l] = lo.layer_hi[l];
+        b.layer_hi[l] = last ? hgt : hi.layer_hi[l];
+    }
+    b.scan_lo = lo.scan_hi;
+    b.scan_hi = last ? (hgt - 2 * kBorder + 7) / 8 : hi.scan_hi;
+    return true;
+}
+
+// What the pieces cost, from this chip's timelines of the reference benchmark's frame (4096 x 3072; profiles/r06_bands.md):
+// picoseconds per pixel of a stage's rows plus a floor per launch; the link's rate for a copy from pageable memory and what
+// an extra piece costs the link: ~11 us per copy call (r05_upload_probe.txt) + ~15 us in which the host, blocked in the
+// copy until then, records the event and launches the head (LF_MKD_BAND_TRACE prints the calls' host times).
+struct FrontModel {
+    double sep3 = 2.3, swt = 1.7, swt_deep = 2.3, floor_us = 5.0, link_gb_s = 56.0, gap_us = 26.0;
+    double scan(int n_fine) const { return std::max(3.25 * n_fine - 6.85, 2.0); }
+};
+// Modelled time (us) at which the device is through with the front's share of pieces 0 .. n_pieces-1 of a frame cut at
+// `cuts` (n_pieces = cuts.size() + 1: the whole front); *link_us: when the last of these pieces has arrived.
+double front_finish_us(const std::vector<uint32_t> &cuts, size_t n_pieces, int w, int hgt, int bpp, int n_layers,
+                       const FrontModel &m, double *link_us = nullptr) {
+    const double row_us = double(w) * bpp / (m.link_gb_s * 1e3);
+    double t_link = 0, t_dev = 0;
+    uint32_t from = 0;
+    for (size_t p = 0; p < n_pieces; ++p) {
+        const uint32_t to = p < cuts.size() ? cuts[p] : uint32_t(hgt);
+        t_link += (p ? m.gap_us : 0.0) + double(to - from) * row_us;
+        from = to;
+        RowBands b;
+        if (!piece_bands(cuts, p, w, hgt, n_layers, b)) return 1e30;
+        double head = 0;
+        auto add = [&](int rows, double ps) {
+            if (rows > 0) head += m.floor_us + double(rows) * w * ps * 1e-6;
+        };
+        add(b.level0_hi - b.level0_lo, m.sep3);
+        for (int l = 0; l + 1 < n_layers; ++l) add(b.layer_hi[l] - b.layer_lo[l], (1 << l) > 32 ? m.swt_deep : m.swt);
+        add((b.scan_hi - b.scan_lo) * 8, m.scan(n_layers - 1));
+        t_dev = std::max(t_dev, t_link) + head;
+    }
+    if (link_us) *link_us = t_link;
+    return t_dev;
+}
+
+// Where to cut a frame of `bpp` bytes per pixel.  Candidates: k equal pieces, and plans in which every piece after the first
+// is sized so that its upload ends when the device is through with the pieces before it (the link and the device both stay
+// busy) -- an 8-bit frame, whose front takes longer than its upload, comes out as a small first piece and growing ones after
+// it; an f32 frame, four times the bytes, as a large first piece and shrinking ones, so that little is left to do when the
+// last byte lands.  The candidate with the earliest modelled finish wins; no cuts (one piece) unless it is ahead by 4 %.
+// LF_MKD_DETECT_BANDS=0: one piece.  LF_MKD_BAND_SPLIT=f1[,f2..]: cuts at these fractions of the height;
+// LF_MKD_BAND_PIECES=k: k equal pieces -- both whatever the frame's size (tests, A/B runs).
+std::vector<uint32_t> plan_cuts(const lf_mkd *h, uint32_t width, uint32_t height, bool u8) {
+    const std::vector<uint32_t> none;
+    const int w = int(width), hgt = int(height), bpp = u8 ? 1 : 4;
+    RowBands probe;
+    if (h->pd.levels < 2 || height < 64 || !plan_row_bands(int(height) / 2 / 4 * 4, w, hgt, h->n_layers, kBorder, probe)) return none;
+    // cuts on multiples of four rows, at least 16 rows from either end, strictly increasing
+    auto valid = [&](std::vector<uint32_t> &c) {
+        for (auto &r : c) r = std::min<uint32_t>(std::max<uint32_t>(r, 16), height - 16) / 4 * 4;
+        c.erase(std::unique(c.begin(), c.end()), c.end());
+        for (size_t i = 0; i < c.size(); ++i)
+            if (c[i] >= height || (i && c[i] <= c[i - 1])) return false;
+        return !c.empty();
+    };
+    const char *env_b = getenv("LF_MKD_DETECT_BANDS"), *env_f = getenv("LF_MKD_BAND_SPLIT"), *env_k = getenv("LF_MKD_BAND_PIECES");
+    auto equal_pieces = [&](int k) {
+        std::vector<uint32_t> c;
+        for (int i = 1; i < k; ++i) c.push_back(uint32_t(uint64_t(height) * i / k));
+        return c;
+    };
+    if (env_f) {
+        std::vector<uint32_t> c;
+        for (const char *q = env_f; *q;) {
+            char *end = nullptr;
+            const double f = strtod(q, &end);
+            if (end == q) break;
+            c.push_back(uint32_t(double(height) * std::min(std::max(f, 0.0), 1.0)));
+            q = *end == ',' ? end + 1 : end;
+        }
+        std::sort(c.begin(), c.end());
+        return valid(c) ? c : none;
+    }
+    if (env_k) {
+        std::vector<uint32_t> c = equal_pieces(std::min(std::max(atoi(env_k), 1), 16));
+        return valid(c) ? c : none;
+    }
+    if ((env_b && env_b[0] == '0') || uint64_t(width) * height * bpp < 6000000ull) return none;
+    const FrontModel m;
+    const double row_us = double(w) * bpp / (m.link_gb_s * 1e3);
+    std::vector<uint32_t> best;
+    double best_t = front_finish_us(none, 1, w, hgt, bpp, h->n_layers, m) * 0.96;
+    auto consider = [&](std::vector<uint32_t> c) {
+        if (!valid(c)) return;
+        const double t = front_finish_us(c, c.size() + 1, w, hgt, bpp, h->n_layers, m);
+        if (t < best_t) {
+            best_t = t;
+            best = c;
+        }
+    };
+    for (int k = 2; k <= 6; ++k) consider(equal_pieces(k));
+    for (int i = 1; i <= 14; ++i) {             // first piece = i / 16 of the frame, the others by the recurrence
+        std::vector<uint32_t> c{uint32_t(uint64_t(height) * i / 16)};
+        while (c.size() < 6 && valid(c)) {
+            consider(c);
+            // the next piece: as many rows as the link delivers while the device works off the pieces so far
+            double t_link = 0;
+            const double t_dev = front_finish_us(c, c.size(), w, hgt, bpp, h->n_layers, m, &t_link);
+            const uint32_t rows = uint32_t(std::max((t_dev - t_link - m.gap_us) / row_us, double(height) / 16));
+            if (c.back() + rows + height / 16 >= height) break;
+            c.push_back(c.back() + rows);
+        }
+    }
+    return best;
+}
+
 }  // namespace
 
 int lf_mkd_internal_device(const lf_mkd *h) { return h->params.device; }
@@ -574,17 +716,12 @@ void lf_mkd_destroy(lf_mkd *h) {
                     h->d_match_part,   h->d_match_in,    h->d_match_out,   h->d_mf_padded,   h->d_mf_list,
                     h->d_mf_frame_start, h->d_mf_offsets, h->d_mf_frame_of,
                     h->d_match_rec,    h->d_match_cnt,   h->d_match_norm,  h->d_match_misc,
-                    h->d_match_few_tiles, h->d_match_few};
+                    h->d_match_few_tiles, h->d_match_few, h->d_kp_xchg, h->d_kp_words};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
-    for (auto &p : h->plans) {
-        if (p.exec) (void)hipGraphExecDestroy(p.exec);
-        if (p.graph) (void)hipGraphDestroy(p.graph);
-        if (p.head) (void)hipGraphExecDestroy(p.head);
-        if (p.head_graph) (void)hipGraphDestroy(p.head_graph);
-    }
+    for (auto &p : h->plans) destroy_plan(p);
     for (hipEvent_t e : h->copy_ev)
         if (e) (void)hipEventDestroy(e);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -821,6 +958,14 @@ int lf_mkd_describe_keypoints(lf_mkd *h, const lf_mkd_keypoint *kps, uint64_t n,
         LF_HIP(h, hipMemcpyAsync(out + off * kOut, h->d_out, m * kOut * 4, hipMemcpyDeviceToHost, h->stream));
         LF_HIP(h, hipStreamSynchronize(h->stream));
     }
+    if (h->d_kp_words) {   // the row-split form counts partial sums that never reached their consumer (none, ever: a fault if so)
+        unsigned lost = 0;
+        LF_HIP(h, hipMemcpy(&lost, h->d_kp_words, 4, hipMemcpyDeviceToHost));
+        if (lost) {
+            (void)hipMemset(h->d_kp_words, 0, kp_split_counter_words(h->num_cus) * 4);
+            return fail(h, LF_MKD_ERR_HIP, "describe_keypoints: " + std::to_string(lost) + " partial sums of the row-split form did not arrive");
+        }
+    }
     return LF_MKD_OK;
 }
 
@@ -1006,7 +1151,7 @@ static int record_pipeline(lf_mkd *h, uint32_t width, uint32_t height, uint32_t 
     const uint64_t cap = top_n ? top_n : h->max_extrema;   // extrema that can reach orientation
     // the detector needs pyramid level 0 and a-trous layer 1 only: the other levels (read by the sampler at the very end)
     // are a branch of the graph beside the a-trous stack, the scan, the selection and the orientation
-    const bool head_only = bands && bands->part == 0;       // (the first band's share: the front's kernels on its rows, nothing else)
+    const bool head_only = bands && !bands->last;           // (a piece's share: the front's kernels on its rows, nothing else)
     const bool fork = h->pd.levels >= 2 && !head_only;
     if (fork)
         if (int rc = ensure_side_stream(h, 2)) return rc;
@@ -1054,7 +1199,7 @@ static int record_pipeline(lf_mkd *h, uint32_t width, uint32_t height, uint32_t 
     if (fused_keypoints(h)) {
         launch_describe_keypoints(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr, 1,
                                   long(max_out), cnt + 3, h->params.patch_scale_factor, h->dc, h->params.angle_mode,
-                                  d_descriptors, h->num_cus, s);
+                                  d_descriptors, h->num_cus, s, nullptr, h->d_kp_xchg, h->d_kp_words);
     } else {
         launch_sample_patches(h->d_pyr, h->pyr_stride, h->pd, reinterpret_cast<const float *>(d_keypoints), nullptr, 1,
                               long(max_out), cnt + 3, h->params.patch_scale_factor, h->d_stream_patches, s);
@@ -1193,79 +1338,99 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
             for (size_t i = 1; i < h->plans.size(); ++i)
                 if (h->plans[i].stamp < h->plans[old].stamp) old = i;
             LF_HIP(h, hipStreamSynchronize(s));
-            (void)hipGraphExecDestroy(h->plans[old].exec);
-            (void)hipGraphDestroy(h->plans[old].graph);
-            if (h->plans[old].head) (void)hipGraphExecDestroy(h->plans[old].head);
-            if (h->plans[old].head_graph) (void)hipGraphDestroy(h->plans[old].head_graph);
+            destroy_plan(h->plans[old]);
             h->plans.erase(h->plans.begin() + long(old));
         }
         lf_mkd::DetectPlan p;
         p.w = width; p.h = height; p.top_n = top_n; p.min_size_bits = ms_bits; p.max_out = max_out; p.u8 = u8;
         p.pd = h->pd;
-        // Large frames go over PCIe in two pieces, and the pipeline's front runs on the first piece's rows while the second is
-        // on its way (RowBands).  Where to cut: the first piece's share of the front (~0.6 of the pipeline) should take as long
-        // as the second piece's upload -- an 8-bit frame uploads in about the time the front takes (cut in the middle), an f32
-        // frame in four times that (cut at three quarters); a deep a-trous stack (n_scales 5: dilation 64, tiles of 768 rows)
-        // needs a later cut before its last layer gets any rows.  Worth it from about 12 MB of upload (the reference's
-        // houses.jpg sweep: an 8-bit frame of 7 MP gains nothing, an f32 frame of 3 MP gains 6 %, the 12.6 MP frame 8 % either
-        // way; a second copy costs ~25 us by itself).  LF_MKD_DETECT_BANDS=0: one piece; LF_MKD_BAND_SPLIT=fraction: that cut,
-        // whatever the size (tests).
-        RowBands bands{};
-        const char *env_b = getenv("LF_MKD_DETECT_BANDS"), *env_f = getenv("LF_MKD_BAND_SPLIT");
-        const bool want_bands = env_f || (uint64_t(width) * height * (u8 ? 1 : 4) >= 12000000ull && !(env_b && env_b[0] == '0'));
-        uint32_t cut = 0;
-        bool banded = false;
-        for (double frac = env_f ? atof(env_f) : (u8 ? 0.5 : 0.75); want_bands && !banded && h->pd.levels >= 2 && frac < 0.96;
-             frac += 0.1) {
-            cut = uint32_t(double(height) * std::min(std::max(frac, 0.05), 0.95)) / 4 * 4;
-            banded = plan_row_bands(int(cut), int(width), int(height), h->n_layers, kBorder, bands) &&
-                     (env_f || bands.scan_tile_rows * 8 * 4 >= int(height));      // the head gets a quarter of the frame at least
-            if (env_f) break;
+        // Large frames go over PCIe in pieces, and the pipeline's front runs on the rows a piece completes while the next one
+        // is on its way (RowBands; plan_cuts chooses the pieces).
+        p.cuts = plan_cuts(h, width, height, u8);
+        if (getenv("LF_MKD_BAND_DEBUG")) {
+            std::string line = "lf_mkd: detect " + std::to_string(width) + "x" + std::to_string(height) + (u8 ? " u8" : " f32") +
+                               ", " + std::to_string(h->n_layers) + " layers: cuts";
+            for (uint32_t c : p.cuts) line += " " + std::to_string(c);
+            const FrontModel m;
+            line += p.cuts.empty() ? " (one piece)" : "";
+            line += "; modelled front done at " +
+                    std::to_string(front_finish_us(p.cuts, p.cuts.size() + 1, int(width), int(height), u8 ? 1 : 4, h->n_layers, m)) +
+                    " us, one piece " +
+                    std::to_string(front_finish_us({}, 1, int(width), int(height), u8 ? 1 : 4, h->n_layers, m)) + " us\n";
+            fputs(line.c_str(), stderr);
         }
-        if (banded) {
-            if (!h->copy_stream) {
-                LF_HIP(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-                for (auto &e : h->copy_ev) LF_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (!p.cuts.empty()) {
+            if (!h->copy_stream) LF_HIP(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+            while (h->copy_ev.size() < p.cuts.size() + 1) {
+                hipEvent_t e;
+                LF_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                h->copy_ev.push_back(e);
             }
-            bands.part = 0;
-            if (int rc = record_pipeline(h, width, height, top_n, min_size, max_out, u8 ? nullptr : h->d_image,
-                                         u8 ? h->d_image_u8 : nullptr, reinterpret_cast<lf_mkd_keypoint *>(h->d_kps_out),
-                                         h->d_det_desc, h->d_det_counts, h->h_det_counts, h->h_res_kps, &p.head_graph, &p.head,
-                                         &bands))
-                return rc;
-            p.band_rows = cut;
-            bands.part = 1;
         }
-        if (int rc = record_pipeline(h, width, height, top_n, min_size, max_out, u8 ? nullptr : h->d_image,
+        RowBands bands{};
+        for (size_t piece = 0; piece <= p.cuts.size(); ++piece) {
+            const bool last = piece == p.cuts.size();
+            int rc = LF_MKD_OK;
+            if (!p.cuts.empty() && !piece_bands(p.cuts, piece, int(width), int(height), h->n_layers, bands))
+                rc = fail(h, LF_MKD_ERR_BAD_ARG, "detect: internal error planning the banded upload");
+            hipGraph_t g = nullptr;
+            hipGraphExec_t e = nullptr;
+            if (!rc)
+                rc = record_pipeline(h, width, height, top_n, min_size, max_out, u8 ? nullptr : h->d_image,
                                      u8 ? h->d_image_u8 : nullptr, reinterpret_cast<lf_mkd_keypoint *>(h->d_kps_out),
-                                     h->d_det_desc, h->d_det_counts, h->h_det_counts, h->h_res_kps, &p.graph, &p.exec,
-                                     banded ? &bands : nullptr)) {
-            if (p.head) (void)hipGraphExecDestroy(p.head);
-            if (p.head_graph) (void)hipGraphDestroy(p.head_graph);
-            return rc;
+                                     h->d_det_desc, h->d_det_counts, h->h_det_counts, h->h_res_kps, &g, &e,
+                                     p.cuts.empty() ? nullptr : &bands);
+            if (rc) {
+                destroy_plan(p);
+                return rc;
+            }
+            if (last) {
+                p.graph = g;
+                p.exec = e;
+            } else {
+                p.head_graphs.push_back(g);
+                p.heads.push_back(e);
+            }
         }
         h->plans.push_back(p);
         plan = &h->plans.back();
     }
     plan->stamp = ++h->plan_clock;
-    if (!plan->head) {
+    if (plan->cuts.empty()) {
         if (int rc = upload_whole()) return rc;
         if (timed) LF_HIP(h, hipEventRecord(h->det_ev[1], s));
     } else {
-        // piece 1 (the call has waited for the device at its previous return: nothing still reads the staging frame), the
-        // head on its rows; piece 2 beside it; then the rest.  A copy from pageable memory returns when its bytes are on
-        // their way, so the host is in the second copy while the device runs the head.
-        const size_t bpp = u8 ? 1 : 4, row = size_t(width) * bpp, cut = plan->band_rows;
+        // piece by piece (the call has waited for the device at its previous return: nothing still reads the staging frame):
+        // copy, then the head on the rows it completes, the next piece beside it; after the last piece, the rest.  A copy from
+        // pageable memory returns when its bytes are on their way, so the host is in the next copy while the device runs a head.
+        const size_t bpp = u8 ? 1 : 4, row = size_t(width) * bpp;
         const unsigned char *src = u8 ? image_u8 : reinterpret_cast<const unsigned char *>(image);
         unsigned char *dst = u8 ? h->d_image_u8 : reinterpret_cast<unsigned char *>(h->d_image);
-        LF_HIP(h, hipMemcpyAsync(dst, src, row * cut, hipMemcpyHostToDevice, h->copy_stream));
-        LF_HIP(h, hipEventRecord(h->copy_ev[0], h->copy_stream));
-        LF_HIP(h, hipStreamWaitEvent(s, h->copy_ev[0], 0));
-        LF_HIP(h, hipGraphLaunch(plan->head, s));
-        LF_HIP(h, hipMemcpyAsync(dst + row * cut, src + row * cut, row * (height - cut), hipMemcpyHostToDevice, h->copy_stream));
-        LF_HIP(h, hipEventRecord(h->copy_ev[1], h->copy_stream));
-        LF_HIP(h, hipStreamWaitEvent(s, h->copy_ev[1], 0));
-        if (timed) LF_HIP(h, hipEventRecord(h->det_ev[1], s));     // (on s behind the wait: the moment the whole frame is there)
+        size_t from = 0;
+        static const bool trace = getenv("LF_MKD_BAND_TRACE") != nullptr;
+        std::vector<double> stamps;
+        const auto t_origin = std::chrono::steady_clock::now();
+        auto stamp = [&] {
+            if (trace) stamps.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_origin).count());
+        };
+        for (size_t piece = 0; piece <= plan->cuts.size(); ++piece) {
+            const size_t to = piece < plan->cuts.size() ? plan->cuts[piece] : height;
+            stamp();
+            LF_HIP(h, hipMemcpyAsync(dst + row * from, src + row * from, row * (to - from), hipMemcpyHostToDevice, h->copy_stream));
+            stamp();
+            LF_HIP(h, hipEventRecord(h->copy_ev[piece], h->copy_stream));
+            LF_HIP(h, hipStreamWaitEvent(s, h->copy_ev[piece], 0));
+            stamp();
+            if (piece < plan->cuts.size()) LF_HIP(h, hipGraphLaunch(plan->heads[piece], s));
+            stamp();
+            from = to;
+        }
+        if (trace) {
+            std::string line = "lf_mkd: band trace (us: copy call begin, end, events done, head launched):";
+            for (size_t i = 0; i < stamps.size(); ++i) line += (i % 4 ? " " : " | ") + std::to_string(int(stamps[i] + 0.5));
+            fputs((line + "\n").c_str(), stderr);
+        }
+        if (timed) LF_HIP(h, hipEventRecord(h->det_ev[1], s));     // (on s behind the last wait: the moment the whole frame is there)
     }
     LF_HIP(h, hipGraphLaunch(plan->exec, s));
     if (timed) LF_HIP(h, hipEventRecord(h->det_ev[2], s));

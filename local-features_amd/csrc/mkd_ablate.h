@@ -11,6 +11,7 @@
 //   LF_ABLATE_FORCE_W4     the 4-wave form at every request size
 //   LF_KP_ABLATE_PRODUCER  keypoint mode: the describe waves alone   LF_KP_ABLATE_TAPS   ... everything but a sample's loads
 //   LF_KP_PRODUCER_PRIO=n / LF_KP_CONSUMER_PRIO=n                    wave priorities of the two kinds of wave
+//   LF_ABLATE_ROWS=n       the row loop walks n of a patch's 32 rows (producers too): the bound of a row-split form
 //   LF_PHASE_TIMING        per-wave clocks of the phases of a patch row, left by workgroup 0 in out[wave * 128 + phase]
 #pragma once
 #include <hip/hip_runtime.h>
@@ -77,6 +78,12 @@ constexpr int kProducerPrio = 2;      // the product's setting (same-box A/B: +4
 constexpr int kConsumerPrio = LF_KP_CONSUMER_PRIO;
 #else
 constexpr int kConsumerPrio = -1;     // the describe waves keep the default priority
+#endif
+
+#ifdef LF_ABLATE_ROWS
+constexpr int kRows = LF_ABLATE_ROWS;
+#else
+constexpr int kRows = 32;             // rows of a patch (lib.rs:15 PATCH_SIZE)
 #endif
 
 // ---- phase clocks ------------------------------------------------------------------------------------------------

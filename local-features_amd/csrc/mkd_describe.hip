@@ -62,7 +62,9 @@ constexpr int kRingSlots = 6;
 // patch rows at a time (a group), so it holds 12 rows: the 8 a describe wave reads while a group is being written + that
 // group.  Raw row r of the workgroup's it-th batch lives in slot (8 it + r) mod 12 (32 mod 12 = 8: the numbering simply
 // runs on across batches).  4 describe waves: kRingOff + 4 * 12 * 2048 = 159744 B, plus the level table.
-[[maybe_unused]] constexpr int kSrcPatches = 0, kSrcKeypoints = 1;
+// SRC = kSrcKeypointsSplit (round 6; requests of at most 4096 keypoints): the 32 rows of a batch's patches are divided among
+// R = 2 or 4 WORKGROUPS (row-split form, see mkd_pool) whose partial pooled sums meet in global memory.
+[[maybe_unused]] constexpr int kSrcPatches = 0, kSrcKeypoints = 1, kSrcKeypointsSplit = 2;
 constexpr int kRingSlotsKp = 12;
 constexpr int kLevelTableBytes = 5 * kMaxPyrLevels * 4;
 
@@ -816,6 +818,11 @@ struct KpSource {
     unsigned n_frames;           // frames in the store: larger indices (caller's data) are clamped
     float psf;                   // patch_scale_factor
     PyramidDesc pd;
+    // row-split form only: workgroups per batch (2 or 4), the partial sums' exchange buffer
+    // [batch][role R-1][wave W][tile 24][half 2][lane 64] 2 x f32, its arrival counters [batch][wave] and an error word
+    int split;
+    float *xchg;
+    unsigned *xchg_cnt;
 };
 
 // Batches of a workgroup.  Keypoints arrive ordered by frame, and every XCD has its own L2: workgroups that share an XCD
@@ -1027,7 +1034,7 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
             else if (more) sm.finish(qc - 32, set ^ 1, slot1, cur);
         };
 #pragma unroll 1
-        for (int g = 0; g < 32; g += 2) {
+        for (int g = 0; g < ablate::kRows; g += 2) {
             step(g, ta, tb);
             step(g + 1, tb, ta);
         }
@@ -1038,6 +1045,76 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
         slot0 = slot1;
     }
 }
+
+// The row-split form's share of a batch: patch rows [lo, hi) of its 32 keypoints.  The describe waves need blurred rows
+// lo-1 .. hi, i.e. raw rows lo-3 .. hi+2 (clamped to the patch): the row groups of four that hold them are the quarters
+// [q_first, q_end) of the producers' numbering (quarter = 4 x group + patch quad).  n_pro of them are sampled before the
+// first row barrier: the describe waves' first step reads raw rows up to lo+3 and the second up to lo+4, so from the group
+// of row lo+4 on a group has exactly the four steps before its first use -- everything before it, and all but one quarter
+// of that group when lo > 0 (its first use comes one step after the start), belongs to the prologue: 7 quarters for the
+// rows from 0 (as in the whole-patch form), 11 otherwise.  Ring slot of raw row r: r mod 12, as in the whole-patch form.
+struct RowSpan {
+    int lo, hi, q_first, q_end, n_pro;
+    bool consumer;      // the workgroup of the LAST rows: it collects the others' partial sums and finishes the descriptors
+};
+__device__ __forceinline__ RowSpan row_span(int role, int n_roles) {
+    RowSpan sp;
+    sp.lo = 32 * role / n_roles;
+    sp.hi = 32 * (role + 1) / n_roles;
+    const int r_first = sp.lo - 3 > 0 ? sp.lo - 3 : 0, r_last = sp.hi + 2 < 31 ? sp.hi + 2 : 31;
+    sp.q_first = 4 * (r_first >> 2);
+    sp.q_end = 4 * ((r_last >> 2) + 1);
+    sp.n_pro = sp.lo == 0 ? 7 : 11;
+    sp.consumer = role == n_roles - 1;
+    return sp;
+}
+
+// The producer wave of a row-split workgroup: kp_produce for rows [lo, hi) of ONE batch.  One quarter per row step of the
+// describe waves, requested a step ahead like there; every barrier of the describe waves has its twin here: hi - lo row steps,
+// and the 12 of finish_descriptors in the consumer workgroup.
+template <int W>
+__device__ __forceinline__ void kp_produce_split(const KpSource &ks, const LevelTable &lt, const long *lvl_offset, long n,
+                                                 long batch, const RowSpan &sp, unsigned char *s_mem,
+                                                 const unsigned char *__restrict__ lut_rows, int pw, int lane) {
+    __builtin_amdgcn_s_setprio(ablate::kProducerPrio);
+    KpSampler<W> sm(ks, lt, lvl_offset, n, s_mem, pw, lane);
+    KpTaps ta, tb;
+    sm.load_geometry(batch, 0);
+    // the prologue, two tap sets in flight: the taps of quarter i + 1 are on their way while quarter i is blended
+    sm.request(sp.q_first, 0, ta);
+#pragma unroll 1
+    for (int i = 0; i + 1 < sp.n_pro; i += 2) {
+        sm.request(sp.q_first + i + 1, 0, tb);
+        sm.finish(sp.q_first + i, 0, 0, ta);
+        sm.request(sp.q_first + i + 2, 0, ta);     // (n_pro is odd: i + 2 <= n_pro - 1 is a prologue quarter)
+        sm.finish(sp.q_first + i + 1, 0, 0, tb);
+    }
+    sm.finish(sp.q_first + sp.n_pro - 1, 0, 0, ta);
+    const int q_step0 = sp.q_first + sp.n_pro;      // the quarter row step 0 writes
+    if (q_step0 < sp.q_end) sm.request(q_step0, 0, ta);
+    auto step = [&](int st, KpTaps &cur, KpTaps &nxt) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // ring writes, LUT pieces and taps have landed
+        __syncthreads();
+        // LUT row lo + st + 1 into the buffer the describe waves have just left (never beyond the span: during the last
+        // step of the consumer workgroup buffer 0 takes the epilogue's first whitening step)
+        if (sp.lo + st + 1 < sp.hi) issue_lut_row<W>(lut_rows, sp.lo + st + 1, s_mem + ((st + 1) & 1) * kRowBytes, pw, lane);
+        if (q_step0 + st + 1 < sp.q_end) sm.request(q_step0 + st + 1, 0, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q_step0 + st < sp.q_end) sm.finish(q_step0 + st, 0, 0, cur);
+    };
+#pragma unroll 1
+    for (int st = 0; st < sp.hi - sp.lo; st += 2) {
+        step(st, ta, tb);
+        step(st + 1, tb, ta);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (sp.consumer) {
+#pragma unroll 1
+        for (int e = 0; e < 12; ++e) __syncthreads();   // finish_descriptors: one on entry, one per whitening step
+    }
+}
+
+constexpr int kSplitSpinMax = 1 << 21;   // polls of a consumer wave for its partners' partial sums before it gives up (~1 s)
 
 }  // namespace
 
@@ -1053,13 +1130,22 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
 // of the text above; waves W .. 2W-1 are their producers (kp_produce): wave W + i samples the patches of describe wave i from
 // the pyramid straight into its row ring, so a sampled patch never leaves the CU.  `patches` is unused, `ks` says what to
 // sample.  The two kinds of wave sit side by side on every SIMD -- one waits on the texture path while the other computes.
+// SRC = kSrcKeypointsSplit (W = 2; requests small enough that every workgroup below is resident at once): a launch of the
+// form above is a wave walking 32 rows for its 16 patches whatever the request's size -- ~70 us of latency at the reference's
+// own 2000-3000 keypoints, on a quarter of the chip.  Here R = 2 or 4 workgroups share a batch of 32 keypoints by ROWS:
+// workgroup `role` samples and pools rows [32 role / R, 32 (role + 1) / R) only (pooling is a sum over pixels), the first
+// R - 1 leave their 24 accumulator tiles in global memory and count themselves in, the last one -- the highest workgroup id of
+// the batch, so that those it waits for were dispatched before it -- adds them to its own in a fixed order and runs the
+// epilogue.  A descriptor's sum is then R partial chains instead of one: bit-identical within the form, ~1e-7 relative
+// from the whole-patch forms.  Same sampling, blur, gradient and MFMA arithmetic per row.
 template <int ANGLE, int POOL, int W, int SRC>
-__global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_pool(
+__global__ __launch_bounds__(SRC != kSrcPatches ? 128 * W : 64 * W) void mkd_pool(
     const float *__restrict__ patches, long n_host, const unsigned long long *__restrict__ n_dev,
     const unsigned char *__restrict__ lut_rows, const short *__restrict__ colmap, const unsigned char *__restrict__ wfrag,
     const float *__restrict__ bias, float *__restrict__ out, float *__restrict__ raw_out,
-    std::conditional_t<SRC == kSrcKeypoints, KpSource, int> ks, unsigned long long *__restrict__ clk) {
-    constexpr bool kKp = SRC == kSrcKeypoints;
+    std::conditional_t<SRC != kSrcPatches, KpSource, int> ks, unsigned long long *__restrict__ clk) {
+    constexpr bool kKp = SRC != kSrcPatches, kSplit = SRC == kSrcKeypointsSplit;
+    static_assert(!kSplit || W == 2, "the row-split form is the narrow (2 + 2 wave) form");
     // clk (LF_MKD_FLAG_KERNEL_TIMING, else null): workgroup 0 stamps the shader clock (s_memtime) and the constant 100 MHz
     // clock (s_memrealtime) on entry and on exit -- the clock the chip sustained under THIS launch is their quotient
     // (MI355X_MICROARCH.md, DVFS give-back); the values go to a buffer nothing else reads
@@ -1082,8 +1168,22 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
     const long nbatch = (n + 16 * W - 1) / (16 * W);
     unsigned char *ring = s_mem + kRingOff + wave * (kSlots * 2048);
     BatchWalk walk{(long)blockIdx.x, nbatch, (long)gridDim.x};
+    [[maybe_unused]] RowSpan span{0, 32, 0, 32, 7, true};
+    [[maybe_unused]] int role = 0, n_roles = 1;
     if constexpr (kKp) {
-        walk = kp_batches(nbatch);
+        if constexpr (kSplit) {
+            // workgroup id -> (batch, role): ids 8 R k + 8 role + x serve batch 8 k + x -- the R workgroups of a batch sit 8 ids
+            // apart (dispatch deals ids to the 8 XCDs round-robin: they share an L2, a matter of speed only) and the consumer
+            // (role R - 1) has the highest id of its batch (its partners were dispatched before it)
+            n_roles = ks.split;
+            const long id = blockIdx.x, grp = id / (8 * n_roles), in = id - grp * (8 * n_roles);
+            role = (int)(in >> 3);
+            const long b = grp * 8 + (in & 7);
+            walk = BatchWalk{b, b < nbatch ? b + 1 : b, 1};
+            span = row_span(role, n_roles);
+        } else {
+            walk = kp_batches(nbatch);
+        }
         if (walk.cur >= walk.end) return;
         // per-level geometry into LDS (lanes look up different levels: see LevelTable)
         int *lv = reinterpret_cast<int *>(s_mem + kRingOff + W * kSlots * 2048);
@@ -1101,7 +1201,8 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
         __syncthreads();
         const LevelTable lt{ks.pd.levels, lv, lv + kMaxPyrLevels, lv + 2 * kMaxPyrLevels, lv + 3 * kMaxPyrLevels};
         if (wave >= W) {
-            kp_produce<W>(ks, lt, lv_off, n, walk, s_mem, lut_rows, wave - W, lane);
+            if constexpr (kSplit) kp_produce_split<W>(ks, lt, lv_off, n, walk.cur, span, s_mem, lut_rows, wave - W, lane);
+            else kp_produce<W>(ks, lt, lv_off, n, walk, s_mem, lut_rows, wave - W, lane);
             return;
         }
 
@@ -1126,7 +1227,7 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
 #pragma unroll
             for (int r = -2; r <= 3; ++r) issue_raw_row(src, r, ring, r + 2);
         }
-        issue_lut_row<W>(lut_rows, 0, s_mem, wave, lane);
+        issue_lut_row<W>(lut_rows, kSplit ? span.lo : 0, s_mem, wave, lane);
     }
     int slot0 = 0;   // keypoint mode: ring slot of raw row 0 of the current batch
     unsigned par = 0;  // LUT row buffer holding the row about to be consumed
@@ -1163,6 +1264,7 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
         // every row (ten v_mov).
         auto patch_row = [&](auto kind, const int g) __attribute__((always_inline)) {
             constexpr bool kFirst = decltype(kind)::value == 0, kLast = decltype(kind)::value == 2;
+            constexpr bool kFirstInner = decltype(kind)::value == 3;   // row-split form: a first row that is not row 0
 
             // LUT row g and ring row g+3 have landed (own DMA: vmcnt; everyone's: barrier); row g-1 is done
             phase.mark(7);
@@ -1202,6 +1304,11 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
                     blur_row(ring_lane, 0, addr_l, addr_r, has_l, has_r, cur, cur_l, cur_r);
 #pragma unroll
                 for (int x = 0; x < 8; ++x) prv[x] = cur[x];
+            }
+            if constexpr (kFirstInner) {   // blurred rows g - 1 and g themselves: nothing replicates
+                float edge_l, edge_r;
+                blur_row_impl(ring_lane, [&](int i) { return kp_slot(g - 1, i); }, addr_l, addr_r, has_l, has_r, prv, edge_l, edge_r);
+                blur_row_impl(ring_lane, [&](int i) { return kp_slot(g, i); }, addr_l, addr_r, has_l, has_r, cur, cur_l, cur_r);
             }
             float nxt[8], nxt_l, nxt_r;
             if (!kLast) {  // hb(g+1) from raw rows g-1..g+3 = slots s0..s0+4
@@ -1281,10 +1388,69 @@ __global__ __launch_bounds__(SRC == kSrcKeypoints ? 128 * W : 64 * W) void mkd_p
             phase.mark(4);
             phase.mark(5);
         };
-        patch_row(std::integral_constant<int, 0>(), 0);
+        if constexpr (kSplit) {
+            if (span.lo == 0) patch_row(std::integral_constant<int, 0>(), 0);
+            else patch_row(std::integral_constant<int, 3>(), span.lo);
 #pragma unroll 1
-        for (int g = 1; g < 31; ++g) patch_row(std::integral_constant<int, 1>(), g);
-        patch_row(std::integral_constant<int, 2>(), 31);
+            for (int g = span.lo + 1; g < span.hi - 1; ++g) patch_row(std::integral_constant<int, 1>(), g);
+            if (span.consumer) patch_row(std::integral_constant<int, 2>(), span.hi - 1);
+            else patch_row(std::integral_constant<int, 1>(), span.hi - 1);
+            // the partial sums meet: [batch][role][wave][tile][lane] f32x4, one counter per (batch, wave)
+            unsigned *cnt = ks.xchg_cnt + batch * W + wave;
+            // Every access to the exchange buffer and its counters is a relaxed atomic of agent scope: such a store is
+            // complete (vmcnt) once it has reached the level of the memory system all XCDs see, such a load is served from
+            // there -- no release / acquire fence, whose cost on this chip is a write-back and an invalidation of the whole L2
+            // (the LUT rows and the pyramid every other workgroup is reading: measured, profiles/r06_row_split.md).
+            typedef unsigned long long u64;
+            if (!span.consumer) {
+                u64 *dst = reinterpret_cast<u64 *>(ks.xchg + ((((long)batch * (n_roles - 1) + role) * W + wave) * kAccTiles) * 256) + lane;
+#pragma unroll
+                for (int t = 0; t < kAccTiles; ++t) {
+                    const u64 v0 = ((u64)__float_as_uint(acc[t][1]) << 32) | __float_as_uint(acc[t][0]);
+                    const u64 v1 = ((u64)__float_as_uint(acc[t][3]) << 32) | __float_as_uint(acc[t][2]);
+                    __hip_atomic_store(dst + t * 128, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + t * 128 + 64, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the wave's partial sums are where everyone sees them ...
+                if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before it counts itself in
+                if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+                    clk[2] = __builtin_readcyclecounter();
+                    clk[3] = __builtin_amdgcn_s_memrealtime();
+                }
+                return;
+            }
+            int polls = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(n_roles - 1) &&
+                   polls < kSplitSpinMax) {
+                __builtin_amdgcn_s_sleep(1);
+                ++polls;
+            }
+            asm volatile("" ::: "memory");
+            if (polls >= kSplitSpinMax && lane == 0) atomicAdd(ks.xchg_cnt - 1, 1u);   // the error word: a partner never arrived
+#pragma unroll 1
+            for (int r = 0; r + 1 < n_roles; ++r) {
+                const u64 *srcp = reinterpret_cast<const u64 *>(ks.xchg + ((((long)batch * (n_roles - 1) + r) * W + wave) * kAccTiles) * 256) + lane;
+                // a partner's 24 tiles are requested in one go (48 loads in flight: one trip to memory per partner, not per
+                // tile -- a workgroup of this form has a SIMD's 512 registers per wave) and added in tile order
+                u64 v[2 * kAccTiles];
+#pragma unroll
+                for (int t = 0; t < 2 * kAccTiles; ++t)
+                    v[t] = __hip_atomic_load(srcp + t * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < kAccTiles; ++t)
+                    acc[t] += f32x4{__uint_as_float((unsigned)v[2 * t]), __uint_as_float((unsigned)(v[2 * t] >> 32)),
+                                    __uint_as_float((unsigned)v[2 * t + 1]), __uint_as_float((unsigned)(v[2 * t + 1] >> 32))};
+            }
+            if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            // (the epilogue counts its own LDS-DMA requests on vmcnt: nothing of the above may still be in flight)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            patch_row(std::integral_constant<int, 0>(), 0);
+#pragma unroll 1
+            for (int g = 1; g < ablate::kRows - 1; ++g) patch_row(std::integral_constant<int, 1>(), g);
+            patch_row(std::integral_constant<int, 2>(), ablate::kRows - 1);
+        }
         if constexpr (ablate::kNoEpilogue) {
             f32x4 sum = acc[0];
             for (int t = 1; t < kAccTiles; ++t) sum += acc[t];
@@ -1357,10 +1523,17 @@ void launch_describe(const float *patches, long n, const unsigned long long *n_d
 #else   // LF_DESCRIBE_KP
 // Keypoint mode in one launch: 4 describe waves + 4 producer waves per workgroup, 64 keypoints per batch, one workgroup
 // per CU (160 KB of LDS), persistent; requests of at most 8192 keypoints: 2 + 2 waves, 32 keypoints per workgroup (below).
+static long nbatch32(long n) { return (n + 31) / 32; }
+size_t kp_split_exchange_bytes(int num_cus) {
+    // R = 4: num_cus / 4 batches x 3 partial roles; R = 2: num_cus / 2 x 1 -- the larger of the two, x 2 waves x 24 tiles x 1 KiB
+    return size_t(num_cus / 4 + 8) * 3 * 2 * kAccTiles * 1024;
+}
+size_t kp_split_counter_words(int num_cus) { return 1 + size_t(num_cus / 2 + 8) * 2; }   // the error word, then [batch][wave]
+
 void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                                const unsigned *frame_of_kp, unsigned n_frames, long n, const unsigned long long *n_dev,
                                float psf, const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream,
-                               unsigned long long *clk) {
+                               unsigned long long *clk, float *xchg, unsigned *xchg_words) {
     if (n <= 0) return;
     // A request of at most one round of 32-keypoint workgroups (<= 32 x CUs = 8192 keypoints: a frame at the reference's own
     // settings, top_n 2000 / max_features 3000) takes the 2 + 2-wave form: every wave has a SIMD to itself -- the describe
@@ -1375,6 +1548,30 @@ void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidD
     KpSource ks;
     ks.pyr = pyr; ks.pyr_stride = pyr_stride; ks.kps = kps; ks.frame_of = frame_of_kp; ks.n_frames = n_frames ? n_frames : 1u;
     ks.psf = psf; ks.pd = pd;
+    ks.split = 1; ks.xchg = nullptr; ks.xchg_cnt = nullptr;
+    // The row-split form where R workgroups per batch of 32 are all resident at once (one per CU): R = 4 up to 8 x CUs
+    // keypoints (2048), R = 2 up to 16 x CUs (4096) -- the reference's own operating point (top_n 2000, max_features 3000).
+    // LF_MKD_KP_SPLIT=1 / 2 / 4 forces a form where it fits (tests, A/B runs).
+    if (xchg && xchg_words) {
+        const long nb8 = (nbatch32(n) + 7) / 8 * 8;
+        int r = nb8 * 4 <= num_cus ? 4 : (nb8 * 2 <= num_cus ? 2 : 1);
+        if (const char *e = getenv("LF_MKD_KP_SPLIT")) {
+            const int want = atoi(e);
+            if (want == 1 || ((want == 2 || want == 4) && nb8 * want <= num_cus)) r = want;
+        }
+        if (r > 1) {
+            ks.split = r; ks.xchg = xchg; ks.xchg_cnt = xchg_words + 1;
+            const unsigned sgrid = (unsigned)(nb8 * r);
+#define LF_LAUNCH_KP_SPLIT(A)                                                                                                  \
+    hipLaunchKernelGGL((mkd_pool<A, LF_POOL_F16X3, 2, kSrcKeypointsSplit>), dim3(sgrid), dim3(256), 0, stream,                    \
+                       (const float *)nullptr, n, n_dev, lut, dc.colmap, wf, dc.white_bias, out, (float *)nullptr, ks, clk)
+            if (angle_mode == LF_ANGLE_EXACT) LF_LAUNCH_KP_SPLIT(LF_ANGLE_EXACT);
+            else if (angle_mode == LF_ANGLE_EXACT_ZERO) LF_LAUNCH_KP_SPLIT(LF_ANGLE_EXACT_ZERO);
+            else LF_LAUNCH_KP_SPLIT(LF_ANGLE_SHADER);
+#undef LF_LAUNCH_KP_SPLIT
+            return;
+        }
+    }
 #define LF_LAUNCH_KP_W(A, WV)                                                                                          \
     hipLaunchKernelGGL((mkd_pool<A, LF_POOL_F16X3, WV, kSrcKeypoints>), dim3(grid), dim3(128 * WV), 0, stream,          \
                        (const float *)nullptr, n, n_dev, lut, dc.colmap, wf, dc.white_bias, out, (float *)nullptr, ks, clk)

@@ -780,11 +780,11 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, int layer0_p
         const int aligned = w % 4 == 0 && layer0_pitch % 4 == 0 && layer0_stride % 4 == 0 && coarse_stride % 4 == 0 &&
                             layer_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(layer0) & 15) == 0 &&
                             (reinterpret_cast<uintptr_t>(coarse) & 15) == 0;
-        // (bands: part 0 scans the tile rows the frame's first band allows and stops; part 1 scans the rest and compacts)
-        const int part = bands ? bands->part : -1;
+        // (bands: a piece scans the tile rows [lo, hi) its rows allow and stops; the last piece scans the rest and compacts)
+        const bool head_only = bands && !bands->last;
         const int all_rows = (gy + kScanTY / 4 - 1) / (kScanTY / 4);
-        const int by_first = part == 1 ? std::min(bands->scan_tile_rows, all_rows) : 0;
-        const int by_rows = (part == 0 ? std::min(bands->scan_tile_rows, all_rows) : all_rows) - by_first;
+        const int by_first = bands ? std::min(bands->scan_lo, all_rows) : 0;
+        const int by_rows = (head_only ? std::min(bands->scan_hi, all_rows) : all_rows) - by_first;
         auto scan = [&](auto kernel, int tx) {
             if (by_rows > 0)
                 hipLaunchKernelGGL(kernel, dim3((gx + tx / 4 - 1) / (tx / 4), by_rows, frames), dim3(256), 0, stream, layer0,
@@ -793,9 +793,9 @@ void launch_detect_extrema(const float *layer0, long layer0_stride, int layer0_p
         };
         if ((long)frames * w * h >= 2000000L) scan(scan_extrema<64>, 64);
         else scan(scan_extrema<32>, 32);
-        if (part == 0) return;
+        if (head_only) return;
         hipLaunchKernelGGL(cubes_block_sums, dim3((unsigned)nb), dim3(1024), 0, stream, (const unsigned *)counts, n, sums);
-    } else if (bands && bands->part == 0) {
+    } else if (bands && !bands->last) {
         return;
     }
     if (ncubes > 0)

@@ -33,16 +33,22 @@ struct PyramidDesc {
     long offset[kMaxPyrLevels];  // in floats, of texel (0, 0)
 };
 
-// Row bands (lf_mkd_detect's upload / compute overlap, round 5): the frame reaches the device in two pieces, and the row-tiled
-// kernels of the pipeline's front -- level 0, the a-trous layers, the extremum scan -- run once for the rows the first piece
-// allows (part 0, while the second piece is still on its way over PCIe) and once for the rest (part 1).  A stage's split is a
-// tile boundary of its kernel, chosen so that part 0 reads nothing part 1's rows produce: plan_row_bands.
+// Row bands (lf_mkd_detect's upload / compute overlap; two pieces in round 5, any number since round 6): the frame reaches the
+// device in pieces, and the row-tiled kernels of the pipeline's front -- level 0, the a-trous layers, the extremum scan -- run
+// once per piece on the rows that piece completes, while the next piece is still on its way over PCIe.  A launch sequence is
+// given the rows [lo, hi) of every stage it is to produce: hi = what the frame's rows so far allow (plan_row_bands: level 0
+// needs two raw rows below an output row, a-trous layer l + 1 with dilation d = 2^l needs 2 d rows of layer l, the scan one row
+// of every layer below a tile's candidates), lo = the previous piece's hi.  The last piece has hi = everything and also runs
+// what is not row-tiled.  Splits fall on multiples of 12 rows for level 0, of d rows for a layer of dilation d, of a tile row
+// (8 candidate rows) for the scan; no piece reads a row a later piece produces.
 struct RowBands {
-    int part;             // 0: the rows before each split; 1: the rows from each split on (and everything that is not row-tiled)
-    int level0_rows;      // pyramid level 0 = a-trous layer 0: rows [0, level0_rows) are part 0 (a multiple of 12)
-    int layer_rows[8];    // a-trous layer l + 1 (dilation 2^l): rows [0, layer_rows[l]) are part 0 (a multiple of 12 * 2^l)
-    int scan_tile_rows;   // extremum scan: tile rows (8 candidate rows each) [0, scan_tile_rows) are part 0
+    int last;             // 1: the final piece -- every stage to its end, then the rest of the pipeline
+    int level0_lo, level0_hi;       // pyramid level 0 = a-trous layer 0: rows (multiples of 12; hi of the last piece: the height)
+    int layer_lo[8], layer_hi[8];   // a-trous layer l + 1 (dilation 2^l): rows (multiples of 2^l)
+    int scan_lo, scan_hi;           // extremum scan: tile rows (8 candidate rows each)
 };
+// the `hi` fields for a frame of which the first raw_rows rows have arrived (`lo` and `last` are the caller's); false: the
+// frame's shape does not take row bands (the staged kernels' alignment), or raw_rows covers the frame
 bool plan_row_bands(int raw_rows, int w, int h, int n_layers, int border, RowBands &bands);
 
 // Device copies of HostConsts' device layouts (mkd_consts.hpp).
@@ -73,7 +79,12 @@ void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc 
 void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                                const unsigned *frame_of_kp, unsigned n_frames, long n, const unsigned long long *n_dev,
                                float psf, const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream,
-                               unsigned long long *clk = nullptr);
+                               unsigned long long *clk = nullptr, float *xchg = nullptr, unsigned *xchg_words = nullptr);
+// xchg / xchg_words (nullable: the whole-patch forms only): scratch of the row-split form a request of at most 16 x CUs
+// keypoints takes -- kp_split_exchange_bytes(num_cus) bytes and kp_split_counter_words(num_cus) u32 words, the words zero
+// before the first launch (they return to zero at the end of every launch; word 0 counts partial sums that never arrived)
+size_t kp_split_exchange_bytes(int num_cus);
+size_t kp_split_counter_words(int num_cus);
 // rest_stream (nullable): levels >= 1 are built there -- after `fork`, recorded on `stream` once level 0 and a-trous layer 1
 // exist -- and `join` is recorded behind them; the caller waits for `join` before it samples patches
 void launch_build_pyramid(const float *image, long image_stride, float *pyr, long pyr_stride, float *tmp_a,

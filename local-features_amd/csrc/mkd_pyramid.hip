@@ -220,14 +220,15 @@ constexpr int kSwtRows = 12, kSwtCols = 256;
 
 __global__ __launch_bounds__(256) void pyr_swt_fused(const float *__restrict__ in, float *__restrict__ out, long in_stride,
                                                      long out_stride, int w, int h, int ipitch, int d, int blocks_per_class,
-                                                     int kb_base) {
+                                                     int k_first, int k_end) {
 #pragma clang fp contract(off)
     __shared__ float s_h[kSwtRows + 4][kSwtCols];
     const float k0 = 6.f / 16.f, k1 = 4.f / 16.f, k2 = 1.f / 16.f;
     in += blockIdx.z * in_stride;
     out += blockIdx.z * out_stride;
     const int r = blockIdx.y / blocks_per_class;                    // residue class of the rows
-    const int kb = (blockIdx.y - r * blocks_per_class + kb_base) * kSwtRows;  // first lattice index of this workgroup
+    // first lattice index of this workgroup: the launch covers lattice rows [k_first, k_end) of every class (row bands)
+    const int kb = k_first + (blockIdx.y - r * blocks_per_class) * kSwtRows;
     const int xs = (int)blockIdx.x * kSwtCols;   // signed: xs - 2 d must be able to go negative
     const int xr = xs + (int)threadIdx.x, x = xr < w ? xr : w - 1;
     const bool interior = xs - 2 * d >= 0 && xs + kSwtCols - 1 + 2 * d < w;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void pyr_swt_fused(const float *__restrict__ i
 #pragma unroll 4
     for (int k = 0; k < kSwtRows; ++k) {
         const int y = r + (kb + k) * d;
-        if (y >= h) break;
+        if (y >= h || kb + k >= k_end) break;
         float sum = s_h[k + 2][threadIdx.x] * k0;
         sum += s_h[k + 1][threadIdx.x] * k1;
         sum += s_h[k][threadIdx.x] * k2;
@@ -276,7 +277,7 @@ struct SwtBlit { float *out; long stride; int pitch, apron; };
 template <int H4>
 __global__ __launch_bounds__(256) void pyr_swt_staged(const float *__restrict__ in, float *__restrict__ out, long in_stride,
                                                       long out_stride, int w, int h, int ipitch, int d, int blocks_per_class,
-                                                      SwtBlit blit, int kb_base) {
+                                                      SwtBlit blit, int k_first, int k_end) {
 #pragma clang fp contract(off)
     constexpr int kSlots = kSwtRows + 4, kOutCols = kSwtCols - 2 * H4;
     __shared__ __attribute__((aligned(16))) float s_raw[kSlots][kSwtCols];
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void pyr_swt_staged(const float *__restrict__ 
     in += tile.z * in_stride;
     out += tile.z * out_stride;
     const int r = tile.y / blocks_per_class;
-    const int kb = (tile.y - r * blocks_per_class + kb_base) * kSwtRows;
+    const int kb = k_first + (tile.y - r * blocks_per_class) * kSwtRows;   // (lattice rows [k_first, k_end): see pyr_swt_fused)
     const int xs = (int)tile.x * kOutCols;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // this lane's four texels of a segment: columns c0 .. c0 + 3 (virtual: mirrored where they leave the frame)
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256) void pyr_swt_staged(const float *__restrict__ 
 #pragma unroll
     for (int k = 0; k < kSwtRows; ++k) {
         const int y = r + (kb + k) * d;
-        if (y >= h) break;
+        if (y >= h || kb + k >= k_end) break;
         float sum = hres[k + 2] * k0;
         sum += hres[k + 1] * k1;
         sum += hres[k] * k2;
@@ -753,17 +754,17 @@ void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc 
 // hold frames x w x h floats each.
 // one a-trous layer (both passes) for `frames` frames
 // returns whether the launch also wrote `blit` (pyramid level 1, from the dilation-1 layer)
-// (row_lo, row_hi: the launch covers output rows [row_lo, row_hi) only -- multiples of 12 d, or the frame's height for row_hi:
-//  whole tiles of every residue class; the default is the whole frame)
+// (row_lo, row_hi: the launch covers output rows [row_lo, row_hi) only -- multiples of d, or the frame's height / -1 for row_hi:
+//  the same lattice rows of every residue class, in tiles of kSwtRows of them from row_lo / d on (the last tile of a range may
+//  be partial); the default is the whole frame)
 static bool launch_swt(const float *in, long in_stride, int in_pitch, float *out, long out_stride, int w, int h, int d,
                        int frames, hipStream_t stream, SwtBlit blit = SwtBlit{nullptr, 0, 0, 0}, int row_lo = 0, int row_hi = -1) {
     const int classes = d < h ? d : h;                                   // residue classes that hold rows
     const int lattice = (h + d - 1) / d;                                 // rows of the longest class
-    const int all_tiles = (lattice + kSwtRows - 1) / kSwtRows;           // tiles of a class over the whole frame
-    const int kb_base = row_lo / (kSwtRows * d);
-    const int kb_end = row_hi < 0 || row_hi >= h ? all_tiles : row_hi / (kSwtRows * d);
-    const int per_class = kb_end - kb_base;
-    if (per_class <= 0) return false;
+    const int k_first = row_lo / d;
+    const int k_end = row_hi < 0 || row_hi >= h ? lattice : row_hi / d;
+    const int per_class = (k_end - k_first + kSwtRows - 1) / kSwtRows;   // tiles of a class
+    if (k_end <= k_first) return false;
     // the staged form where its 16-byte requests are aligned and its halo fits
     // (d = 32 leaves 128 of the segment's 256 columns to write and is still ahead: 17 against 21 us on a 4K frame)
     if (d <= 32 && w % 4 == 0 && in_pitch % 4 == 0 && in_stride % 4 == 0 &&
@@ -773,7 +774,7 @@ static bool launch_swt(const float *in, long in_stride, int in_pitch, float *out
         auto go = [&](auto kernel, int h4) {
             const int oc = kSwtCols - 2 * h4;
             hipLaunchKernelGGL(kernel, dim3((w + oc - 1) / oc, classes * per_class, frames), dim3(256), 0, stream, in, out,
-                               in_stride, out_stride, w, h, in_pitch, d, per_class, blit, kb_base);
+                               in_stride, out_stride, w, h, in_pitch, d, per_class, blit, k_first, k_end);
         };
         if (d <= 2) go(pyr_swt_staged<4>, 4);
         else if (d == 4) go(pyr_swt_staged<8>, 8);
@@ -783,7 +784,7 @@ static bool launch_swt(const float *in, long in_stride, int in_pitch, float *out
         return with_blit;
     }
     hipLaunchKernelGGL(pyr_swt_fused, dim3((w + kSwtCols - 1) / kSwtCols, classes * per_class, frames), dim3(256), 0, stream,
-                       in, out, in_stride, out_stride, w, h, in_pitch, d, per_class, kb_base);
+                       in, out, in_stride, out_stride, w, h, in_pitch, d, per_class, k_first, k_end);
     return false;
 }
 
@@ -804,11 +805,11 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
                           hipStream_t stream, hipStream_t rest_stream, hipEvent_t fork, hipEvent_t join,
                           const std::function<void()> &main_next, const unsigned char *image_u8, const RowBands *bands) {
     const int w = pd.w[0], h = pd.h[0];
-    // (bands: this launch sequence is one of the two parts of a banded frame -- part 0 stops after the rows the first band
-    //  allows and builds nothing below level 1; part 1 does the remaining rows and everything else)
-    const int part = bands ? bands->part : -1;
-    const int l0_first = part == 1 ? bands->level0_rows / 12 : 0;
-    const int l0_tiles = (part == 0 ? bands->level0_rows / 12 : (h + 11) / 12) - l0_first;
+    // (bands: this launch sequence is one piece of a banded frame -- it produces the rows [lo, hi) of level 0 and of a-trous
+    //  layer 1 its piece allows; only the last piece builds the levels below level 1 and everything else)
+    const bool head_only = bands && !bands->last;
+    const int l0_first = bands ? bands->level0_lo / 12 : 0;
+    const int l0_tiles = (bands && !bands->last ? bands->level0_hi / 12 : (h + 11) / 12) - l0_first;
     const long ts = (long)w * h;
     const dim3 blk(32, 8);
     auto grid = [&](int gw, int gh) { return dim3((gw + 31) / 32, (gh + 7) / 8, frames); };
@@ -858,8 +859,8 @@ void launch_build_pyramid(const float *image, long image_stride, float *pyr, lon
     if (need_layer1)
         level1_done = launch_swt(pyr + pd.offset[0], pyr_stride, pd.pitch[0], l1, l1s, w, h, 1, frames, stream,
                                  SwtBlit{pyr + pd.offset[1], pyr_stride, pd.pitch[1], apron_of(1)},
-                                 part == 1 ? bands->layer_rows[0] : 0, part == 0 ? bands->layer_rows[0] : -1);
-    if (part == 0) {          // the first band's share ends with the a-trous layers its rows allow (queued by the caller)
+                                 bands ? bands->layer_lo[0] : 0, head_only ? bands->layer_hi[0] : -1);
+    if (head_only) {          // a piece's share ends with the a-trous layers its rows allow (queued by the caller)
         if (main_next) main_next();
         return;
     }
@@ -926,31 +927,31 @@ void launch_build_coarse_stack(const float *layer0, long layer0_stride, int laye
                                long layer_stride, float *tmp, int n_layers, int first_layer, int w, int h, int frames,
                                hipStream_t stream, const RowBands *bands) {
     (void)tmp;
-    const int part = bands ? bands->part : -1;
+    const bool head_only = bands && !bands->last;
     for (int l = first_layer; l + 1 < n_layers; ++l) {   // first_layer = 1: layer 1 came with the pyramid
         const float *in = l == 0 ? layer0 : coarse + (long)(l - 1) * layer_stride;
         const long in_stride = l == 0 ? layer0_stride : coarse_stride;
         launch_swt(in, in_stride, l == 0 ? layer0_pitch : w, coarse + (long)l * layer_stride, coarse_stride, w, h, 1 << l, frames,
-                   stream, SwtBlit{nullptr, 0, 0, 0}, part == 1 ? bands->layer_rows[l] : 0, part == 0 ? bands->layer_rows[l] : -1);
+                   stream, SwtBlit{nullptr, 0, 0, 0}, bands ? bands->layer_lo[l] : 0, head_only ? bands->layer_hi[l] : -1);
     }
 }
 
 // Which rows each stage of the pipeline's front can produce from the frame's first `raw_rows` rows (see RowBands): level 0
 // needs two raw rows below an output row, a-trous layer l + 1 (dilation d = 2^l) needs 2 d rows of layer l, the extremum scan one
-// row of every layer below a tile's candidates; every split falls on a tile boundary of its kernel.  False: not worth it
-// (a stage would get no rows, or the layers are not the staged kernels' shapes).
+// row of every layer below a tile's candidates; every split falls on a boundary its kernel can start from (12 rows for
+// level 0, d rows for a layer, a tile row for the scan).  Fills the `hi` fields.  False: the frame does not take row bands.
 bool plan_row_bands(int raw_rows, int w, int h, int n_layers, int border, RowBands &b) {
     if (w % 4 || h % 2 || n_layers - 1 > 8 || raw_rows >= h) return false;
-    b.part = 0;
-    b.level0_rows = (raw_rows - 2) / 12 * 12;
-    int prev = b.level0_rows;
+    b.level0_hi = raw_rows > 2 ? (raw_rows - 2) / 12 * 12 : 0;
+    int prev = b.level0_hi;
+    for (int l = 0; l < 8; ++l) b.layer_hi[l] = 0;
     for (int l = 0; l + 1 < n_layers; ++l) {
-        const int d = 1 << l, g = kSwtRows * d;
-        b.layer_rows[l] = prev - 2 * d > 0 ? (prev - 2 * d) / g * g : 0;
-        prev = b.layer_rows[l];
+        const int d = 1 << l;
+        b.layer_hi[l] = prev - 2 * d > 0 ? (prev - 2 * d) / d * d : 0;
+        prev = b.layer_hi[l];
     }
-    b.scan_tile_rows = prev - border - 1 > 0 ? (prev - border - 1) / 8 : 0;     // tile rows of 8 candidates from row `border`
-    return b.level0_rows > 0 && prev > 0 && b.scan_tile_rows > 0;
+    b.scan_hi = prev - border - 1 > 0 ? (prev - border - 1) / 8 : 0;     // tile rows of 8 candidates from row `border`
+    return true;
 }
 
 }  // namespace lfmkd

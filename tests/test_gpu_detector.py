@@ -274,9 +274,9 @@ def test_detect_recorded_stepwise_and_u8_return_the_same_bits(lfp, torch, oracle
 
 @pytest.mark.parametrize("w,hgt,n_scales", [(1280, 1024, 4), (2048, 1100, 3), (1024, 1536, 5)])
 def test_banded_upload_returns_the_unbanded_bits(lfp, oracle, monkeypatch, w, hgt, n_scales):
-    """Frames of a megapixel and more reach the device in two pieces, and the pipeline's front (level 0, the a-trous layers,
-    the extremum scan) runs on the rows the first piece allows while the second is still on its way (RowBands).  Wherever the
-    cut falls, whatever the pixel type, the call must return what the one-piece form (LF_MKD_DETECT_BANDS=0) and the
+    """Large frames reach the device in pieces, and the pipeline's front (level 0, the a-trous layers, the extremum scan)
+    runs on the rows a piece completes while the next is still on its way (RowBands).  Wherever the cuts fall, however many
+    there are, whatever the pixel type, the call must return what the one-piece form (LF_MKD_DETECT_BANDS=0) and the
     stage-by-stage form return: every extremum (top_n = 0, so that a row lost at a band boundary would show), keypoints,
     descriptors, counters."""
     u8, f32 = _u8_frame(w, hgt, 23, 2500)
@@ -290,9 +290,16 @@ def test_banded_upload_returns_the_unbanded_bits(lfp, oracle, monkeypatch, w, hg
         got = one.detect(img, 0, 0.0, 20000)
         assert got[2:] == want[2:] and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     monkeypatch.delenv("LF_MKD_DETECT_BANDS")
-    for frac in (None, "0.12", "0.33", "0.5", "0.77", "0.94"):
+    # one cut (two pieces, round 5), then K pieces (round 6): equal ones, uneven ones, a first piece too small for the deep
+    # layers to get any row, a last piece smaller than the a-trous stack's cumulative halo, cuts a few rows apart
+    for frac in (None, "0.12", "0.33", "0.5", "0.77", "0.94", "pieces=3", "pieces=4", "pieces=7", "0.2,0.5,0.8",
+                 "0.03,0.06,0.5,0.97", "0.4,0.41,0.42"):
+        monkeypatch.delenv("LF_MKD_BAND_SPLIT", raising=False)
+        monkeypatch.delenv("LF_MKD_BAND_PIECES", raising=False)
         if frac is None:
-            monkeypatch.delenv("LF_MKD_BAND_SPLIT", raising=False)
+            pass
+        elif frac.startswith("pieces="):
+            monkeypatch.setenv("LF_MKD_BAND_PIECES", frac[7:])
         else:
             monkeypatch.setenv("LF_MKD_BAND_SPLIT", frac)
         h = lfp.MkdHandle(**kw)                                  # (the cut is fixed when a request is first recorded)
@@ -302,6 +309,8 @@ def test_banded_upload_returns_the_unbanded_bits(lfp, oracle, monkeypatch, w, hg
                 exp = want if top_n == 0 else ref.detect(f32, top_n, 0.0, 20000)
                 assert got[2:] == exp[2:], (frac, img.dtype, top_n)
                 assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]), (frac, img.dtype, top_n)
+    monkeypatch.delenv("LF_MKD_BAND_SPLIT", raising=False)
+    monkeypatch.delenv("LF_MKD_BAND_PIECES", raising=False)
     # and what the call returns is the oracle's detect of the frame
     want_k, _ = oracle.detect(f32, n_scales=n_scales, max_blobs=16384)
     assert want[0].shape == want_k.shape
