@@ -181,7 +181,17 @@ int lf_mkd_set_images_device(lf_mkd *h, const float *d_images, uint32_t n_frames
                              uint32_t height, void *stream);
 
 /* Keypoint mode, step 2: sample + describe (patch_gradients.glsl:42-70 onwards).
- * out: [n][128].  Host pointers; synchronous. */
+ * out: [n][128].  Host pointers; synchronous.
+ * Forms of the launch, chosen by the size of the request (the capacity max_out for lf_mkd_detect* and lf_mkd_stream_*):
+ *   whole-patch   one wave walks the 32 rows of its 16 patches and sums them in one chain: any size; ~72 us of latency
+ *                 however few the keypoints;
+ *   row-split     at most 4096 keypoints (16 x the chip's CUs; the reference's own settings are top_n 2000 / max_features
+ *                 3000): the rows of a batch of 32 patches are shared by 4 workgroups (up to 2048 keypoints) or 2, whose
+ *                 partial sums are added in a fixed order -- 43 us at 2000 keypoints, 50 at 3000.
+ * Within a form a descriptor's bits depend on its keypoint and its frame alone (whatever else is in the request, however
+ * often it is computed).  Between forms the pooled sums round differently: descriptors agree to ~3e-6 relative L2 (worst
+ * measured 4.3e-6; the tests hold 1e-5), both within the same distance of the reference.  LF_MKD_KP_SPLIT=1 in the
+ * environment keeps every request in the whole-patch form (2 / 4: that row-split form wherever it fits). */
 int lf_mkd_describe_keypoints(lf_mkd *h, const lf_mkd_keypoint *kps, uint64_t n, float *out);
 int lf_mkd_describe_keypoints_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64_t n,
                                      float *d_out, void *stream);

@@ -348,12 +348,12 @@ bool fused_keypoints(const lf_mkd *h) {
     return h->params.pool_mode == LF_MKD_POOL_F16X3 && !(h->params.flags & LF_MKD_FLAG_UNFUSED_KEYPOINTS);
 }
 int describe_keypoints_on_device(lf_mkd *h, const float *d_kps, const uint32_t *d_frame_of, uint64_t n, float *d_out,
-                                 hipStream_t s) {
+                                 hipStream_t s, uint64_t form_n = 0) {
     if (fused_keypoints(h)) {
         if (int rc = mark(h, s)) return rc;
         launch_describe_keypoints(h->d_pyr, h->pyr_stride, h->pd, d_kps, d_frame_of, h->n_frames, long(n), nullptr,
                                   h->params.patch_scale_factor, h->dc, h->params.angle_mode, d_out, h->num_cus, s, h->d_clk,
-                                  h->d_kp_xchg, h->d_kp_words);
+                                  h->d_kp_xchg, h->d_kp_words, long(form_n));
         LF_HIP(h, hipGetLastError());
         return mark(h, s);
     }
@@ -1110,9 +1110,8 @@ static int detect_stepwise(lf_mkd *h, bool u8, uint32_t width, uint32_t height, 
         return rc;
     if (n_kp == 0) return LF_MKD_OK;
     static_assert(sizeof(lf_mkd_keypoint) == 20, "keypoint layout");
-    if (int rc = lf_mkd_describe_keypoints_device(h, reinterpret_cast<const lf_mkd_keypoint *>(h->d_kps_out), n_kp,
-                                                  h->d_det_desc, s))
-        return rc;
+    // (in the form the recorded pipeline takes for this request's max_out: the same bits)
+    if (int rc = describe_keypoints_on_device(h, h->d_kps_out, nullptr, n_kp, h->d_det_desc, s, max_out)) return rc;
     LF_HIP(h, hipMemcpyAsync(keypoints, h->d_kps_out, n_kp * sizeof(lf_mkd_keypoint), hipMemcpyDeviceToHost, s));
     LF_HIP(h, hipMemcpyAsync(descriptors, h->d_det_desc, n_kp * kOut * 4, hipMemcpyDeviceToHost, s));
     LF_HIP(h, hipStreamSynchronize(s));

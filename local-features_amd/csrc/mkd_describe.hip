@@ -1533,8 +1533,9 @@ size_t kp_split_counter_words(int num_cus) { return 1 + size_t(num_cus / 2 + 8) 
 void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                                const unsigned *frame_of_kp, unsigned n_frames, long n, const unsigned long long *n_dev,
                                float psf, const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream,
-                               unsigned long long *clk, float *xchg, unsigned *xchg_words) {
+                               unsigned long long *clk, float *xchg, unsigned *xchg_words, long form_n) {
     if (n <= 0) return;
+    if (form_n < n) form_n = n;
     // A request of at most one round of 32-keypoint workgroups (<= 32 x CUs = 8192 keypoints: a frame at the reference's own
     // settings, top_n 2000 / max_features 3000) takes the 2 + 2-wave form: every wave has a SIMD to itself -- the describe
     // waves do not share theirs with a producer -- and the launch spreads over twice as many CUs.  It is a launch's latency
@@ -1553,11 +1554,13 @@ void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidD
     // keypoints (2048), R = 2 up to 16 x CUs (4096) -- the reference's own operating point (top_n 2000, max_features 3000).
     // LF_MKD_KP_SPLIT=1 / 2 / 4 forces a form where it fits (tests, A/B runs).
     if (xchg && xchg_words) {
-        const long nb8 = (nbatch32(n) + 7) / 8 * 8;
-        int r = nb8 * 4 <= num_cus ? 4 : (nb8 * 2 <= num_cus ? 2 : 1);
+        // (the form follows form_n -- the capacity of the request the launch belongs to: lf_mkd_detect stage by stage, which
+        //  knows its keypoint count, takes the form its recorded twin, which does not, takes for max_out: the same bits)
+        const long nf8 = (nbatch32(form_n) + 7) / 8 * 8, nb8 = (nbatch32(n) + 7) / 8 * 8;
+        int r = nf8 * 4 <= num_cus ? 4 : (nf8 * 2 <= num_cus ? 2 : 1);
         if (const char *e = getenv("LF_MKD_KP_SPLIT")) {
             const int want = atoi(e);
-            if (want == 1 || ((want == 2 || want == 4) && nb8 * want <= num_cus)) r = want;
+            if (want == 1 || ((want == 2 || want == 4) && nf8 * want <= num_cus)) r = want;
         }
         if (r > 1) {
             ks.split = r; ks.xchg = xchg; ks.xchg_cnt = xchg_words + 1;

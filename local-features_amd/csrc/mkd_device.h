@@ -79,7 +79,9 @@ void launch_sample_patches(const float *pyr, long pyr_stride, const PyramidDesc 
 void launch_describe_keypoints(const float *pyr, long pyr_stride, const PyramidDesc &pd, const float *kps,
                                const unsigned *frame_of_kp, unsigned n_frames, long n, const unsigned long long *n_dev,
                                float psf, const DeviceConsts &dc, int angle_mode, float *out, int num_cus, hipStream_t stream,
-                               unsigned long long *clk = nullptr, float *xchg = nullptr, unsigned *xchg_words = nullptr);
+                               unsigned long long *clk = nullptr, float *xchg = nullptr, unsigned *xchg_words = nullptr,
+                               long form_n = 0);
+// form_n (0: n): the request size the choice between the whole-patch and the row-split forms follows, when it is not n
 // xchg / xchg_words (nullable: the whole-patch forms only): scratch of the row-split form a request of at most 16 x CUs
 // keypoints takes -- kp_split_exchange_bytes(num_cus) bytes and kp_split_counter_words(num_cus) u32 words, the words zero
 // before the first launch (they return to zero at the end of every launch; word 0 counts partial sums that never arrived)

@@ -100,6 +100,42 @@ def pytest_terminal_summary(terminalreporter):
             pass
 
 
+# --- the forms of the keypoint kernel ---------------------------------------------------------------------------------
+# Requests of at most 4096 keypoints take the row-split form (round 6: 2 or 4 workgroups per batch of 32 keypoints, each
+# pooling its share of the 32 patch rows, the partial sums added in a fixed order), larger ones the whole-patch form (one
+# chain of 32 row sums).  Within a form a descriptor's bits depend on its keypoint and frame alone; between forms the sums
+# round differently: ~3e-6 relative L2 after whitening (measured worst 4.3e-6 over tools/check_split.py's sizes).
+# LF_MKD_KP_SPLIT=1 / 2 / 4 in the environment (read per launch) forces a form where it fits.
+CROSS_FORM = 1e-5
+
+
+class kp_form:
+    """with kp_form("1"): ...   -- the launches inside take the whole-patch (1) or a row-split (2, 4) form"""
+
+    def __init__(self, form):
+        self.form, self.old = str(form), None
+
+    def __enter__(self):
+        self.old = os.environ.get("LF_MKD_KP_SPLIT")
+        os.environ["LF_MKD_KP_SPLIT"] = self.form
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("LF_MKD_KP_SPLIT", None)
+        else:
+            os.environ["LF_MKD_KP_SPLIT"] = self.old
+
+
+def assert_same_descriptors(a, b, what=""):
+    """descriptors of the same keypoints from requests of different sizes, i.e. possibly from different forms of the kernel"""
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    e = rel_l2(a, b).max(initial=0.0)
+    _report(f"[cross-form] {what or '-'}: {len(a)} descriptors, worst relative L2 between the two requests {e:.2e}"
+            + (" (same bits)" if np.array_equal(a, b) else ""))
+    assert e < CROSS_FORM, (what, e)
+
+
 def settled_detail(oracle, patches, atan_mode, gate=GATE):
     """(settled mask, contracted descriptors, uncontracted descriptors, mask of patches with a pixel on the shader's
     gx == 0 discontinuity, mask of patches on which the reference's two readings of the blur differ by more than a quarter

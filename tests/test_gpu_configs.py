@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GATE, GOLDEN, ROOT, assert_keypoint_parity, assert_patch_parity, rel_l2
+from conftest import assert_same_descriptors, kp_form, GATE, GOLDEN, ROOT, assert_keypoint_parity, assert_patch_parity, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -97,9 +97,13 @@ def test_configs3_own_form_128_frames_1080p_8192_keypoints_each(lfp, torch, orac
     sub_k, sub_f = d_k[idx].contiguous(), d_f[idx].contiguous()
     out2 = torch.empty((1000, 128), device="cuda")
     torch.cuda.synchronize()
+    with kp_form(1):       # the form the whole batch took: the same bits; the form a request of 1000 takes by itself: close
+        h.describe_keypoints_frames_device(sub_k.data_ptr(), sub_f.data_ptr(), 1000, out2.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+    assert torch.equal(out2, out[idx])
     h.describe_keypoints_frames_device(sub_k.data_ptr(), sub_f.data_ptr(), 1000, out2.data_ptr(), stream.cuda_stream)
     stream.synchronize()
-    assert torch.equal(out2, out[idx])
+    assert_same_descriptors(out2.cpu().numpy(), out[idx].cpu().numpy(), "1000 rows of a large batch in a request of their own")
     # a second run of the whole call (pyramids rebuilt) gives the same bits
     out3 = torch.empty_like(out)
     h.set_images_device(d_img.data_ptr(), nf, w, hgt, stream.cuda_stream)
@@ -137,7 +141,9 @@ def test_configs1_10k_keypoints_on_a_1080p_frame(lfp, torch, oracle):
     rng = np.random.default_rng(13)
     pick = np.sort(rng.choice(n, 1000, replace=False))
     # the same keypoints in a request of their own give the same bits
-    assert np.array_equal(h.describe_keypoints(k5[pick]), d[pick])
+    with kp_form(1):
+        assert np.array_equal(h.describe_keypoints(k5[pick]), d[pick])
+    assert_same_descriptors(h.describe_keypoints(k5[pick]), d[pick], "1000 of 10 000 keypoints in a request of their own")
     # (sample coordinates reach 1920: one ulp there is 1.2e-4 texel, and the two sides round their sin / cos / exp2
     #  differently -- the sampled values agree to that times the local slope)
     assert_keypoint_parity(oracle, h, img, k5[pick], d[pick], what="configs[1]", patch_tol=5e-5)
@@ -209,9 +215,13 @@ def test_configs2_256_frames_640x480_2000_keypoints_each(lfp, torch, oracle):
     sub_k, sub_f = d_k[idx].contiguous(), d_f[idx].contiguous()
     out2 = torch.empty((1000, 128), device="cuda")
     torch.cuda.synchronize()
+    with kp_form(1):       # the form the whole batch took: the same bits; the form a request of 1000 takes by itself: close
+        h.describe_keypoints_frames_device(sub_k.data_ptr(), sub_f.data_ptr(), 1000, out2.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+    assert torch.equal(out2, out[idx])
     h.describe_keypoints_frames_device(sub_k.data_ptr(), sub_f.data_ptr(), 1000, out2.data_ptr(), stream.cuda_stream)
     stream.synchronize()
-    assert torch.equal(out2, out[idx])
+    assert_same_descriptors(out2.cpu().numpy(), out[idx].cpu().numpy(), "1000 rows of a large batch in a request of their own")
     # and a second run of the whole batch gives the same bits
     out3 = torch.empty_like(out)
     h.describe_keypoints_frames_device(d_k.data_ptr(), d_f.data_ptr(), n, out3.data_ptr(), stream.cuda_stream)

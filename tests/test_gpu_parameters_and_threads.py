@@ -14,7 +14,7 @@ import threading
 import numpy as np
 import pytest
 
-from conftest import GATE, assert_keypoint_parity, rel_l2
+from conftest import GATE, assert_keypoint_parity, assert_same_descriptors, kp_form, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -68,12 +68,16 @@ def test_patch_scale_factor_keypoint_entry_points(lfp, torch, oracle, psf):
     for flags in (0, lfp.FLAG_UNFUSED_KEYPOINTS):
         h = lfp.MkdHandle(max_features=256, max_image_width=w, max_image_height=hgt, patch_scale_factor=psf, flags=flags)
         h.set_image(img)
-        outs[flags] = h.describe_keypoints(k5)                  # 3 internal batches
+        if flags == 0:
+            with kp_form(1):                                    # the whole-patch form: the two-launch form's arithmetic
+                whole = h.describe_keypoints(k5)
+        outs[flags] = h.describe_keypoints(k5)                  # 3 internal batches (the row-split form when fused)
         # (keypoints clamped to the last levels -- a few texels wide -- sample near-constant patches: pixels with gx == 0 are
         #  common there, so more patches than usual are set aside end to end; on the GPU's own patch bits all of them are held)
         assert_keypoint_parity(oracle, h, img, k5, outs[flags], what=f"patch_scale_factor {psf:g}, flags {flags}",
                                patch_scale_factor=psf, min_settled=0.85)
-    assert np.array_equal(outs[0], outs[lfp.FLAG_UNFUSED_KEYPOINTS])          # one launch == sampler + patch kernel
+    assert np.array_equal(whole, outs[lfp.FLAG_UNFUSED_KEYPOINTS])            # one launch == sampler + patch kernel
+    assert_same_descriptors(outs[0], whole, f"row-split vs whole-patch form, patch_scale_factor {psf:g}")
     assert rel_l2(outs[0], d24).max() > 0.05
     # the oracle at the default value does NOT describe these: the helper above would fail with the wrong parameter
     ref24 = oracle.describe_keypoints(img, k5[:, :4])
@@ -158,7 +162,8 @@ def _every_entry_point_once(lfp, torch, h, device):
         dk = h.describe_keypoints(kps)
         for _ in range(3):
             k2, d2, _, _ = h.detect(img, 0, 0.0, 4000)
-        assert len(k2) == len(kps) and np.array_equal(d2, dk)
+        assert len(k2) == len(kps)
+        assert_same_descriptors(d2, dk, "detect vs describe_keypoints of the same keypoints")
         h.match(dk, dk[::-1].copy())
         h.pyramid_level(1)
         h.coarse_layer(2, w, hgt)

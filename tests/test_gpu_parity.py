@@ -4,7 +4,7 @@
 import numpy as np
 import pytest
 
-from conftest import assert_keypoint_parity, assert_patch_parity, golden, rel_l2
+from conftest import assert_keypoint_parity, assert_patch_parity, assert_same_descriptors, golden, kp_form, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -626,13 +626,20 @@ def test_the_fused_keypoint_kernel_describes_exactly_what_the_sampler_samples(lf
             h = lfp.MkdHandle(max_features=1024, max_image_width=w, max_image_height=hgt, flags=flags)   # several internal batches
             h.set_image(img)
             out = torch.full((n, 128), -7.0, device="cuda")
-            h.describe_keypoints_device(d_k.data_ptr(), n, out.data_ptr())
+            with kp_form(1):        # the whole-patch form: one chain of row sums, like the patch kernel the two-launch form uses
+                h.describe_keypoints_device(d_k.data_ptr(), n, out.data_ptr())
             outs.append(out.cpu().numpy())
+            if flags == 0:          # ... and the form a request of this size takes by itself: the same keypoints, other rounding
+                out2 = torch.full((n, 128), -7.0, device="cuda")
+                h.describe_keypoints_device(d_k.data_ptr(), n, out2.data_ptr())
+                split = out2.cpu().numpy()
         fused, unfused = outs
         fin = np.isfinite(fused).all(axis=1)
         assert np.array_equal(fin, np.isfinite(unfused).all(axis=1)), (w, hgt)
         assert fin[:4100].all() and fin.sum() >= n - 8
         assert np.array_equal(fused[fin], unfused[fin]), (w, hgt, np.abs(fused[fin] - unfused[fin]).max())
+        assert np.array_equal(fin, np.isfinite(split).all(axis=1))
+        assert_same_descriptors(split[fin], fused[fin], f"adversarial keypoints {w}x{hgt}: row-split vs whole-patch form")
         assert (fused[fin] != -7.0).any(axis=1).all()                      # every row written
         # the tap, described by the patch kernel, is the fused kernel's answer too
         d_p = torch.full((n, 32, 32), -7.0, device="cuda")
@@ -646,3 +653,56 @@ def test_the_fused_keypoint_kernel_describes_exactly_what_the_sampler_samples(lf
         ref_p = oracle.sample_patches(oracle.build_pyramid(img), w, hgt, k5[ok, :4])
         tol = 6e-5 if w > 1000 else 1e-5    # (coordinates up to 1920: one ulp there is 1.2e-4 texel)
         assert np.abs(p[ok] - ref_p).max() < tol, (w, hgt, np.abs(p[ok] - ref_p).max())
+
+
+def test_row_split_forms_of_the_keypoint_kernel(lfp, torch, oracle):
+    """Round 6: requests of at most 4096 keypoints are described by R = 2 or 4 workgroups per batch of 32 keypoints, each
+    pooling its share of the patch rows (partial sums through global memory, added in a fixed order; mkd_describe.hip).  Every
+    form is held to the oracle directly; forms agree with each other to the rounding of their sums; a form is deterministic
+    (repeated launches, the consumer's counters return to zero); frame ids, batch tails and the sizes at which the default
+    form changes are covered; a form that does not fit (more workgroups than CUs) is not taken."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_golden import random_keypoints, smooth_image
+    w, hgt, nf = 512, 384, 3
+    frames = np.ascontiguousarray(np.stack([smooth_image(hgt, w, 130 + f) for f in range(nf)]))
+    d_frames = torch.from_numpy(frames).cuda()
+    h = lfp.MkdHandle(max_features=8192, max_image_width=w, max_image_height=hgt, max_frames=nf)
+    h.set_images_device(d_frames.data_ptr(), nf, w, hgt)
+    rng = np.random.default_rng(8)
+    for n in (1, 31, 33, 500, 2047, 2049, 4096, 4097):
+        k = random_keypoints(n, w, hgt, 140 + n, margin=0.0)
+        k5 = np.ascontiguousarray(np.concatenate([k, np.zeros((n, 1), np.float32)], axis=1))
+        fid = np.ascontiguousarray(rng.integers(0, nf, n).astype(np.int32))
+        d_k, d_f = torch.from_numpy(k5).cuda(), torch.from_numpy(fid).cuda()
+        out = {}
+        for form in ("1", "2", "4", None):
+            o = torch.full((n, 128), float("nan"), device="cuda")
+            runs = []
+            for _ in range(3):
+                if form is None:
+                    h.describe_keypoints_frames_device(d_k.data_ptr(), d_f.data_ptr(), n, o.data_ptr())
+                else:
+                    with kp_form(form):
+                        h.describe_keypoints_frames_device(d_k.data_ptr(), d_f.data_ptr(), n, o.data_ptr())
+                runs.append(o.cpu().numpy().copy())
+            assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2]), (n, form)
+            assert np.isfinite(runs[0]).all(), (n, form)
+            out[form] = runs[0]
+        for form in ("2", "4", None):
+            assert_same_descriptors(out[form], out["1"], f"n = {n}: form {form or 'default'} vs the whole-patch form")
+        fits4, fits2 = (n + 31) // 32 <= 64, (n + 31) // 32 <= 128            # 8 x the batches' multiple of 8 <= 256 CUs
+        assert np.array_equal(out[None], out["4" if fits4 else ("2" if fits2 else "1")]), n       # the default's choice
+        if not fits4:
+            assert np.array_equal(out["4"], out["2" if fits2 else "1"]), n     # a form that does not fit is not forced
+        if not fits2:
+            assert np.array_equal(out["2"], out["1"]), n
+    # each row-split form against the oracle, end to end (frame 0; the helper needs the handle to hold one frame)
+    one = lfp.MkdHandle(max_features=2048, max_image_width=w, max_image_height=hgt)
+    one.set_image(frames[0])
+    k = random_keypoints(700, w, hgt, 150)
+    k5 = np.ascontiguousarray(np.concatenate([k, np.zeros((len(k), 1), np.float32)], axis=1))
+    for form in ("2", "4"):
+        with kp_form(form):
+            d = one.describe_keypoints(k5)
+        assert_keypoint_parity(oracle, one, frames[0], k5, d, what=f"row-split form R = {form}")
