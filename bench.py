@@ -444,6 +444,31 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
         if not good:
             raise StageFailed(what + ("" if ok_local else f" [failed on rank {rank}]"))
 
+    # Before anything depends on it: the point-to-point branch of the gather against the librccl this process finds.  A
+    # one-rank communicator of this rank's own (lf_mkd_comm_loopback: one group of ncclSend + ncclRecv to itself, through
+    # the routine the DIRECT form posts its transfers with) moves a shard-sized block and the rows must arrive -- at N = 1
+    # too, where the gather itself has no peer to talk to.
+    def loopback(c, rows, tag):
+        src = out[:rows]
+        dst = torch.full((rows + 1, 128), -3.0, device="cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        c.loopback(src.data_ptr(), dst.data_ptr(), rows, s)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        good = bool(torch.equal(dst[:rows], src)) and bool((dst[rows] == -3.0).all().item())
+        res[tag] = {"rows": rows, "ms": round(ms, 3), "arrived": good, "gb_s": rows * 512 / ms / 1e6}
+        return good
+    ok_loop = True
+    try:
+        self_comm = lfp.Comm(hm, lfp.comm_unique_id(), 1, 0)
+        res["rccl_version"] = self_comm.info()[0]
+        ok_loop = loopback(self_comm, n, "rccl_loopback_own_communicator")
+        self_comm.close()
+    except Exception as e:
+        res["rccl_loopback_error"] = f"{type(e).__name__}: {e}"
+        ok_loop = False
+    agree(ok_loop, "RCCL loopback (grouped ncclSend / ncclRecv to this rank): the rows did not arrive")
     comm = None
     if world > 1:
         # the gather goes through the C boundary (lf_mkd_allgather_descriptors over RCCL: what the Rust crate calls);
@@ -464,6 +489,10 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
                 comm = None
                 res["comm_error"] = "another rank could not create its communicator"
         res["allgather_transport"] = "lf_mkd_allgather_descriptors (RCCL, C boundary)" if comm else "torch.distributed"
+        if comm:      # the same self-transfer on the N-rank communicator the gather is about to use
+            agree(loopback(comm, min(n, 65536), "rccl_loopback_gather_communicator"),
+                  "RCCL loopback on the gather's communicator: the rows did not arrive")
+        res["gather_form_run"] = {}
         for mode in ("direct", "ring"):
             run = lambda: sharding.all_gather_descriptors(out, mode=mode, out=gathered, counts=counts, comm=comm)
             run()                                                       # first call sets up the communicator's channels
@@ -471,6 +500,9 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
             res[f"allgather_{mode}_ms"] = best
             res[f"allgather_{mode}_ms_per_rank"] = per_rank(round(mine, 3))
             res[f"allgather_{mode}_gbs_per_rank"] = res["received_bytes_per_rank"] / best / 1e6
+            # which form the library ran for this request (RING falls back to DIRECT on unequal shards)
+            res["gather_form_run"][mode] = ({lfp.GATHER_DIRECT: "direct (grouped ncclSend / ncclRecv)", lfp.GATHER_RING: "ring (ncclAllGather)"}
+                                            .get(comm.last_form(), "?") if comm else "torch.distributed all_gather")
         res["allgather_ms"] = min(res["allgather_direct_ms"], res["allgather_ring_ms"])
         # priced against xGMI: a rank receives (N - 1) shards, and in the direct form they arrive on N - 1 of its 7 point-to-point
         # links at once (~153 GB/s per link and direction); a ring moves the same bytes

@@ -118,12 +118,12 @@ struct lf_mkd {
     uint64_t match_a_cap = 0, match_b_cap = 0, match_part_cap = 0, match_in_cap = 0, match_out_cap = 0;
     unsigned char *d_match_rec = nullptr;      // two-pass form: candidate records, their counts, |a| per row, two words
     unsigned char *d_match_cnt = nullptr;      // (largest |b| as float bits, number of overflowed rows)
-    float *d_match_norm = nullptr;
+    float *d_match_norm = nullptr, *d_match_floor = nullptr;   // (floor: the bounds the screen's b splits share, per a row)
     unsigned *d_match_misc = nullptr;
     unsigned char *d_match_few_tiles = nullptr;   // the overflowed rows' own tiles; their indices, exclusion ranges, partials
     unsigned *d_match_few = nullptr;
     uint64_t match_rec_cap = 0, match_cnt_cap = 0, match_norm_cap = 0, match_misc_cap = 0, match_few_tiles_cap = 0,
-             match_few_cap = 0;
+             match_few_cap = 0, match_floor_cap = 0;
     int num_cus = 256;
     // LF_MKD_FLAG_KERNEL_TIMING: (start, end) of the describe kernel per batch
     std::vector<hipEvent_t> ev_pending, ev_free;
@@ -716,7 +716,7 @@ void lf_mkd_destroy(lf_mkd *h) {
                     h->d_match_part,   h->d_match_in,    h->d_match_out,   h->d_mf_padded,   h->d_mf_list,
                     h->d_mf_frame_start, h->d_mf_offsets, h->d_mf_frame_of,
                     h->d_match_rec,    h->d_match_cnt,   h->d_match_norm,  h->d_match_misc,
-                    h->d_match_few_tiles, h->d_match_few, h->d_kp_xchg, h->d_kp_words};
+                    h->d_match_few_tiles, h->d_match_few, h->d_kp_xchg, h->d_kp_words, h->d_match_floor};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
@@ -1646,6 +1646,7 @@ static int match_device_impl(lf_mkd *h, const float *d_a, uint64_t na, const flo
     if (int rc = grow(h, &h->d_match_rec, &h->match_rec_cap, match_record_bytes(long(chunk), splits), 1)) return rc;
     if (int rc = grow(h, &h->d_match_cnt, &h->match_cnt_cap, match_count_bytes(long(chunk), splits), 1)) return rc;
     if (int rc = grow(h, &h->d_match_norm, &h->match_norm_cap, chunk, sizeof(float))) return rc;
+    if (int rc = grow(h, &h->d_match_floor, &h->match_floor_cap, chunk, sizeof(float))) return rc;   // the splits' shared bounds
     if (int rc = ensure_match_misc(h, s)) return rc;
     if (int rc = grow(h, &h->d_match_few_tiles, &h->match_few_tiles_cap, match_few_tiles_bytes(), 1)) return rc;
     if (int rc = grow(h, &h->d_match_few, &h->match_few_cap, match_few_words(), sizeof(unsigned))) return rc;
@@ -1662,7 +1663,7 @@ static int match_device_impl(lf_mkd *h, const float *d_a, uint64_t na, const flo
         if (at) LF_HIP(h, hipMemsetAsync(n_over, 0, sizeof(int), s));
         launch_match_split(a, n, h->d_match_a, h->d_match_norm, nullptr, s);
         launch_match_screen(h->d_match_a, n, h->d_match_b, long(nb), lo, hi, splits, h->d_match_norm, b_max,
-                            h->d_match_rec, h->d_match_cnt, s);
+                            h->d_match_rec, h->d_match_cnt, s, reinterpret_cast<int *>(h->d_match_floor));
         launch_match_verify(a, n, d_b, h->d_match_norm, b_max, h->d_match_rec, h->d_match_cnt, splits, ratio,
                             d_match + at, best, second, n_over, reinterpret_cast<int *>(h->d_match_few), s);
         // rows whose records overflowed (more than 64 near-best candidates in one lane's share of b) are redone by the

@@ -163,9 +163,11 @@ void launch_match_few(const float *a, const unsigned char *b_tiles, long nb, con
 // *n_over (device, zeroed by the caller) counts a rows whose records overflowed
 size_t match_record_bytes(long na, int splits);
 size_t match_count_bytes(long na, int splits);
+// shared_floor [na] ints (nullable): scratch through which the b splits of a query tell each other their running bounds
 void launch_match_screen(const unsigned char *a_tiles, long na, const unsigned char *b_tiles, long nb,
                          const unsigned *excl_lo, const unsigned *excl_hi, int splits, const float *a_norms,
-                         const unsigned *b_max_norm_bits, void *rec, void *rec_info, hipStream_t stream);
+                         const unsigned *b_max_norm_bits, void *rec, void *rec_info, hipStream_t stream,
+                         int *shared_floor = nullptr);
 void launch_match_verify(const float *a, long na, const float *b, const float *a_norms, const unsigned *b_max_norm_bits,
                          const void *rec, const void *rec_info, int splits, float ratio, int *match, float *best,
                          float *second, int *n_over, int *over_rows, hipStream_t stream);

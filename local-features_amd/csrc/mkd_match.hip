@@ -490,16 +490,30 @@ constexpr int kLanesPerRow = 4;  // lanes that hold values of one a row: streams
 // second, count) of a lane's stream live in LDS and only the threshold second - margin in a register.  Common path per
 // half tile: 16 MFMA, then two max3 and a compare per sub-tile; the rare path (a candidate near the threshold) fetches
 // its state from LDS and writes the record.
+//
+// The splits of a query share their bounds (round 6).  Every b split of a query starts with nothing -- until its running
+// second best has grown, every value is a candidate and the rare path is the common one: at 65 536 x 65 536 (4 splits of
+// 16 384 rows) the candidate path is 45 % of the kernel's time (timing-only build without it: 0.81 of 1.48 ms), at
+// 2^20 x 2^20 (one split) nothing; profiles/r06_matcher.md.  Any split's running second-largest is a lower bound of the
+// query's u, so the splits tell each other theirs as they go (shared_floor below): -10 % of the call at 65 536^2, identical
+// decisions.  (A separate first pass over a sample of b, leaving a floor for every split, was built too: it takes 17 % off
+// the main pass and costs as much itself -- the start of a scan is its most expensive part whoever runs it.  Removed.)
 __global__ __launch_bounds__(512, 4) void match_screen(const unsigned char *__restrict__ a_tiles, long na,
                                                        const unsigned char *__restrict__ b_tiles, long nb,
                                                        long tiles_per_split, const unsigned *__restrict__ excl_lo,
                                                        const unsigned *__restrict__ excl_hi,
                                                        const float *__restrict__ a_norms,
                                                        const unsigned *__restrict__ b_max_norm_bits,
-                                                       uint2 *rec, uint2 *rec_info) {
+                                                       uint2 *rec, uint2 *rec_info,
+                                                       int *__restrict__ shared_floor, int share_every) {
+    // shared_floor [na] (nullable; float bits as int, -inf before the launch): the splits of a query tell each other their
+    // bounds as they go -- every share_every stages a lane publishes the bound of one of the wave's 64 rows (atomic max;
+    // positive floats order like their bits) and takes the others' back.  Any split's bound is a lower bound of the query's
+    // u (the argument at the top): the splits then warm each other instead of each starting cold.
     __shared__ __attribute__((aligned(16))) unsigned char s_b[2][kStageTiles][kTileBytes / 2];
     __shared__ float2 s_top[kSub][512];                     // a stream's running (best, second)
     __shared__ float s_margin[kSub][512];
+    __shared__ float s_floor[kSub][512];                    // what the query's other splits have reached (-inf until they say)
     __shared__ int s_cnt[kSub][512];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = lane & 15, g = lane >> 4;
@@ -523,9 +537,11 @@ __global__ __launch_bounds__(512, 4) void match_screen(const unsigned char *__re
 #pragma unroll
         for (int s = 0; s < 4; ++s) ah[j][s] = *reinterpret_cast<const h8 *>(src + s * 2048);
         const bool live = arow < na;
-        thr[j] = live ? -INFINITY : INFINITY;             // a dead lane never has a candidate
+        const float fl = -INFINITY;
+        thr[j] = live ? fl : INFINITY;                    // a dead lane never has a candidate
         s_top[j][threadIdx.x] = make_float2(-INFINITY, -INFINITY);
         s_cnt[j][threadIdx.x] = 0;
+        s_floor[j][threadIdx.x] = fl;
         s_margin[j][threadIdx.x] = live ? screen_margin(a_norms[arow], b_max) : 0.f;
         if (live) {
             rec_info[((long)blockIdx.y * na + arow) * kLanesPerRow + g] = make_uint2(0u, 0xff800000u);   // (count, lost)
@@ -568,7 +584,7 @@ __global__ __launch_bounds__(512, 4) void match_screen(const unsigned char *__re
                 b1 = fmaxf(b1, o.x);
                 s2 = fmaxf(s2, o.y);
             }
-            return fmaxf(b2, s2) - margin;
+            return fmaxf(fmaxf(b2, s2) - margin, s_floor[j][threadIdx.x]);
         };
         float from = row_bound();
         thr[j] = from;
@@ -646,12 +662,44 @@ __global__ __launch_bounds__(512, 4) void match_screen(const unsigned char *__re
         }
     };
     if (t_begin < t_end) issue(t_begin, 0);
+    int shared_seen = (int)0xff800000;        // what the other splits said last time (applied a stage later: no stall)
+    const int sj = lane >> 4, sn = lane & 15; // the (sub-tile, row) this lane speaks for when bounds are shared
+    const long srow = a_tile0 * kTileRows + sn + 16 * sj;
     for (long t = t_begin; t < t_end; t += kStageTiles) {
         const int buf = (int)(((t - t_begin) / kStageTiles) & 1);
         __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of the stage have landed
 #ifndef LF_SCREEN_ABLATE_BARRIER
         __syncthreads();                      // ... and everybody's; everybody is also done with the other buffer
 #endif
+        if (shared_floor && share_every) {
+            const long stage = (t - t_begin) / kStageTiles;
+            if (stage % share_every == 1 && shared_seen > 0) {
+                // a stage after the exchange: the answer has landed with the stage's data; the row's four lanes take it
+                const float fl = __int_as_float(shared_seen);
+#pragma unroll
+                for (int k = 0; k < kLanesPerRow; ++k) {
+                    float *p = &s_floor[sj][(threadIdx.x & ~63) + 16 * k + sn];
+                    *p = fmaxf(*p, fl);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < kSub; ++j) thr[j] = fmaxf(thr[j], s_floor[j][threadIdx.x]);
+            }
+            if (stage % share_every == 0 && stage > 0 && srow < na) {
+                const float2 *row_top = &s_top[sj][(threadIdx.x & ~63) + sn];
+                float b1 = -INFINITY, b2 = -INFINITY, s2 = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < kLanesPerRow; ++k) {
+                    const float2 o = row_top[16 * k];
+                    b2 = o.x > b1 ? b1 : fmaxf(b2, o.x);
+                    b1 = fmaxf(b1, o.x);
+                    s2 = fmaxf(s2, o.y);
+                }
+                const float mine = fmaxf(fmaxf(b2, s2) - s_margin[sj][(threadIdx.x & ~63) + sn], s_floor[sj][(threadIdx.x & ~63) + sn]);
+                shared_seen = mine > 0.f ? atomicMax(shared_floor + srow, __float_as_int(mine))
+                                         : __hip_atomic_load(shared_floor + srow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         if (t + kStageTiles < t_end) issue(t + kStageTiles, buf ^ 1);
 #pragma unroll
         for (int u = 0; u < kStageTiles; ++u)
@@ -757,6 +805,7 @@ int match_splits(long na, long nb, int num_cus) {
     want = want < 1 ? 1 : want;
     want = want > b_tiles ? b_tiles : want;
     want = want > 1024 ? 1024 : want;
+    if (const char *e = getenv("LF_MKD_MATCH_SPLITS")) want = atol(e) < b_tiles ? atol(e) : b_tiles;   // (experiments)
     return (int)(want < 1 ? 1 : want);
 }
 
@@ -837,14 +886,19 @@ size_t match_count_bytes(long na, int splits) { return (size_t)splits * na * kLa
 
 void launch_match_screen(const unsigned char *a_tiles, long na, const unsigned char *b_tiles, long nb,
                          const unsigned *excl_lo, const unsigned *excl_hi, int splits, const float *a_norms,
-                         const unsigned *b_max_norm_bits, void *rec, void *rec_info, hipStream_t stream) {
+                         const unsigned *b_max_norm_bits, void *rec, void *rec_info, hipStream_t stream, int *shared_floor) {
     if (na <= 0) return;
     const long a_blocks = (na + kWaves * kATiles * kTileRows - 1) / (kWaves * kATiles * kTileRows);
     const long n_b_tiles = (nb + kTileRows - 1) / kTileRows;
     const long per = (n_b_tiles + splits - 1) / splits;
+    // the splits share their bounds where there are several of moderate length (LF_MKD_MATCH_SHARE=stages, 0 = off)
+    int share_every = shared_floor && splits >= 2 && per <= 4096 ? 8 : 0;
+    if (const char *e = getenv("LF_MKD_MATCH_SHARE")) share_every = shared_floor && splits >= 2 ? atoi(e) : 0;
+    if (share_every > 0)
+        (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(shared_floor), (int)0xff800000, (size_t)na, stream);
     hipLaunchKernelGGL(match_screen, dim3((unsigned)a_blocks, (unsigned)splits), dim3(512), 0, stream, a_tiles, na, b_tiles,
                        nb, per, excl_lo, excl_hi, a_norms, b_max_norm_bits, static_cast<uint2 *>(rec),
-                       static_cast<uint2 *>(rec_info));
+                       static_cast<uint2 *>(rec_info), share_every > 0 ? shared_floor : nullptr, share_every);
 }
 
 void launch_match_verify(const float *a, long na, const float *b, const float *a_norms, const unsigned *b_max_norm_bits,
