@@ -1002,7 +1002,9 @@ __device__ __forceinline__ void kp_produce(const KpSource &ks, const LevelTable 
     KpSampler<W> sm(ks, lt, lvl_offset, n, s_mem, pw, lane);
     KpTaps ta, tb;
     int set = 0, slot0 = 0;
-    // the first seven quarters of the first batch, before the describe waves' first row barrier.  (Letting the describe
+    // the first seven quarters of the first batch, before the describe waves' first row barrier.  (Two tap sets in flight
+    // here, as in kp_produce_split, was measured in round 6: 76.5 / 79.2 / 93.0 us against 76.9 / 78.7 / 93.6 at 6000 / 8192 /
+    // 10 000 keypoints -- nothing.  Letting the describe
     // waves, idle until then, sample every other one of them was tried: nothing to gain -- same-box, a one-round launch of
     // 10 000 keypoints took 96 us either way.)
     sm.load_geometry(walk.cur, 0);

@@ -30,4 +30,9 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/kp3_write -- python3 $R/t
 # the reference's own settings on one 1080p frame (3000 keypoints): HBM traffic of the same call
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/kpr_fetch -- python3 $R/tools/prof_keypoints.py refdefaults > $OUT/kpr_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/kpr_write -- python3 $R/tools/prof_keypoints.py refdefaults > $OUT/kpr_write.log 2>&1
+# the whitening projection on its own (north_star: "MFMA utilisation on the projection"): phase clocks of a -DLF_PHASE_TIMING
+# build of the same sources (tools/ab_build.sh pt "-DLF_PHASE_TIMING", built beforehand: ab/ travels with the snapshot)
+if [ -f $R/ab/liblf_mkd_pt.so ]; then
+  (cd $R && LF_MKD_LIB=ab/liblf_mkd_pt.so python3 tools/phase_timing.py 1048576 gpurun_out/${TAG}_projection.json > $OUT/phase_timing.txt 2>&1) || echo "phase timing failed" >> $OUT/phase_timing.txt
+fi
 tail -1 $OUT/stats.log | cut -c1-400

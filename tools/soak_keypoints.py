@@ -25,6 +25,7 @@ t0 = time.time()
 for r in range(rounds):
     w, h = int(rng.integers(48, 1400)), int(rng.integers(40, 900))
     nf = int(rng.integers(1, 4))
+    psf = float(rng.choice([12.0, 24.0, 24.0, 32.0, 48.0]))    # patch_scale_factor (lib.rs:34-52): the default and away from it
     kind = r % 3
     frames = []
     for f in range(nf):
@@ -47,17 +48,20 @@ for r in range(rounds):
     d_k, d_f = torch.from_numpy(k5).cuda(), torch.from_numpy(fid).cuda()
     outs = []
     for flags in (0, lfp.FLAG_UNFUSED_KEYPOINTS):
-        hnd = lfp.MkdHandle(max_features=1024, max_image_width=w, max_image_height=h, max_frames=nf, flags=flags)
+        hnd = lfp.MkdHandle(max_features=1024, max_image_width=w, max_image_height=h, max_frames=nf, flags=flags,
+                            patch_scale_factor=psf)
         o = torch.empty((len(k5), 128), device="cuda")
         hnd.set_images_device(d_img.data_ptr(), nf, w, h)
         hnd.describe_keypoints_frames_device(d_k.data_ptr(), d_f.data_ptr(), len(k5), o.data_ptr())
         outs.append(o.cpu().numpy())
-    same = np.array_equal(outs[0], outs[1])
+    # (requests of at most 4096 keypoints take the row-split form when fused: its sums round differently from the patch
+    #  kernel's, which the two-launch form uses -- same bits above that size, within 1e-5 below)
+    same = np.array_equal(outs[0], outs[1]) or float(rel_l2(outs[0], outs[1]).max()) < 1e-5
     errs = []
-    one = lfp.MkdHandle(max_features=1024, max_image_width=w, max_image_height=h)
+    one = lfp.MkdHandle(max_features=1024, max_image_width=w, max_image_height=h, patch_scale_factor=psf)
     for f in range(nf):
         sel = fid == f
-        ref_p = orc.sample_patches(orc.build_pyramid(frames[f]), w, h, k5[sel, :4])
+        ref_p = orc.sample_patches(orc.build_pyramid(frames[f]), w, h, k5[sel, :4], psf)
         one.set_image(frames[f])                        # the GPU's own patches of these keypoints (the verification tap)
         d_p = torch.empty((int(sel.sum()), 32, 32), device="cuda")
         d_ks = torch.from_numpy(k5[sel]).cuda()
@@ -73,7 +77,7 @@ for r in range(rounds):
         errs.append(e[ok]); tot += int(sel.sum()); aside += int((~ok).sum()); over += int((e[ok] >= GATE).sum())
     e = np.concatenate(errs)
     worst = max(worst, float(e.max()))
-    print(f"round {r:2d}: {nf} frame(s) {w}x{h} kind {kind}, {len(k5)} keypoints: fused == two-launch {same}; settled max {e.max():.2e} "
+    print(f"round {r:2d}: {nf} frame(s) {w}x{h} kind {kind}, patch_scale_factor {psf:g}, {len(k5)} keypoints: fused ~ two-launch {same}; settled max {e.max():.2e} "
           f"p99.9 {np.quantile(e, 0.999):.2e}; finite {bool(np.isfinite(outs[0]).all())}", flush=True)
 print(f"soak_keypoints: {tot} keypoints, {aside} set aside (the reference's own two readings of the blur differ on either side's "
       f"patch), worst settled relative L2 end to end {worst:.2e}, >= 1e-4: {over}; describe stage on the GPU's own patch bits, "
