@@ -531,7 +531,7 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
         ms, mine = timed(run)
         r = {"match_ms": ms, "match_ms_per_rank": per_rank(round(mine, 3)),
              "rows_redone_by_full_scan": int(hm.match_overflowed(s))}
-        # the match stage is matrix-core work: one 128-long f16 dot product per pair in the screening pass
+        # the match stage is matrix-core work: one 128-long f16 dot product per pair in the screening pass (NOTEBOOK.md 4d)
         tf = 2.0 * 128 * float(n) * n * world / (ms * 1e-3) / 1e12          # per GPU
         r["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / MFMA_F16_PEAK_TFLOPS, "flop_per_pair": 256, "traffic": None,
@@ -779,7 +779,7 @@ def main():
         # the same workload with the pooling contraction in exact f32 arithmetic (LF_MKD_POOL_F32, the verification mode)
         alt_f32 = side_figure(lfp.ANGLE_SHADER, lfp.POOL_F32)
         # ... and with the harmonics' cross terms in e2m3 (LF_MKD_POOL_F16_FP6: round 4's formulation experiment, kept as a
-        # mode; 51 instead of 81 matrix instructions per wave-row at ~6 x the default mode's error)
+        # mode; 51 instead of 81 matrix instructions per wave-row at ~6 x the default mode's error, NOTEBOOK.md section 11)
         alt_fp6 = side_figure(lfp.ANGLE_SHADER, lfp.POOL_F16_FP6)
 
     # sanity on the timed output: finite, unit norm (a wrong-but-fast kernel must not pass silently)

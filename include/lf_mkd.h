@@ -66,7 +66,7 @@ typedef enum { LF_MKD_ANGLE_SHADER = 0, LF_MKD_ANGLE_EXACT = 1, LF_MKD_ANGLE_EXA
  *           descriptors/s per MI355X in patch mode.
  * F32     : v_mfma_f32_16x16x4_f32, bit-for-bit an f32 fma chain; the verification mode, bound by the f32 MFMA
  *           rate at ~117 M descriptors/s (2.1x slower).
- * F16_FP6 : an experiment kept as a mode (round 4): hi*hi in f16 as above, the two cross terms of the
+ * F16_FP6 : an experiment kept as a mode (round 4, NOTEBOOK.md section 11): hi*hi in f16 as above, the two cross terms of the
  *           harmonics' streams in ONE block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 per accumulator tile with e2m3
  *           operands (51 instead of 81 matrix instructions per wave-row).  e2m3 carries three bits below its block's
  *           maximum: descriptors within 3e-5 of the oracle (measured worst 2.95e-5, mean 2.0e-5, over the goldens and 4099

@@ -3,7 +3,7 @@
 // A PRODUCT build defines none of the macros below: every switch is then `false`, every hook a no-op that folds away, and
 // the kernel source itself carries no preprocessor conditionals -- it reads as the product.  An instrument build
 // (tools/ab_build.sh NAME "-DLF_ABLATE_MMA", tools/phase_timing.py, ...) flips one of them; such a build produces WRONG
-// descriptors by design and exists only to be timed (DESIGN.md sections 4, 9, 10 quote what they measured).
+// descriptors by design and exists only to be timed (NOTEBOOK.md sections 4, 9, 10 quote what they measured).
 //
 //   LF_ABLATE_BLOAD        no LUT fragment reads from LDS            LF_ABLATE_SPLIT     no f16 hi / lo split of the streams
 //   LF_ABLATE_MMA          no matrix instructions (operands kept)    LF_ABLATE_FRONT     no blur, no gradient direction
@@ -72,7 +72,7 @@ constexpr bool kNoTaps = false;
 #ifdef LF_KP_PRODUCER_PRIO
 constexpr int kProducerPrio = LF_KP_PRODUCER_PRIO;
 #else
-constexpr int kProducerPrio = 2;      // the product's setting (same-box A/B: +4 % over 0)
+constexpr int kProducerPrio = 2;      // the product's setting (same-box A/B: +4 % over 0; NOTEBOOK.md 4f)
 #endif
 #ifdef LF_KP_CONSUMER_PRIO
 constexpr int kConsumerPrio = LF_KP_CONSUMER_PRIO;

@@ -504,7 +504,7 @@ __device__ __forceinline__ void pool_harmonics(const f32x2 (&m)[4], const f32x2 
     }
 }
 
-// LF_POOL_F16_FP6 (an experiment kept as a mode): the harmonics with hi x hi in f16 (8 instructions per
+// LF_POOL_F16_FP6 (an experiment kept as a mode; NOTEBOOK.md section 11): the harmonics with hi x hi in f16 (8 instructions per
 // harmonic) and BOTH cross terms of every accumulator tile in one v_mfma_scale_f32_16x16x128_f8f6f4 with e2m3 operands (7):
 // a lane's 32 K slots hold (a_e, 2048 r_e) of its 8 pixels for the cos stream (fields 0-15 = registers 0-2) and for the
 // sin stream (16-31 = registers 3-5), a = the stream value, r = a - f16(a), all divided by the lane's block scale S (from

@@ -5,7 +5,7 @@
 // The similarity matrix is a GEMM (K = 128) and lives on the matrix cores, b on the M side: a lane of an accumulator
 // tile then holds ONE a column and a few b rows, so the running best / second best of an a row is an in-register
 // reduction.  Both sides are split once by `match_split` into f16 hi / lo MFMA operand tiles, so the hot loops only move
-// fragments.  Two forms (lf_mkd.h), chosen by problem size in lf_mkd_match_device:
+// fragments.  Two forms (lf_mkd.h; NOTEBOOK.md 4d), chosen by problem size in lf_mkd_match_device:
 //
 //   SCAN (`match_scan` + `match_merge`): every pair from three terms, hi*hi + lo*hi + hi*lo (f32 accumulate, ~2^-21
 //   relative), v_mfma_f32_32x32x16_f16.  Workgroup = 8 waves x 64 a rows resident in registers (2 x 64 VGPRs of fragments

@@ -42,7 +42,7 @@ def test_patch_goldens(lfp, name):
 
 
 def test_fp6_cross_term_mode_stays_inside_the_gate(lfp, torch, oracle):
-    """LF_MKD_POOL_F16_FP6 (an experiment kept as a mode): the harmonics' cross terms in e2m3.  Its
+    """LF_MKD_POOL_F16_FP6 (an experiment kept as a mode, NOTEBOOK.md section 11): the harmonics' cross terms in e2m3.  Its
     error is seven times the default mode's (2.95e-5 worst against 4.2e-6) -- the reason it is not the default -- and must still be inside the gate on every
     patch: goldens of the three models, 4096 random and the structured patches, both request sizes (4- and 8-wave forms),
     ragged tail, every angle mode.  Also: the keypoint entry points work in this mode (two-launch form)."""
@@ -76,7 +76,7 @@ def test_fp6_cross_term_mode_stays_inside_the_gate(lfp, torch, oracle):
             assert np.isfinite(d).all() and np.abs(np.linalg.norm(d, axis=1) - 1).max() < 1e-5
     print(f"fp6 cross-term mode: worst relative L2 over goldens + 4099 patches x 3 angle modes x 2 forms = {worst:.2e}")
     assert worst > 8e-6         # (if this ever fails the mode has become as good as the default: make it the default)
-    assert worst < 4e-5         # the figure include/lf_mkd.h, README.md and DESIGN.md section 11 quote: 2.95e-5 measured
+    assert worst < 4e-5         # the figure include/lf_mkd.h, README.md and NOTEBOOK.md section 11 quote: 2.95e-5 measured
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     from gen_golden import random_keypoints, smooth_image

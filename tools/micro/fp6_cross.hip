@@ -1,4 +1,4 @@
-// fp6 cross terms for the pooling contraction: can the two cross terms of the
+// fp6 cross terms for the pooling contraction (NOTEBOOK.md section 8.1): can the two cross terms of the
 // f16 hi/lo split -- hi_s x lo_L and lo_s x hi_L, 54 of the 81 v_mfma_f32_16x16x32_f16 per wave-row -- ride on
 // v_mfma_scale_f32_16x16x128_f8f6f4 with e2m3 operands (4x the K at the cycles of the f16 form)?
 //   1. layout:  which input of v_cvt_scalef32_2xpk16_fp6_f32 / v_cvt_scalef32_pk32_fp6_f16 lands in which 6-bit field, and

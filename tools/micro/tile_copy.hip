@@ -1,5 +1,5 @@
 // How fast a batch of small frames (256 x 640 x 480 f32) streams through the chip by workgroup-to-texel mapping: what the
-// pyramid / a-trous / scan kernels of the detector rows can expect from HBM.
+// pyramid / a-trous / scan kernels of the detector rows can expect from HBM (NOTEBOOK.md section 10).
 //   linear   one dword per lane, consecutive workgroups consecutive kilobytes
 //   tile     256 columns x R rows per workgroup (the kernels' mapping: grid (ceil(w/256), ceil(h/R), frames)), each row a
 //            1 KB segment, `taps` overlapping loads per output (columns x-2 .. x+2 clamped) summed

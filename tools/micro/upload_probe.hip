@@ -1,4 +1,4 @@
-// How a host image reaches the device fastest (round 5): the reference's callers hand detect_top_n a
+// How a host image reaches the device fastest (round 5, NOTEBOOK.md section 12): the reference's callers hand detect_top_n a
 // pageable host array (examples/match_images/src/main.rs:44-76), 4096 x 3072 f32 = 50 MB in its own benchmark
 // (benches/bench.rs:41-112).  Measures, per strategy, wall time from the call to "data usable on the device":
 //   pageable-whole     one hipMemcpyAsync from the caller's (pageable) array + sync            (what lf_mkd_detect did)

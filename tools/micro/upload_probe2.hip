@@ -1,4 +1,4 @@
-// Second upload probe (round 5): can a kernel pull the caller's image over PCIe itself?
+// Second upload probe (round 5, NOTEBOOK.md section 12): can a kernel pull the caller's image over PCIe itself?
 // upload_probe showed a copy kernel reading pinned host memory at the DMA engines' rate (56 GB/s) with 64 workgroups.  The
 // caller's array is pageable, so it has to be registered first: what does that cost on FRESH memory (upload_probe reused one
 // array the runtime had already pinned for its own staging), and does the pull run at full rate from registered memory?
