@@ -260,11 +260,13 @@ int lf_mkd_filter_extrema_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, ui
  * own size, and never pays a recording; a camera loop pays it on its second frame (LF_MKD_DETECT_RECORD_AFTER=k in the
  * environment at lf_mkd_create: k sightings before recording, 0 = record at once; cost of the three kinds of call:
  * INTEGRATION.md section 2).  Handles whose keypoint mode takes the two-launch form (LF_MKD_POOL_F32, LF_MKD_POOL_F16_FP6,
- * LF_MKD_FLAG_UNFUSED_KEYPOINTS) always take the stage-by-stage form here.  A frame of 12 MB or more crosses PCIe in two pieces, and the
- * pipeline's front (level 0, the a-trous layers, the extremum scan) runs on the rows the first piece allows while the second
- * is on its way (LF_MKD_DETECT_BANDS=0 in the environment: one piece); same results bit for bit.  Afterwards the handle holds
- * the frame like lf_mkd_set_image.  (benches/bench.rs on houses.jpg, 4096 x 3072, top 2000: 1.29 ms, 0.94 of it the 50 MB
- * upload at the link's 56 GB/s; lf_mkd_detect_u8 on the same frame: 0.68 ms.) */
+ * LF_MKD_FLAG_UNFUSED_KEYPOINTS) always take the stage-by-stage form here.  A frame of 6 MB or more crosses PCIe in pieces
+ * (two to four, planned from a model of the link and of the pipeline's front when the request is recorded), and the front --
+ * level 0, the a-trous layers, the extremum scan -- runs on the rows a piece completes while the next one is on its way
+ * (LF_MKD_DETECT_BANDS=0 in the environment: one piece; LF_MKD_BAND_PIECES=k / LF_MKD_BAND_SPLIT=f1,f2,..: k equal pieces /
+ * cuts at these fractions of the height, for tests); same results bit for bit.  Afterwards the handle holds the frame like
+ * lf_mkd_set_image.  (benches/bench.rs on houses.jpg, 4096 x 3072, top 2000, n_scales 3: 1.25 ms, 0.91 of it the 50 MB upload
+ * at the link's 56 GB/s; lf_mkd_detect_u8 on the same frame: 0.66 ms; n_scales 5: 1.30 / 0.80 ms.) */
 int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height, uint32_t top_n,
                   float min_size, lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out,
                   uint64_t *n_out, uint64_t *dropped_blobs, uint64_t *dropped_features);

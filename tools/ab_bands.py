@@ -24,7 +24,7 @@ def run(ns, img, w, h, env):
     for k in ("LF_MKD_DETECT_BANDS", "LF_MKD_BAND_SPLIT", "LF_MKD_BAND_PIECES"):
         os.environ.pop(k, None)
     if env != "default":
-        k, v = env.split("=")
+        k, v = env.split("=")                      # BANDS=0 | PIECES=k | SPLIT=f1,f2,..
         os.environ["LF_MKD_DETECT_" + k if k == "BANDS" else "LF_MKD_BAND_" + k] = v
     lf = lfp.MkdHandle(max_features=2000, max_image_width=w, max_image_height=h, n_scales=ns, max_blobs=10000,
                        flags=lfp.FLAG_KERNEL_TIMING)
@@ -50,6 +50,6 @@ for ns in (3, 5):
             if ref is None:
                 ref = d
             assert np.array_equal(ref, d), (ns, name, env)            # every plan returns the same bits
-            say(f"n_scales {ns} {name:>3} {env:>10}: {ms:7.3f} ms  ({sp[0]:.3f} + {sp[1]:.3f} + {sp[2]:.3f})")
+            say(f"n_scales {ns} {name:>3} {env:>24}: {ms:7.3f} ms  ({sp[0]:.3f} + {sp[1]:.3f} + {sp[2]:.3f})")
 if out:
     open(out, "w").write("\n".join(lines) + "\n")
