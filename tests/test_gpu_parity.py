@@ -697,6 +697,19 @@ def test_row_split_forms_of_the_keypoint_kernel(lfp, torch, oracle):
             assert np.array_equal(out["4"], out["2" if fits2 else "1"]), n     # a form that does not fit is not forced
         if not fits2:
             assert np.array_equal(out["2"], out["1"]), n
+    # the other angle modes are separate instantiations of the row-split kernel: same agreement with their whole-patch forms
+    for angle in (lfp.ANGLE_EXACT, lfp.ANGLE_EXACT_ZERO):
+        ha = lfp.MkdHandle(max_features=4096, max_image_width=w, max_image_height=hgt, angle_mode=angle)
+        ha.set_image(frames[1])
+        k = random_keypoints(1000, w, hgt, 160 + angle, margin=0.0)
+        k5 = np.ascontiguousarray(np.concatenate([k, np.zeros((len(k), 1), np.float32)], axis=1))
+        got = {}
+        for form in ("1", "2", "4"):
+            with kp_form(form):
+                got[form] = ha.describe_keypoints(k5)
+            assert np.isfinite(got[form]).all()
+        for form in ("2", "4"):
+            assert_same_descriptors(got[form], got["1"], f"angle mode {angle}: form {form} vs the whole-patch form")
     # each row-split form against the oracle, end to end (frame 0; the helper needs the handle to hold one frame)
     one = lfp.MkdHandle(max_features=2048, max_image_width=w, max_image_height=hgt)
     one.set_image(frames[0])
