@@ -490,8 +490,12 @@ def match_stage(args, lfp, torch, dist, sharding, rank, world, local_rank, rehea
                 res["comm_error"] = "another rank could not create its communicator"
         res["allgather_transport"] = "lf_mkd_allgather_descriptors (RCCL, C boundary)" if comm else "torch.distributed"
         if comm:      # the same self-transfer on the N-rank communicator the gather is about to use
-            agree(loopback(comm, min(n, 65536), "rccl_loopback_gather_communicator"),
-                  "RCCL loopback on the gather's communicator: the rows did not arrive")
+            try:
+                ok_gc = loopback(comm, min(n, 65536), "rccl_loopback_gather_communicator")
+            except Exception as e:          # (every rank still reaches agree(): nobody is left alone in a collective)
+                res["rccl_loopback_gather_communicator"] = {"error": f"{type(e).__name__}: {e}"}
+                ok_gc = False
+            agree(ok_gc, "RCCL loopback on the gather's communicator: the rows did not arrive")
         res["gather_form_run"] = {}
         for mode in ("direct", "ring"):
             run = lambda: sharding.all_gather_descriptors(out, mode=mode, out=gathered, counts=counts, comm=comm)
