@@ -166,6 +166,8 @@ extern "C" {
     pub fn lf_mkd_comm_info(c: *const lf_mkd_comm, rccl_version: *mut i32, n_ranks: *mut i32, rank: *mut i32) -> c_int;
     pub fn lf_mkd_allgather_descriptors(h: *mut lf_mkd, c: *mut lf_mkd_comm, counts: *const u64, d_buf: *mut f32,
                                         mode: i32, stream: *mut c_void) -> c_int;
+    pub fn lf_mkd_plan_upload(width: u32, height: u32, bytes_per_pixel: u32, n_scales: u32, cuts: *mut u32, max_cuts: u32,
+                              n_cuts: *mut u32, modelled_us: *mut f64, one_piece_us: *mut f64) -> c_int;
     pub fn lf_mkd_comm_loopback(h: *mut lf_mkd, c: *mut lf_mkd_comm, d_src: *const f32, d_dst: *mut f32, n_rows: u64,
                                 stream: *mut c_void) -> c_int;
     pub fn lf_mkd_comm_last_form(c: *const lf_mkd_comm) -> c_int;

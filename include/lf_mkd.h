@@ -271,6 +271,14 @@ int lf_mkd_detect(lf_mkd *h, const float *image, uint32_t width, uint32_t height
                   float min_size, lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out,
                   uint64_t *n_out, uint64_t *dropped_blobs, uint64_t *dropped_features);
 
+/* Host-only diagnostic (needs no device): where lf_mkd_detect / lf_mkd_detect_u8 would cut a frame of this size for its banded
+ * upload -- the rows after which a piece ends, ascending, *n_cuts of them (0: one piece; at most max_cuts are written to cuts) --
+ * and what the plan's model says: the time (us, from the start of the first copy) at which the pipeline's front has run on the
+ * whole frame with these pieces and with one.  bytes_per_pixel 4 (f32 frame) or 1 (8-bit); n_scales as in lf_mkd_params (0: 4).
+ * Honours LF_MKD_DETECT_BANDS / LF_MKD_BAND_SPLIT / LF_MKD_BAND_PIECES like the call itself.  modelled_us / one_piece_us may be NULL. */
+int lf_mkd_plan_upload(uint32_t width, uint32_t height, uint32_t bytes_per_pixel, uint32_t n_scales, uint32_t *cuts,
+                       uint32_t max_cuts, uint32_t *n_cuts, double *modelled_us, double *one_piece_us);
+
 /* lf_mkd_detect on an 8-bit frame (see lf_mkd_set_image_u8): same results, a quarter of the upload. */
 int lf_mkd_detect_u8(lf_mkd *h, const uint8_t *image, uint32_t width, uint32_t height, uint32_t top_n, float min_size,
                      lf_mkd_keypoint *keypoints, float *descriptors, uint64_t max_out, uint64_t *n_out,

@@ -586,11 +586,12 @@ double front_finish_us(const std::vector<uint32_t> &cuts, size_t n_pieces, int w
 // last byte lands.  The candidate with the earliest modelled finish wins; no cuts (one piece) unless it is ahead by 4 %.
 // LF_MKD_DETECT_BANDS=0: one piece.  LF_MKD_BAND_SPLIT=f1[,f2..]: cuts at these fractions of the height;
 // LF_MKD_BAND_PIECES=k: k equal pieces -- both whatever the frame's size (tests, A/B runs).
-std::vector<uint32_t> plan_cuts(const lf_mkd *h, uint32_t width, uint32_t height, bool u8) {
+std::vector<uint32_t> plan_cuts(int n_layers, uint32_t width, uint32_t height, bool u8) {
     const std::vector<uint32_t> none;
     const int w = int(width), hgt = int(height), bpp = u8 ? 1 : 4;
     RowBands probe;
-    if (h->pd.levels < 2 || height < 64 || !plan_row_bands(int(height) / 2 / 4 * 4, w, hgt, h->n_layers, kBorder, probe)) return none;
+    // (a frame with a pyramid of one level -- fewer than 3 rows or columns -- has nothing to band)
+    if (pyramid_levels(width, height) < 2 || height < 64 || !plan_row_bands(int(height) / 2 / 4 * 4, w, hgt, n_layers, kBorder, probe)) return none;
     // cuts on multiples of four rows, at least 16 rows from either end, strictly increasing
     auto valid = [&](std::vector<uint32_t> &c) {
         for (auto &r : c) r = std::min<uint32_t>(std::max<uint32_t>(r, 16), height - 16) / 4 * 4;
@@ -625,10 +626,10 @@ std::vector<uint32_t> plan_cuts(const lf_mkd *h, uint32_t width, uint32_t height
     const FrontModel m;
     const double row_us = double(w) * bpp / (m.link_gb_s * 1e3);
     std::vector<uint32_t> best;
-    double best_t = front_finish_us(none, 1, w, hgt, bpp, h->n_layers, m) * 0.96;
+    double best_t = front_finish_us(none, 1, w, hgt, bpp, n_layers, m) * 0.96;
     auto consider = [&](std::vector<uint32_t> c) {
         if (!valid(c)) return;
-        const double t = front_finish_us(c, c.size() + 1, w, hgt, bpp, h->n_layers, m);
+        const double t = front_finish_us(c, c.size() + 1, w, hgt, bpp, n_layers, m);
         if (t < best_t) {
             best_t = t;
             best = c;
@@ -641,7 +642,7 @@ std::vector<uint32_t> plan_cuts(const lf_mkd *h, uint32_t width, uint32_t height
             consider(c);
             // the next piece: as many rows as the link delivers while the device works off the pieces so far
             double t_link = 0;
-            const double t_dev = front_finish_us(c, c.size(), w, hgt, bpp, h->n_layers, m, &t_link);
+            const double t_dev = front_finish_us(c, c.size(), w, hgt, bpp, n_layers, m, &t_link);
             const uint32_t rows = uint32_t(std::max((t_dev - t_link - m.gap_us) / row_us, double(height) / 16));
             if (c.back() + rows + height / 16 >= height) break;
             c.push_back(c.back() + rows);
@@ -687,6 +688,21 @@ int lf_mkd_build_constants(const float *mean, const float *eigvals, const float 
     if (embedding_cartesian)
         std::memcpy(embedding_cartesian, hc.embedding_cartesian.data(), hc.embedding_cartesian.size() * 4);
     if (w_t) std::memcpy(w_t, hc.w_t.data(), hc.w_t.size() * 4);
+    return LF_MKD_OK;
+}
+
+int lf_mkd_plan_upload(uint32_t width, uint32_t height, uint32_t bytes_per_pixel, uint32_t n_scales, uint32_t *cuts,
+                       uint32_t max_cuts, uint32_t *n_cuts, double *modelled_us, double *one_piece_us) {
+    if (!n_cuts || (bytes_per_pixel != 1 && bytes_per_pixel != 4) || width < 2 || height < 2 || (max_cuts && !cuts))
+        return LF_MKD_ERR_BAD_ARG;
+    const int n_layers = int(n_scales ? n_scales : 4) + 3;
+    if (n_layers - 1 > 8) return LF_MKD_ERR_BAD_ARG;
+    const std::vector<uint32_t> c = plan_cuts(n_layers, width, height, bytes_per_pixel == 1);
+    *n_cuts = uint32_t(c.size());
+    for (size_t i = 0; i < c.size() && i < max_cuts; ++i) cuts[i] = c[i];
+    const FrontModel m;
+    if (modelled_us) *modelled_us = front_finish_us(c, c.size() + 1, int(width), int(height), int(bytes_per_pixel), n_layers, m);
+    if (one_piece_us) *one_piece_us = front_finish_us({}, 1, int(width), int(height), int(bytes_per_pixel), n_layers, m);
     return LF_MKD_OK;
 }
 
@@ -1345,7 +1361,7 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
         p.pd = h->pd;
         // Large frames go over PCIe in pieces, and the pipeline's front runs on the rows a piece completes while the next one
         // is on its way (RowBands; plan_cuts chooses the pieces).
-        p.cuts = plan_cuts(h, width, height, u8);
+        p.cuts = h->pd.levels >= 2 ? plan_cuts(h->n_layers, width, height, u8) : std::vector<uint32_t>();
         if (getenv("LF_MKD_BAND_DEBUG")) {
             std::string line = "lf_mkd: detect " + std::to_string(width) + "x" + std::to_string(height) + (u8 ? " u8" : " f32") +
                                ", " + std::to_string(h->n_layers) + " layers: cuts";

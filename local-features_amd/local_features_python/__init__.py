@@ -15,11 +15,11 @@ import numpy as np
 
 from ._lib import (ANGLE_EXACT, ANGLE_EXACT_ZERO, ANGLE_SHADER, FLAG_DETECT_STEPWISE, FLAG_KERNEL_TIMING, FLAG_UNFUSED_KEYPOINTS, KEYPOINT_DTYPE, LIB_PATH, MODEL_DIR, PCA_NAMES,
                    POOL_DEFAULT, POOL_F16X3, POOL_F32, POOL_F16_FP6, SYMBOLS, COMM_ID_BYTES, GATHER_DIRECT, GATHER_RING, Comm, MkdHandle,
-                   comm_unique_id, load_library, model_path)
+                   comm_unique_id, load_library, model_path, plan_upload)
 
 __all__ = ["Keypoint", "LocalFeatures", "MkdHandle", "ANGLE_SHADER", "ANGLE_EXACT", "ANGLE_EXACT_ZERO", "POOL_DEFAULT", "POOL_F32", "POOL_F16_FP6",
            "POOL_F16X3", "FLAG_KERNEL_TIMING", "FLAG_UNFUSED_KEYPOINTS", "FLAG_DETECT_STEPWISE", "KEYPOINT_DTYPE", "PCA_NAMES", "SYMBOLS", "LIB_PATH", "MODEL_DIR",
-           "load_library", "model_path", "Comm", "comm_unique_id", "COMM_ID_BYTES", "GATHER_DIRECT", "GATHER_RING"]
+           "load_library", "model_path", "plan_upload", "Comm", "comm_unique_id", "COMM_ID_BYTES", "GATHER_DIRECT", "GATHER_RING"]
 
 
 class Keypoint:

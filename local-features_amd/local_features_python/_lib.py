@@ -32,7 +32,7 @@ SYMBOLS = (
     "lf_mkd_match", "lf_mkd_match_device", "lf_mkd_match_both_device", "lf_mkd_match_overflowed", "lf_mkd_stream_create", "lf_mkd_stream_frame",
     "lf_mkd_detect_frames_device", "lf_mkd_orient_keypoints_blocked",
     "lf_mkd_comm_unique_id", "lf_mkd_comm_create", "lf_mkd_comm_destroy", "lf_mkd_comm_info", "lf_mkd_allgather_descriptors",
-    "lf_mkd_comm_loopback", "lf_mkd_comm_last_form",
+    "lf_mkd_comm_loopback", "lf_mkd_comm_last_form", "lf_mkd_plan_upload",
 )
 COMM_ID_BYTES = 128
 GATHER_DIRECT, GATHER_RING = 0, 1
@@ -129,10 +129,24 @@ def load_library():
     L.lf_mkd_allgather_descriptors.argtypes = [vp, vp, vp, vp, i32, vp]
     L.lf_mkd_comm_loopback.argtypes = [vp, vp, vp, vp, u64, vp]
     L.lf_mkd_comm_last_form.argtypes = [vp]
+    L.lf_mkd_plan_upload.argtypes = [u32, u32, u32, u32, vp, u32, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_double),
+                                     ctypes.POINTER(ctypes.c_double)]
     L.lf_mkd_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(u64)]
     _lib = L
     return L
+
+
+def plan_upload(width, height, bytes_per_pixel=4, n_scales=4):
+    """(cuts, modelled_us, one_piece_us): the pieces lf_mkd_detect[_u8] would upload a frame of this size in (lf_mkd_plan_upload;
+    needs no device)."""
+    cuts = (ctypes.c_uint32 * 16)()
+    n, a, b = ctypes.c_uint32(), ctypes.c_double(), ctypes.c_double()
+    rc = load_library().lf_mkd_plan_upload(width, height, bytes_per_pixel, n_scales, cuts, 16, ctypes.byref(n), ctypes.byref(a),
+                                           ctypes.byref(b))
+    if rc != 0:
+        raise RuntimeError(f"lf_mkd_plan_upload failed ({rc})")
+    return [int(cuts[i]) for i in range(min(n.value, 16))], a.value, b.value
 
 
 def comm_unique_id():
