@@ -183,6 +183,7 @@ extern "C" {
                                   embedding_cartesian: *mut f32, w_t: *mut f32) -> c_int;
     pub fn lf_mkd_kernel_times(h: *mut lf_mkd, pool_ms: *mut f64, whiten_ms: *mut f64, launches: *mut u64) -> c_int;
     pub fn lf_mkd_kernel_clock(h: *mut lf_mkd, stream: *mut c_void, shader_mhz: *mut f64, kernel_ms: *mut f64) -> c_int;
+    pub fn lf_mkd_detect_recordings(h: *const lf_mkd, n_recordings: *mut u32, n_banded: *mut u32, n_sightings: *mut u32) -> c_int;
     pub fn lf_mkd_synchronize(h: *mut lf_mkd) -> c_int;
     pub fn lf_mkd_version() -> *const c_char;
 }

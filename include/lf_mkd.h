@@ -456,6 +456,11 @@ int lf_mkd_detect_times(lf_mkd *h, double *upload_ms, double *pipeline_ms, doubl
  * comparable.  Waits for `stream` (NULL: the handle's own).  Either output pointer may be NULL. */
 int lf_mkd_kernel_clock(lf_mkd *h, void *stream, double *shader_mhz, double *kernel_ms);
 
+/* Diagnostic of lf_mkd_detect / lf_mkd_detect_u8 (host state only, no device work): how many recorded pipelines the handle holds
+ * at the moment (at most 8), how many of them upload their frame in pieces, and how many distinct requests it remembers having
+ * seen (at most 64; a request is recorded on its second sighting).  Any output pointer may be NULL. */
+int lf_mkd_detect_recordings(const lf_mkd *h, uint32_t *n_recordings, uint32_t *n_banded, uint32_t *n_sightings);
+
 /* Blocks until everything enqueued on the handle's own stream has finished. */
 int lf_mkd_synchronize(lf_mkd *h);
 

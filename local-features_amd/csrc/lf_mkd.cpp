@@ -1474,6 +1474,16 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
     return LF_MKD_OK;
 }
 
+int lf_mkd_detect_recordings(const lf_mkd *h, uint32_t *n_recordings, uint32_t *n_banded, uint32_t *n_sightings) {
+    if (!h) return LF_MKD_ERR_BAD_ARG;
+    uint32_t banded = 0;
+    for (const auto &p : h->plans) banded += p.cuts.empty() ? 0u : 1u;
+    if (n_recordings) *n_recordings = uint32_t(h->plans.size());
+    if (n_banded) *n_banded = banded;
+    if (n_sightings) *n_sightings = uint32_t(h->sightings.size());
+    return LF_MKD_OK;
+}
+
 int lf_mkd_detect_times(lf_mkd *h, double *upload_ms, double *pipeline_ms, double *readback_ms) {
     if (!h) return LF_MKD_ERR_BAD_ARG;
     if (!(h->params.flags & LF_MKD_FLAG_KERNEL_TIMING))

@@ -32,7 +32,7 @@ SYMBOLS = (
     "lf_mkd_match", "lf_mkd_match_device", "lf_mkd_match_both_device", "lf_mkd_match_overflowed", "lf_mkd_stream_create", "lf_mkd_stream_frame",
     "lf_mkd_detect_frames_device", "lf_mkd_orient_keypoints_blocked",
     "lf_mkd_comm_unique_id", "lf_mkd_comm_create", "lf_mkd_comm_destroy", "lf_mkd_comm_info", "lf_mkd_allgather_descriptors",
-    "lf_mkd_comm_loopback", "lf_mkd_comm_last_form", "lf_mkd_plan_upload",
+    "lf_mkd_comm_loopback", "lf_mkd_comm_last_form", "lf_mkd_plan_upload", "lf_mkd_detect_recordings",
 )
 COMM_ID_BYTES = 128
 GATHER_DIRECT, GATHER_RING = 0, 1
@@ -129,6 +129,7 @@ def load_library():
     L.lf_mkd_allgather_descriptors.argtypes = [vp, vp, vp, vp, i32, vp]
     L.lf_mkd_comm_loopback.argtypes = [vp, vp, vp, vp, u64, vp]
     L.lf_mkd_comm_last_form.argtypes = [vp]
+    L.lf_mkd_detect_recordings.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.lf_mkd_plan_upload.argtypes = [u32, u32, u32, u32, vp, u32, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_double)]
     L.lf_mkd_kernel_times.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
@@ -303,6 +304,13 @@ class MkdHandle:
         self._check(fn(self._h, a.ctypes.data, a.shape[1], a.shape[0], top_n, min_size, kps.ctypes.data, desc.ctypes.data, cap,
                        ctypes.byref(m), ctypes.byref(db), ctypes.byref(df)), what)
         return m.value, db.value, df.value
+
+    def detect_recordings(self):
+        """(recorded pipelines held, of them with a banded upload, distinct requests remembered) -- lf_mkd_detect_recordings"""
+        a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self.L.lf_mkd_detect_recordings(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)),
+                    "lf_mkd_detect_recordings")
+        return a.value, b.value, c.value
 
     def detect_times(self):
         """(upload_ms, pipeline_ms, readback_ms) of the latest detect call; needs FLAG_KERNEL_TIMING."""

@@ -579,3 +579,63 @@ def test_handle_lifecycle_does_not_leak(lfp, torch, monkeypatch):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, (free0, free1)
+
+
+def test_a_request_is_recorded_on_its_second_sighting(lfp, monkeypatch):
+    """Round 6 (the advisor's round-5 finding): recording a pipeline costs a capture and an instantiation, several times the call
+    -- so the first sighting of a request is served stage by stage, the second records, later ones replay; at most 8 recordings
+    are kept (the least recently used one makes room); a call that moves a buffer the recordings name retires them, and a request
+    seen before is then recorded again at once.  LF_MKD_DETECT_RECORD_AFTER (read at creation) moves the threshold; handles in a
+    two-launch keypoint mode never record.  lf_mkd_detect_recordings is the window."""
+    w, hgt = 320, 240
+    u8, f32 = _u8_frame(w, hgt, 9, 200)
+    kw = dict(max_features=512, max_image_width=w, max_image_height=hgt, max_blobs=512)
+    h = lfp.MkdHandle(**kw)
+    assert h.detect_recordings() == (0, 0, 0)
+    first = h.detect(u8, 100, 0.0, 512)
+    assert h.detect_recordings() == (0, 0, 1)                # seen, served stage by stage
+    again = h.detect(u8, 100, 0.0, 512)
+    assert h.detect_recordings() == (1, 0, 1)                # recorded
+    for _ in range(3):
+        rep = h.detect(u8, 100, 0.0, 512)
+        assert np.array_equal(rep[1], first[1]) and np.array_equal(again[1], first[1])
+    assert h.detect_recordings() == (1, 0, 1)                # replayed
+    h.detect(f32, 100, 0.0, 512)                             # another pixel type is another request
+    assert h.detect_recordings() == (1, 0, 2)
+    for t in range(10):                                      # ten more requests, twice each: only 8 recordings stay
+        for _ in range(2):
+            h.detect(u8, 20 + t, 0.0, 512)
+    assert h.detect_recordings() == (8, 0, 12)
+    ex, _ = h.detect_extrema(max_out=1 << 14)                # grows the detector's extremum list: the recordings name it
+    assert h.detect_recordings()[0] == 0
+    h.detect(u8, 100, 0.0, 512)                              # seen before: recorded at once, not stage by stage again
+    assert h.detect_recordings()[0] == 1
+    # counts only (max_out == 0) and a capacity beyond 18 keypoints per extremum
+    h.detect(u8, 100, 0.0, 0)
+    n_before = h.detect_recordings()[2]
+    a = h.detect(u8, 5, 0.0, 512)                            # capacity 512 > 5 x 18: treated as 90 -- the same request as ...
+    b = h.detect(u8, 5, 0.0, 90)                             # ... this one: recorded on this, its second sighting
+    assert np.array_equal(a[1], b[1]) and h.detect_recordings()[2] == n_before + 1 and h.detect_recordings()[0] == 2
+    # the threshold
+    monkeypatch.setenv("LF_MKD_DETECT_RECORD_AFTER", "0")
+    h0 = lfp.MkdHandle(**kw)
+    r0 = h0.detect(u8, 100, 0.0, 512)
+    assert h0.detect_recordings()[0] == 1 and np.array_equal(r0[1], first[1])
+    monkeypatch.setenv("LF_MKD_DETECT_RECORD_AFTER", "3")
+    h3 = lfp.MkdHandle(**kw)
+    for i in range(4):
+        assert h3.detect_recordings()[0] == 0
+        h3.detect(u8, 100, 0.0, 512)
+    assert h3.detect_recordings()[0] == 1
+    monkeypatch.delenv("LF_MKD_DETECT_RECORD_AFTER")
+    # a handle whose keypoint mode is the two-launch form stays stage by stage
+    hv = lfp.MkdHandle(pool_mode=lfp.POOL_F32, **kw)
+    for _ in range(3):
+        rv = hv.detect(u8, 100, 0.0, 512)
+    assert hv.detect_recordings() == (0, 0, 0) and len(rv[0]) == len(first[0])
+    # large frames: the recording uploads in pieces
+    monkeypatch.setenv("LF_MKD_BAND_PIECES", "3")
+    hb = lfp.MkdHandle(**kw)
+    for _ in range(2):
+        rb = hb.detect(u8, 100, 0.0, 512)
+    assert hb.detect_recordings() == (1, 1, 1) and np.array_equal(rb[1], first[1])
