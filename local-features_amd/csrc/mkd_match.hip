@@ -598,10 +598,12 @@ __global__ __launch_bounds__(512, 4) void match_screen(const unsigned char *__re
             if (v > -INFINITY && v >= fmaxf(from, second - margin)) {
                 // a ring: beyond the capacity the oldest record goes, and the largest value that went is kept --
                 // verify needs only to know that nothing it would have re-scored was lost
+#ifndef LF_SCREEN_ABLATE_STORE   // (timing-only build: the candidate path without its record stores)
                 uint2 *slot = rec + sidx * kRecCap + (cnt & (kRecCap - 1));
                 if (cnt >= kRecCap) rec_info[sidx].y = __float_as_uint(fmaxf(__uint_as_float(rec_info[sidx].y),
                                                                              __uint_as_float(slot->x)));
                 *slot = make_uint2(__float_as_uint(v), (unsigned)(row0 + e));
+#endif
                 ++cnt;
             }
             const bool nb_ = v >= best && v > -INFINITY;
