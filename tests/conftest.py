@@ -104,7 +104,8 @@ def pytest_terminal_summary(terminalreporter):
 # Requests of at most 4096 keypoints take the row-split form (round 6: 2 or 4 workgroups per batch of 32 keypoints, each
 # pooling its share of the 32 patch rows, the partial sums added in a fixed order), larger ones the whole-patch form (one
 # chain of 32 row sums).  Within a form a descriptor's bits depend on its keypoint and frame alone; between forms the sums
-# round differently: ~3e-6 relative L2 after whitening (measured worst 4.3e-6 over tools/check_split.py's sizes).
+# round differently: ~3e-6 relative L2 after whitening (measured worst 4.3e-6 over tools/check_split.py's sizes, 6.5e-6 over
+# tools/soak_split.py's 32 000 launches).
 # LF_MKD_KP_SPLIT=1 / 2 / 4 in the environment (read per launch) forces a form where it fits.
 CROSS_FORM = 1e-5
 
