@@ -1242,10 +1242,12 @@ static int record_pipeline(lf_mkd *h, uint32_t width, uint32_t height, uint32_t 
     return LF_MKD_OK;
 }
 
-// LocalFeaturesVulkan::detect / detect_top_n (mod.rs:346-593) from a HOST frame, f32 or 8-bit: one upload, one launch of the
-// pipeline recorded for this (frame size, top_n, min_size, max_out, pixel type) -- recorded on the first such call, kept
-// for the later ones -- one wait, the result copies.  The reference's callers make this call per image
-// (examples/match_images/src/main.rs:44-76) or per camera frame (examples/webcam/src/main.rs:136-160).
+// LocalFeaturesVulkan::detect / detect_top_n (mod.rs:346-593) from a HOST frame, f32 or 8-bit.  A request -- (frame size, top_n,
+// min_size, max_out, pixel type) -- seen for the first time is served stage by stage; the second time its pipeline is recorded
+// (lf_mkd::Sighting), and from then on a call is one upload (in planned pieces when the frame is large: plan_cuts), one launch
+// of the recording, one wait, the result copies.  The reference's callers make this call per image
+// (examples/match_images/src/main.rs:44-76: once per image, at its own size -- never a recording) or per camera frame
+// (examples/webcam/src/main.rs:136-160).
 constexpr size_t kMaxPlans = 8;
 
 static int detect_host(lf_mkd *h, const float *image, const unsigned char *image_u8, uint32_t width, uint32_t height,

@@ -5,7 +5,7 @@
 `image` crate's) -- groups scale_scales={3,5} (3000 features at the four scales) and feats_scales={3,5} (100 .. 2000
 features at full size), max_blobs = 5 x max_features (bench.rs:57-64).  Host image in, host results out, as
 `lf.detect_top_n(&image.view(), n, 0.)` does, in three forms:
-   f32       lf_mkd_detect        the caller's f32 frame (4 B/px over PCIe), one recorded hipGraph per request shape
+   f32       lf_mkd_detect        the caller's f32 frame (4 B/px over PCIe), one recorded hipGraph per request shape (from its second sighting on)
    u8        lf_mkd_detect_u8     the 8-bit frame the f32 one was made from (1 B/px), same results bit for bit
    stepwise  lf_mkd_detect with LF_MKD_FLAG_DETECT_STEPWISE: the call as it was before round 5 (three host waits)
 Median of 20 calls after 3 warm-up calls, into arrays the caller keeps (MkdHandle.detect_into: the C call alone); the split

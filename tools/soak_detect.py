@@ -38,7 +38,7 @@ for r in range(rounds):
         w, h = int(rng.integers(40, 700)), int(rng.integers(40, 500))
     elif kind == 1:    # aligned, mid-sized
         w, h = 4 * int(rng.integers(100, 500)), 2 * int(rng.integers(100, 600))
-    elif kind == 2:    # large: the banded upload at its default cut (>= 12 MB as f32 from 3 MP, as u8 from 12 MP)
+    elif kind == 2:    # large: the banded upload as planned (>= 6 MB: as f32 from 1.5 MP, as u8 from 6 MP)
         w, h = 4 * int(rng.integers(500, 1050)), 2 * int(rng.integers(500, 1600))
     else:              # slim or flat shapes
         w, h = (4 * int(rng.integers(10, 60)), int(rng.integers(1500, 3000))) if rng.random() < 0.5 else (
