@@ -85,9 +85,9 @@ typedef enum { LF_MKD_POOL_DEFAULT = 0, LF_MKD_POOL_F16X3 = 1, LF_MKD_POOL_F32 =
                                         (LF_MKD_POOL_F32 always takes the two-launch form.) */
 
 #define LF_MKD_FLAG_DETECT_STEPWISE 4u /* lf_mkd_detect / lf_mkd_detect_u8 stage by stage, every count fetched by the host before the
-                                        next stage is sized (three waits): the verification form.  By default the call launches
-                                        the whole pipeline as ONE hipGraph, recorded the second time a (frame size, top_n,
-                                        min_size, max_out, pixel type) is asked for and kept; same bits. */
+                                        next stage is sized (three waits): the verification form.  By default every count stays
+                                        on the device, and the whole pipeline is ONE hipGraph launch, recorded the second time a
+                                        (frame size, top_n, min_size, max_out, pixel type) is asked for and kept; same bits. */
 
 /* Mirrors BuildTimeParams (lib.rs:54-75) + FeatureDetectParams (lib.rs:34-52) for this path.
  * Zero-initialise, then set what you need; 0 means "default". */
@@ -255,8 +255,8 @@ int lf_mkd_filter_extrema_device(lf_mkd *h, const lf_mkd_extremum *d_extrema, ui
  * that bound: it sizes no buffer and no copy.  The whole pipeline is one hipGraph launch, recorded the SECOND time these
  * arguments' frame size, top_n, min_size, max_out and pixel type are seen (up to 8 such recordings are kept per handle, the
  * least recently used one makes room): a replayed call costs the upload of the frame, the pipeline and the copy of *n_out
- * results, with one wait in between.  The first sighting of a request is served stage by stage (the form
- * LF_MKD_FLAG_DETECT_STEPWISE keeps: three waits, same bits) -- the reference's match_images detects each image once, at its
+ * results, with one wait in between.  The first sighting of a request is served by the same launches without recording them
+ * (one upload, the pipeline's ~20 launches, one wait; same bits) -- the reference's match_images detects each image once, at its
  * own size, and never pays a recording; a camera loop pays it on its second frame (LF_MKD_DETECT_RECORD_AFTER=k in the
  * environment at lf_mkd_create: k sightings before recording, 0 = record at once; cost of the three kinds of call:
  * INTEGRATION.md section 2).  Handles whose keypoint mode takes the two-launch form (LF_MKD_POOL_F32, LF_MKD_POOL_F16_FP6,

@@ -85,8 +85,8 @@ struct lf_mkd {
     };
     std::vector<DetectPlan> plans;
     uint64_t plan_clock = 0;
-    // Requests seen but not recorded yet.  Recording costs a capture and an instantiation (two when the upload is banded) --
-    // several times the call itself -- so a request is served stage by stage until it has been seen record_after times
+    // Requests seen but not recorded yet.  Recording costs a capture and an instantiation (more when the upload is banded) --
+    // several times the call itself -- so a request is served by the pipeline's plain launches until it has been seen record_after times
     // (default 1: the reference's match_images detects each image once, at its own size, and never pays a recording; a
     // camera loop records on its second frame and replays from the third).  LF_MKD_DETECT_RECORD_AFTER in the environment,
     // read at creation: 0 records on the first sighting.
@@ -1153,24 +1153,22 @@ static int prepare_pipeline(lf_mkd *h, uint32_t top_n, uint64_t cap) {
     return ensure_orient_scratch(h, cap, false, 0);
 }
 
-// Records the launch sequence of lf_mkd_detect for frames of width x height read from d_image (f32) or d_image_u8 -- pyramid,
+// The launch sequence of lf_mkd_detect for frames of width x height read from d_image (f32) or d_image_u8 -- pyramid,
 // a-trous stack, extremum scan, [top_n filter if top_n > 0], orientation, sampling + description -- with every count handed
 // from stage to stage in device memory (cnt [8]: see lf_mkd_stream_create in lf_mkd.h).  host_counts (nullable, pinned): a
-// last node copies cnt there.  h->pd must describe the frame; every buffer must exist (prepare_pipeline).
-static int record_pipeline(lf_mkd *h, uint32_t width, uint32_t height, uint32_t top_n, float min_size, uint64_t max_out,
-                           const float *d_image, const unsigned char *d_image_u8, lf_mkd_keypoint *d_keypoints,
-                           float *d_descriptors, unsigned long long *cnt, unsigned long long *host_counts,
-                           lf_mkd_keypoint *host_keypoints, hipGraph_t *graph_out, hipGraphExec_t *exec_out,
-                           const RowBands *bands = nullptr) {
+// last operation copies cnt there.  h->pd must describe the frame; every buffer must exist (prepare_pipeline), and the side
+// stream when the frame has levels to build beside the detector.  Enqueued on the handle's stream: inside a capture
+// (record_pipeline) or as it is (the first sighting of a request: the same launches, no recording, one wait).
+static void enqueue_pipeline(lf_mkd *h, uint32_t width, uint32_t height, uint32_t top_n, float min_size, uint64_t max_out,
+                             const float *d_image, const unsigned char *d_image_u8, lf_mkd_keypoint *d_keypoints,
+                             float *d_descriptors, unsigned long long *cnt, unsigned long long *host_counts,
+                             lf_mkd_keypoint *host_keypoints, const RowBands *bands) {
     hipStream_t s = h->stream;
     const uint64_t cap = top_n ? top_n : h->max_extrema;   // extrema that can reach orientation
     // the detector needs pyramid level 0 and a-trous layer 1 only: the other levels (read by the sampler at the very end)
-    // are a branch of the graph beside the a-trous stack, the scan, the selection and the orientation
+    // are a branch beside the a-trous stack, the scan, the selection and the orientation
     const bool head_only = bands && !bands->last;           // (a piece's share: the front's kernels on its rows, nothing else)
     const bool fork = h->pd.levels >= 2 && !head_only;
-    if (fork)
-        if (int rc = ensure_side_stream(h, 2)) return rc;
-    LF_HIP(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     // (the a-trous stack is queued from inside, ahead of the branch: see launch_build_pyramid)
     launch_build_pyramid(d_image, long(width) * height, h->d_pyr, h->pyr_stride, h->d_tmp_a, h->d_tmp_b, h->pd, 1,
                          h->pd.levels >= 2 ? h->d_coarse : nullptr, h->coarse_stride, s, fork ? h->side_stream : nullptr,
@@ -1182,22 +1180,7 @@ static int record_pipeline(lf_mkd *h, uint32_t width, uint32_t height, uint32_t 
     launch_detect_extrema(h->d_pyr + h->pd.offset[0], h->pyr_stride, h->pd.pitch[0], h->d_coarse, h->coarse_stride, h->layer_stride,
                           h->n_layers, int(width), int(height), 1, kBorder, kSkipLayers, kContrastThreshold, h->d_slots,
                           h->d_cube_counts, h->d_cube_sums, h->d_det_extrema, nullptr, nullptr, h->max_extrema, cnt + 0, s, bands);
-    if (head_only) {
-        hipGraph_t g0 = nullptr;
-        hipError_t e0 = hipStreamEndCapture(s, &g0);
-        if (e0 != hipSuccess || !g0) {
-            h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e0);
-            return LF_MKD_ERR_HIP;
-        }
-        hipError_t e1 = hipGraphInstantiate(exec_out, g0, nullptr, nullptr, 0);
-        if (e1 != hipSuccess) {
-            (void)hipGraphDestroy(g0);
-            h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e1);
-            return LF_MKD_ERR_HIP;
-        }
-        *graph_out = g0;
-        return LF_MKD_OK;
-    }
+    if (head_only) return;
     const float *d_sel = h->d_det_extrema;
     const unsigned long long *n_sel = cnt + 0;
     if (top_n) {
@@ -1221,11 +1204,25 @@ static int record_pipeline(lf_mkd *h, uint32_t width, uint32_t height, uint32_t 
         launch_describe(h->d_stream_patches, long(max_out), cnt + 3, h->dc, h->params.angle_mode, h->params.pool_mode,
                         d_descriptors, nullptr, h->num_cus, s);
     }
-    // the counts and the keypoints go to pinned host memory as the last nodes (on a branch of their own beside the describe
+    // the counts and the keypoints go to pinned host memory as the last operations (on a branch of their own beside the describe
     // launch they were measured 15 us slower: every join of two branches costs ~12 us of queue latency)
     if (host_counts) (void)hipMemcpyAsync(host_counts, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
     if (host_keypoints)
         (void)hipMemcpyAsync(host_keypoints, d_keypoints, max_out * sizeof(lf_mkd_keypoint), hipMemcpyDeviceToHost, s);
+}
+
+// Records that sequence as a hipGraph (the whole pipeline, or one piece's share of its front: bands).
+static int record_pipeline(lf_mkd *h, uint32_t width, uint32_t height, uint32_t top_n, float min_size, uint64_t max_out,
+                           const float *d_image, const unsigned char *d_image_u8, lf_mkd_keypoint *d_keypoints,
+                           float *d_descriptors, unsigned long long *cnt, unsigned long long *host_counts,
+                           lf_mkd_keypoint *host_keypoints, hipGraph_t *graph_out, hipGraphExec_t *exec_out,
+                           const RowBands *bands = nullptr) {
+    hipStream_t s = h->stream;
+    if (h->pd.levels >= 2 && !(bands && !bands->last))
+        if (int rc = ensure_side_stream(h, 2)) return rc;
+    LF_HIP(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    enqueue_pipeline(h, width, height, top_n, min_size, max_out, d_image, d_image_u8, d_keypoints, d_descriptors, cnt, host_counts,
+                     host_keypoints, bands);
     hipGraph_t graph = nullptr;
     hipError_t e_end = hipStreamEndCapture(s, &graph);
     if (e_end != hipSuccess || !graph) {
@@ -1243,9 +1240,10 @@ static int record_pipeline(lf_mkd *h, uint32_t width, uint32_t height, uint32_t 
 }
 
 // LocalFeaturesVulkan::detect / detect_top_n (mod.rs:346-593) from a HOST frame, f32 or 8-bit.  A request -- (frame size, top_n,
-// min_size, max_out, pixel type) -- seen for the first time is served stage by stage; the second time its pipeline is recorded
-// (lf_mkd::Sighting), and from then on a call is one upload (in planned pieces when the frame is large: plan_cuts), one launch
-// of the recording, one wait, the result copies.  The reference's callers make this call per image
+// min_size, max_out, pixel type) -- seen for the first time is served by the pipeline's own launches, not recorded (one
+// upload, ~20 launches, one wait: no capture and no instantiation, which cost several times the call); the second time the
+// pipeline is recorded (lf_mkd::Sighting), and from then on a call is one upload (in planned pieces when the frame is large:
+// plan_cuts), one launch of the recording, one wait, the result copies.  The reference's callers make this call per image
 // (examples/match_images/src/main.rs:44-76: once per image, at its own size -- never a recording) or per camera frame
 // (examples/webcam/src/main.rs:136-160).
 constexpr size_t kMaxPlans = 8;
@@ -1278,6 +1276,9 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
     // mode takes the two-launch form (POOL_F32, F16_FP6, FLAG_UNFUSED_KEYPOINTS: verification forms whose staging patches
     // are sized by the internal batch there, by max_out x 4 KiB in a recording) ...
     bool stepwise = (h->params.flags & LF_MKD_FLAG_DETECT_STEPWISE) || max_out == 0 || !fused_keypoints(h);
+    // ... or, a request not yet due for recording, as the recording's own launches without recording them (`direct`: every
+    // count handed on in device memory, one wait -- no capture, no instantiation, and none of the three waits either)
+    bool direct = false;
     lf_mkd::DetectPlan *plan = nullptr;
     if (!stepwise) {
         for (auto &p : h->plans)
@@ -1302,7 +1303,7 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
             seen->stamp = ++h->plan_clock;
             if (seen->count < h->record_after) {
                 ++seen->count;
-                stepwise = true;
+                direct = true;
             }
         }
     }
@@ -1344,12 +1345,23 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
                                dropped_features);
     }
     describe_pyramid(width, height, h->pd);
+    if (direct) {
+        // the first sighting(s) of a request: upload in one piece, the pipeline's launches as they are, then the common tail
+        if (h->pd.levels >= 2)
+            if (int rc = ensure_side_stream(h, 2)) return rc;
+        if (int rc = upload_whole()) return rc;
+        if (timed) LF_HIP(h, hipEventRecord(h->det_ev[1], s));
+        enqueue_pipeline(h, width, height, top_n, min_size, max_out, u8 ? nullptr : h->d_image, u8 ? h->d_image_u8 : nullptr,
+                         reinterpret_cast<lf_mkd_keypoint *>(h->d_kps_out), h->d_det_desc, h->d_det_counts, h->h_det_counts,
+                         h->h_res_kps, nullptr);
+        LF_HIP(h, hipGetLastError());
+    }
     // (the buffers above may have moved and retired every recording, `plan` among them: look again)
     plan = nullptr;
     for (auto &p : h->plans)
-        if (p.w == width && p.h == height && p.top_n == top_n && p.min_size_bits == ms_bits && p.max_out == max_out && p.u8 == u8)
+        if (!direct && p.w == width && p.h == height && p.top_n == top_n && p.min_size_bits == ms_bits && p.max_out == max_out && p.u8 == u8)
             plan = &p;
-    if (!plan) {
+    if (!plan && !direct) {
         if (h->plans.size() >= kMaxPlans) {      // the least recently used recording makes room
             size_t old = 0;
             for (size_t i = 1; i < h->plans.size(); ++i)
@@ -1412,8 +1424,10 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
         h->plans.push_back(p);
         plan = &h->plans.back();
     }
-    plan->stamp = ++h->plan_clock;
-    if (plan->cuts.empty()) {
+    if (plan) plan->stamp = ++h->plan_clock;
+    if (direct) {
+        // (already enqueued above)
+    } else if (plan->cuts.empty()) {
         if (int rc = upload_whole()) return rc;
         if (timed) LF_HIP(h, hipEventRecord(h->det_ev[1], s));
     } else {
@@ -1449,7 +1463,7 @@ static int detect_host(lf_mkd *h, const float *image, const unsigned char *image
         }
         if (timed) LF_HIP(h, hipEventRecord(h->det_ev[1], s));     // (on s behind the last wait: the moment the whole frame is there)
     }
-    LF_HIP(h, hipGraphLaunch(plan->exec, s));
+    if (!direct) LF_HIP(h, hipGraphLaunch(plan->exec, s));
     if (timed) LF_HIP(h, hipEventRecord(h->det_ev[2], s));
     h->n_frames = 1;
     h->have_image = h->coarse_valid = h->coarse_l1_valid = true;   // the handle holds this frame's pyramid and a-trous stack

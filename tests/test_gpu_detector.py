@@ -220,7 +220,7 @@ def test_detect_recorded_stepwise_and_u8_return_the_same_bits(lfp, torch, oracle
     """Round 5: lf_mkd_detect is one upload + ONE hipGraph launch recorded per (frame size, top_n, min_size, max_out, pixel
     type), and lf_mkd_detect_u8 takes the 8-bit frame (1 B/px over PCIe, (float)v / 255.0f on the device).  All of them must
     return the bits of the stage-by-stage form the call had before (LF_MKD_FLAG_DETECT_STEPWISE keeps it): keypoints,
-    descriptors and both dropped counters, on the first call (served stage by stage since round 6), the second (recording)
+    descriptors and both dropped counters, on the first call (the pipeline's launches unrecorded, since round 6), the second (recording)
     and on later ones (replay), for aligned frames (the
     staged level-0 kernel) and odd ones (the unaligned kernel), with and without the top-n filter, with an output capacity
     that cuts the list, and with more distinct requests than the handle keeps recordings for."""
@@ -583,7 +583,7 @@ def test_handle_lifecycle_does_not_leak(lfp, torch, monkeypatch):
 
 def test_a_request_is_recorded_on_its_second_sighting(lfp, monkeypatch):
     """Round 6 (the advisor's round-5 finding): recording a pipeline costs a capture and an instantiation, several times the call
-    -- so the first sighting of a request is served stage by stage, the second records, later ones replay; at most 8 recordings
+    -- so the first sighting of a request is served by the pipeline's plain launches (one wait), the second records, later ones replay; at most 8 recordings
     are kept (the least recently used one makes room); a call that moves a buffer the recordings name retires them, and a request
     seen before is then recorded again at once.  LF_MKD_DETECT_RECORD_AFTER (read at creation) moves the threshold; handles in a
     two-launch keypoint mode never record.  lf_mkd_detect_recordings is the window."""
@@ -593,7 +593,7 @@ def test_a_request_is_recorded_on_its_second_sighting(lfp, monkeypatch):
     h = lfp.MkdHandle(**kw)
     assert h.detect_recordings() == (0, 0, 0)
     first = h.detect(u8, 100, 0.0, 512)
-    assert h.detect_recordings() == (0, 0, 1)                # seen, served stage by stage
+    assert h.detect_recordings() == (0, 0, 1)                # seen, served without a recording
     again = h.detect(u8, 100, 0.0, 512)
     assert h.detect_recordings() == (1, 0, 1)                # recorded
     for _ in range(3):

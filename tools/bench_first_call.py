@@ -46,8 +46,35 @@ for scale in (0.25, 0.47, 1.0):
                 ts = calls(img, w, h, 6, ra)
                 say(f"{w:>7}x{h:<4} {name:>4} {ra:>12} {which:>7} | " + " ".join(f"{t:9.3f}" for t in ts))
 os.environ.pop("LF_MKD_DETECT_RECORD_AFTER", None)
-say("record_after 1 (default): call 1 = stage by stage, call 2 = recording + launch, call 3.. = replay")
+say("record_after 1 (default): call 1 = the pipeline's launches, unrecorded (a fresh handle also allocates its scratch), call 2 = recording + launch, call 3.. = replay")
 say("record_after 0 (round 5):  call 1 = recording + launch, call 2.. = replay")
+if len(sys.argv) > 1:
+    with open(sys.argv[1], "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+# ---- what the reference's example does: ONE handle sized for the largest image, every image detected once at its own size ----
+# (examples/match_images/src/main.rs:44-76).  The handle's scratch exists after its first call; what a NEW request then costs:
+say("")
+say("one handle (max 4096 x 3072), a first call on another frame size to allocate its scratch, then each frame size ONCE (first sighting")
+say("of its request), then twice more (recording, replay); the stage-by-stage form (LF_MKD_FLAG_DETECT_STEPWISE) beside it")
+for name in ("u8", "f32"):
+    for flags, label in ((0, "default"), (lfp.FLAG_DETECT_STEPWISE, "stepwise")):
+        lf = lfp.MkdHandle(max_features=3000, max_image_width=4096, max_image_height=3072, n_scales=3, max_blobs=15000, flags=flags)
+        kps, desc = np.empty((3000, 5), np.float32), np.empty((3000, 128), np.float32)
+        u8, f32 = open_image(0.3)
+        lf.detect_into(u8 if name == "u8" else f32, 2000, 0.0, kps, desc)
+        row = []
+        for scale in (0.25, 0.47, 1.0):
+            u8, f32 = open_image(scale)
+            img = u8 if name == "u8" else f32
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                lf.detect_into(img, 2000, 0.0, kps, desc)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            row.append(f"{img.shape[1]}x{img.shape[0]}: " + " / ".join(f"{t:.3f}" for t in ts))
+        say(f"{name:>4} {label:>9} | " + "   ".join(row))
+        lf.close()
 if len(sys.argv) > 1:
     with open(sys.argv[1], "w") as f:
         f.write("\n".join(lines) + "\n")
