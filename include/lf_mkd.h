@@ -191,7 +191,9 @@ int lf_mkd_set_images_device(lf_mkd *h, const float *d_images, uint32_t n_frames
  * Within a form a descriptor's bits depend on its keypoint and its frame alone (whatever else is in the request, however
  * often it is computed).  Between forms the pooled sums round differently: descriptors agree to ~3e-6 relative L2 (worst
  * measured 6.5e-6 over 32 000 soak launches; the tests hold 1e-5), both within the same distance of the reference.  LF_MKD_KP_SPLIT=1 in the
- * environment keeps every request in the whole-patch form (2 / 4: that row-split form wherever it fits). */
+ * environment keeps every request in the whole-patch form (2 / 4: that row-split form wherever it fits).  (In the row-split
+ * form a workgroup waits for its partners' partial sums; the wait is bounded, and a partial sum that never arrived -- a fault,
+ * never observed -- is counted: lf_mkd_describe_keypoints then returns LF_MKD_ERR_HIP.) */
 int lf_mkd_describe_keypoints(lf_mkd *h, const lf_mkd_keypoint *kps, uint64_t n, float *out);
 int lf_mkd_describe_keypoints_device(lf_mkd *h, const lf_mkd_keypoint *d_kps, uint64_t n,
                                      float *d_out, void *stream);
