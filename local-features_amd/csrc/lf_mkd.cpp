@@ -612,7 +612,7 @@ std::vector<uint32_t> plan_cuts(int n_layers, uint32_t width, uint32_t height, b
             char *end = nullptr;
             const double f = strtod(q, &end);
             if (end == q) break;
-            c.push_back(uint32_t(double(height) * std::min(std::max(f, 0.0), 1.0)));
+            c.push_back(uint32_t(double(height) * (f >= 0.0 ? std::min(f, 1.0) : 0.0)));     // (a NaN counts as 0)
             q = *end == ',' ? end + 1 : end;
         }
         std::sort(c.begin(), c.end());
